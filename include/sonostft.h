@@ -1,0 +1,194 @@
+/*
+ * sonostft.h -- C ABI of libsonostft, the MI355X (gfx950) implementation of the
+ * SonoRadar spectrogram hot path.
+ *
+ * Every entry point is the C-level counterpart of one export of the reference's
+ * wasm module, whose raw signatures are declared in
+ *   modules/spectrogram_wasm_bg.wasm.d.ts:4-38
+ * and whose semantics are in spectrogram-wasm/src/lib.rs.  Where the wasm ABI
+ * passes (ptr, len) into wasm linear memory and returns a freshly allocated
+ * (ptr, len) pair, this ABI takes (ptr, len) host pointers in and writes into a
+ * caller-owned buffer of stated capacity; `sono_frames_for` sizes that buffer.
+ *
+ * Conventions
+ *   - Plain C types only; no exceptions cross the boundary.  Every function that
+ *     can fail returns an int status (SONO_OK == 0); `sono_last_error()` gives a
+ *     message for the calling thread's most recent failure.
+ *   - One engine = one mutable object bound to one GPU and one HIP stream, not
+ *     re-entrant (same as one wasm SpectrogramEngine, whose borrow flag throws
+ *     on re-entry).  Different engines may be used from different threads.
+ *   - Entry points ending in `_dev` take DEVICE pointers (hipMalloc memory on the
+ *     engine's GPU), launch asynchronously on the engine's stream and do not
+ *     synchronise; the others take host pointers and return when results are in
+ *     the caller's buffer.
+ *   - The library never computes on the CPU: with no usable gfx950 device every
+ *     compute entry point fails with SONO_EDEVICE.
+ */
+#ifndef SONOSTFT_H
+#define SONOSTFT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SONO_OK        0
+#define SONO_EINVAL    1   /* bad argument (null handle, noverlap >= fft_size, unsupported fft_size ...) */
+#define SONO_ENOMEM    2   /* host or device allocation failed */
+#define SONO_EDEVICE   3   /* no usable GPU / HIP runtime error */
+#define SONO_ECAPACITY 4   /* caller's output buffer is too small */
+
+typedef struct sono_engine sono_engine;       /* SpectrogramEngine, lib.rs:8-35 */
+typedef struct sono_waveform sono_waveform;   /* WaveformEngine,    lib.rs:844-849 */
+
+/* ---- library ------------------------------------------------------------ */
+
+/* Message for the calling thread's last failed call ("" if none). */
+const char *sono_last_error(void);
+
+/* Number of visible GPUs (0 if none / no HIP runtime). */
+int sono_device_count(void);
+
+/* ABI version of this header (bumped on incompatible change). */
+uint32_t sono_abi_version(void);
+
+/* Frame count rule of lib.rs:118-123: n >= N ? (n - N) / (N - noverlap) + 1 : 0.
+ * Returns 0 when noverlap >= fft_size (the reference panics there). */
+size_t sono_frames_for(size_t n_samples, uint32_t fft_size, uint32_t noverlap);
+
+/* ---- SpectrogramEngine -------------------------------------------------- */
+
+/* spectrogramengine_new (wasm.d.ts:22; lib.rs:45-79).  fft_size: power of two in
+ * [256, 4096].  window: one of the ten names of lib.rs:698-776; any other string
+ * selects Hann, as the reference does.  has_alpha == 0 encodes Option::None
+ * (alpha = 0.16).  device < 0 selects the current HIP device. */
+int sono_engine_create(uint32_t fft_size, const char *window, int has_alpha, float alpha,
+                       int device, sono_engine **out);
+
+/* __wbg_spectrogramengine_free (wasm.d.ts:4).  NULL is ignored. */
+void sono_engine_destroy(sono_engine *e);
+
+uint32_t sono_engine_fft_size(const sono_engine *e);      /* spectrogramengine_get_fft_size   :14 */
+uint32_t sono_engine_freq_bins(const sono_engine *e);     /* spectrogramengine_get_freq_bins  :15, = N/2 */
+uint32_t sono_engine_num_filters(const sono_engine *e);   /* spectrogramengine_get_num_filters:17 */
+int sono_engine_device(const sono_engine *e);
+
+/* spectrogramengine_get_window_values (wasm.d.ts:20; lib.rs:165): copies N floats. */
+int sono_engine_window_values(const sono_engine *e, float *out, size_t cap);
+
+/* spectrogramengine_load_filter_bank / _clear_filter_bank (wasm.d.ts:21,10;
+ * lib.rs:90-102).  The weights are used with row stride N/2 (lib.rs:317-326). */
+int sono_engine_load_filter_bank(sono_engine *e, const float *flat_weights, size_t len,
+                                 uint32_t num_filters);
+int sono_engine_clear_filter_bank(sono_engine *e);
+
+/* spectrogramengine_release_memory (wasm.d.ts:23; lib.rs:681-693): drops the
+ * filter bank, the colour map, the last call's peak state and device scratch. */
+int sono_engine_release_memory(sono_engine *e);
+
+/* spectrogramengine_compute_spectrogram (wasm.d.ts:11; lib.rs:113-161).
+ * out: frames x N/2 linear magnitudes, frame-major; cap in floats. */
+int sono_stft_mag_f32(sono_engine *e, const float *x, size_t n, uint32_t noverlap,
+                      float *out, size_t cap, size_t *frames);
+
+/* spectrogramengine_compute_spectrogram_u8 (wasm.d.ts:13; lib.rs:199-304).
+ * out: frames x out_bins bytes (out_bins = num_filters if a bank is loaded, else
+ * N/2); cap in bytes.  Also records per-frame peak bin / peak magnitude and the
+ * global maximum for the three getters below. */
+int sono_stft_u8(sono_engine *e, const float *x, size_t n, uint32_t noverlap,
+                 float gain_db, float range_db, uint8_t *out, size_t cap, size_t *frames);
+
+/* spectrogramengine_get_peaks (wasm.d.ts:19; lib.rs:349-387).  *count = frames of
+ * the last u8 call, or 0 (empty result) before any call / when the global
+ * maximum is <= 0.  Bins below threshold are 0xFFFF. */
+int sono_peaks_u16(const sono_engine *e, float threshold_ratio, uint16_t *out, size_t cap,
+                   size_t *count);
+
+/* spectrogramengine_get_peak_magnitudes (wasm.d.ts:18; lib.rs:398-431). */
+int sono_peak_mags_f32(const sono_engine *e, float threshold_ratio, float *out, size_t cap,
+                       size_t *count);
+
+/* spectrogramengine_get_global_max (wasm.d.ts:16; lib.rs:441-443). */
+float sono_global_max(const sono_engine *e);
+
+/* spectrogramengine_set_color_map (wasm.d.ts:24; lib.rs:450-471): len != 1024 is
+ * silently ignored, as in the reference. */
+int sono_engine_set_color_map(sono_engine *e, const uint8_t *rgba, size_t len);
+
+/* spectrogramengine_set_spectrum_config (wasm.d.ts:25; lib.rs:475-479): stored only. */
+int sono_engine_set_spectrum_config(sono_engine *e, const char *scale, float freq_min,
+                                    float freq_max);
+
+/* spectrogramengine_compute_spectrogram_image (wasm.d.ts:12; lib.rs:494-616).
+ * out: width*height*4 RGBA bytes; all zero when no colour map is set. */
+int sono_spectrogram_image(sono_engine *e, const float *x, size_t n, uint32_t width,
+                           uint32_t height, uint32_t noverlap, float gain_db, float range_db,
+                           uint8_t *out, size_t cap);
+
+/* ---- device-resident / batched forms (no wasm counterpart: the wasm call takes
+ * one channel per call; these run the same computation over data that already
+ * lives in HBM, many recordings per launch) ---------------------------------- */
+
+typedef struct sono_batch {
+    const float *d_samples;     /* device: stream s starts at d_samples + s*stream_stride */
+    size_t n_streams;           /* independent recordings / channels / time chunks */
+    size_t stream_stride;       /* samples between stream starts (>= samples_per_stream) */
+    size_t samples_per_stream;  /* every stream has this many samples */
+} sono_batch;
+
+/* Fused STFT -> dB -> u8 over a batch.  Outputs are device pointers; stream s,
+ * frame f lands at row s*frames_per_stream + f.  d_peak_bin / d_peak_mag /
+ * d_gmax_bits may be NULL.  d_gmax_bits is ONE uint32 holding the f32 bit pattern
+ * of the running maximum; the caller zeroes it (it is only ever raised).
+ * hip_stream: a hipStream_t, or NULL for the engine's stream. */
+int sono_stft_u8_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap,
+                     float gain_db, float range_db,
+                     uint8_t *d_out, uint16_t *d_peak_bin, float *d_peak_mag,
+                     uint32_t *d_gmax_bits, void *hip_stream);
+
+/* Linear-magnitude form of the same (lib.rs:113-161 over a batch). */
+int sono_stft_mag_f32_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap,
+                          float *d_out, void *hip_stream);
+
+/* Blocks until the engine's stream is idle. */
+int sono_engine_synchronize(sono_engine *e);
+
+/* ---- free functions ----------------------------------------------------- */
+
+/* compute_power_spectrum (wasm.d.ts:6; lib.rs:1019-1118).  has_overlap == 0
+ * encodes Option::None.  out: N/2+1 dB values; *bins = 0 for the reference's
+ * empty result (n == 0 or n < fft_size).  device < 0: current device. */
+int sono_power_spectrum(const float *x, size_t n, uint32_t sample_rate, uint32_t fft_size,
+                        const char *window, int has_overlap, float overlap_percent,
+                        int device, float *out, size_t cap, size_t *bins);
+
+/* find_peak_frequency_from_spectrum (wasm.d.ts:9; lib.rs:1132-1179).  Host only. */
+float sono_find_peak_frequency(const float *spectrum, size_t len, uint32_t sample_rate,
+                               uint32_t fft_size, float flow_hz, float fhigh_hz);
+
+/* compute_wave_peaks (wasm.d.ts:7; lib.rs:794-824) and find_global_max
+ * (wasm.d.ts:8; lib.rs:834-840).  Host only (UI helpers, O(n) scans). */
+int sono_wave_peaks(const float *x, size_t n, size_t num_peaks, float *out, size_t cap,
+                    size_t *count);
+float sono_find_global_max(const float *x, size_t n);
+
+/* ---- WaveformEngine (wasm.d.ts:5,26-33; lib.rs:851-1000).  Host only. ------ */
+int sono_waveform_create(sono_waveform **out);                                   /* waveformengine_new */
+void sono_waveform_destroy(sono_waveform *w);                                    /* __wbg_waveformengine_free */
+int sono_waveform_resize(sono_waveform *w, size_t num_channels);                 /* waveformengine_resize */
+int sono_waveform_load_channel(sono_waveform *w, size_t idx, const float *x, size_t n); /* _load_channel */
+size_t sono_waveform_channel_length(const sono_waveform *w, size_t idx);         /* _get_channel_length */
+size_t sono_waveform_num_channels(const sono_waveform *w);                       /* _get_num_channels */
+int sono_waveform_clear(sono_waveform *w);                                       /* waveformengine_clear */
+int sono_waveform_release_memory(sono_waveform *w);                              /* _release_memory */
+/* waveformengine_get_peaks_in_range: writes max(target_width, 1) floats. */
+int sono_waveform_peaks_in_range(const sono_waveform *w, size_t idx, size_t start_sample,
+                                 size_t end_sample, size_t target_width, float *out,
+                                 size_t cap, size_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SONOSTFT_H */

@@ -1,0 +1,352 @@
+"""spectrogram_amd -- Python host side of libsonostft (MI355X spectrogram hot path).
+
+The classes and functions here carry the names, argument meaning and error
+behaviour of the reference's wasm export surface
+(modules/spectrogram_wasm.d.ts:4-271), so code written against
+`SpectrogramEngine`, `WaveformEngine`, `compute_power_spectrum`, ... of the wasm
+module reads the same against this package.  Every numeric call goes through the
+C ABI of include/sonostft.h into HIP kernels; there is no CPU compute path, and
+a missing library or GPU raises instead of falling back.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+__all__ = [
+    "SpectrogramEngine", "WaveformEngine", "compute_power_spectrum",
+    "find_peak_frequency_from_spectrum", "compute_wave_peaks", "find_global_max",
+    "frames_for", "device_count", "lib", "LIB_PATH", "SonoError",
+]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsonostft.so")
+
+SONO_OK, SONO_EINVAL, SONO_ENOMEM, SONO_EDEVICE, SONO_ECAPACITY = 0, 1, 2, 3, 4
+
+_f32p = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+_u16p = C.POINTER(C.c_uint16)
+_u32p = C.POINTER(C.c_uint32)
+_szp = C.POINTER(C.c_size_t)
+
+
+class SonoError(RuntimeError):
+    """A non-zero status from libsonostft (the wasm module throws a JS Error)."""
+
+    def __init__(self, status, message):
+        super().__init__(f"libsonostft status {status}: {message}")
+        self.status = status
+
+
+class Batch(C.Structure):
+    """struct sono_batch of include/sonostft.h."""
+    _fields_ = [("d_samples", C.c_void_p), ("n_streams", C.c_size_t),
+                ("stream_stride", C.c_size_t), ("samples_per_stream", C.c_size_t)]
+
+
+_lib = None
+
+_SIGNATURES = {
+    "sono_last_error": (C.c_char_p, []),
+    "sono_device_count": (C.c_int, []),
+    "sono_abi_version": (C.c_uint32, []),
+    "sono_frames_for": (C.c_size_t, [C.c_size_t, C.c_uint32, C.c_uint32]),
+    "sono_engine_create": (C.c_int, [C.c_uint32, C.c_char_p, C.c_int, C.c_float, C.c_int, C.POINTER(C.c_void_p)]),
+    "sono_engine_destroy": (None, [C.c_void_p]),
+    "sono_engine_fft_size": (C.c_uint32, [C.c_void_p]),
+    "sono_engine_freq_bins": (C.c_uint32, [C.c_void_p]),
+    "sono_engine_num_filters": (C.c_uint32, [C.c_void_p]),
+    "sono_engine_device": (C.c_int, [C.c_void_p]),
+    "sono_engine_window_values": (C.c_int, [C.c_void_p, _f32p, C.c_size_t]),
+    "sono_engine_load_filter_bank": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_uint32]),
+    "sono_engine_clear_filter_bank": (C.c_int, [C.c_void_p]),
+    "sono_engine_release_memory": (C.c_int, [C.c_void_p]),
+    "sono_engine_synchronize": (C.c_int, [C.c_void_p]),
+    "sono_stft_mag_f32": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_uint32, _f32p, C.c_size_t, _szp]),
+    "sono_stft_u8": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_uint32, C.c_float, C.c_float, _u8p,
+                               C.c_size_t, _szp]),
+    "sono_peaks_u16": (C.c_int, [C.c_void_p, C.c_float, _u16p, C.c_size_t, _szp]),
+    "sono_peak_mags_f32": (C.c_int, [C.c_void_p, C.c_float, _f32p, C.c_size_t, _szp]),
+    "sono_global_max": (C.c_float, [C.c_void_p]),
+    "sono_engine_set_color_map": (C.c_int, [C.c_void_p, _u8p, C.c_size_t]),
+    "sono_engine_set_spectrum_config": (C.c_int, [C.c_void_p, C.c_char_p, C.c_float, C.c_float]),
+    "sono_spectrogram_image": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_float, C.c_float, _u8p, C.c_size_t]),
+    "sono_stft_u8_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_float, C.c_float,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sono_stft_mag_f32_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_void_p, C.c_void_p]),
+    "sono_power_spectrum": (C.c_int, [_f32p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_char_p, C.c_int,
+                                      C.c_float, C.c_int, _f32p, C.c_size_t, _szp]),
+    "sono_find_peak_frequency": (C.c_float, [_f32p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_float, C.c_float]),
+    "sono_wave_peaks": (C.c_int, [_f32p, C.c_size_t, C.c_size_t, _f32p, C.c_size_t, _szp]),
+    "sono_find_global_max": (C.c_float, [_f32p, C.c_size_t]),
+    "sono_waveform_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "sono_waveform_destroy": (None, [C.c_void_p]),
+    "sono_waveform_resize": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "sono_waveform_load_channel": (C.c_int, [C.c_void_p, C.c_size_t, _f32p, C.c_size_t]),
+    "sono_waveform_channel_length": (C.c_size_t, [C.c_void_p, C.c_size_t]),
+    "sono_waveform_num_channels": (C.c_size_t, [C.c_void_p]),
+    "sono_waveform_clear": (C.c_int, [C.c_void_p]),
+    "sono_waveform_release_memory": (C.c_int, [C.c_void_p]),
+    "sono_waveform_peaks_in_range": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
+                                               _f32p, C.c_size_t, _szp]),
+}
+
+
+def lib():
+    """The loaded libsonostft.so.  Raises if the in-tree build is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m spectrogram_amd.build` "
+                "(hipcc, gfx950).  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(status):
+    if status != SONO_OK:
+        raise SonoError(status, lib().sono_last_error().decode("utf-8", "replace"))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t=_f32p):
+    return a.ctypes.data_as(t)
+
+
+def device_count():
+    return lib().sono_device_count()
+
+
+def frames_for(n_samples, fft_size, noverlap):
+    """Frame count rule of lib.rs:118-123."""
+    return lib().sono_frames_for(n_samples, fft_size, noverlap)
+
+
+class SpectrogramEngine:
+    """SpectrogramEngine of spectrogram_wasm.d.ts:4-140, computing on the GPU.
+
+    SpectrogramEngine(fft_size, window_func, alpha=None, device=-1)
+    """
+
+    def __init__(self, fft_size, window_func, alpha=None, device=-1):
+        h = C.c_void_p()
+        _check(lib().sono_engine_create(int(fft_size), str(window_func).encode(), 0 if alpha is None else 1,
+                                        0.0 if alpha is None else float(alpha), int(device), C.byref(h)))
+        self._h = h
+
+    # -- lifetime ---------------------------------------------------------
+    def free(self):
+        if getattr(self, "_h", None):
+            lib().sono_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+
+    def _handle(self):
+        if not self._h:
+            raise SonoError(SONO_EINVAL, "null pointer passed to rust")   # the wasm glue's use-after-free message
+        return self._h
+
+    # -- getters ------------------------------------------------------------
+    def get_fft_size(self):
+        return lib().sono_engine_fft_size(self._handle())
+
+    def get_freq_bins(self):
+        return lib().sono_engine_freq_bins(self._handle())
+
+    def get_num_filters(self):
+        return lib().sono_engine_num_filters(self._handle())
+
+    def get_window_values(self):
+        out = np.empty(self.get_fft_size(), dtype=np.float32)
+        _check(lib().sono_engine_window_values(self._handle(), _p(out), out.size))
+        return out
+
+    # -- filter bank ----------------------------------------------------------
+    def load_filter_bank(self, flat_weights, num_filters):
+        w = _f32(flat_weights)
+        _check(lib().sono_engine_load_filter_bank(self._handle(), _p(w), w.size, int(num_filters)))
+
+    def clear_filter_bank(self):
+        _check(lib().sono_engine_clear_filter_bank(self._handle()))
+
+    # -- the hot path -------------------------------------------------------------
+    def compute_spectrogram(self, audio_data, noverlap):
+        """-> Float32Array, frames x fft_size/2 linear magnitudes (lib.rs:113-161)."""
+        x = _f32(audio_data)
+        n_fft = self.get_fft_size()
+        F = frames_for(x.size, n_fft, int(noverlap)) if 0 <= noverlap < n_fft else 0
+        out = np.empty(F * (n_fft // 2), dtype=np.float32)
+        got = C.c_size_t(0)
+        _check(lib().sono_stft_mag_f32(self._handle(), _p(x), x.size, int(noverlap), _p(out), out.size,
+                                       C.byref(got)))
+        return out[: got.value * (n_fft // 2)]
+
+    def compute_spectrogram_u8(self, audio_data, noverlap, gain_db, range_db):
+        """-> Uint8Array, frames x bins dB codes (lib.rs:199-304)."""
+        x = _f32(audio_data)
+        n_fft = self.get_fft_size()
+        nf = self.get_num_filters()
+        bins = nf if nf > 0 else n_fft // 2
+        F = frames_for(x.size, n_fft, int(noverlap)) if 0 <= noverlap < n_fft else 0
+        out = np.empty(F * bins, dtype=np.uint8)
+        got = C.c_size_t(0)
+        _check(lib().sono_stft_u8(self._handle(), _p(x), x.size, int(noverlap), float(gain_db), float(range_db),
+                                  _p(out, _u8p), out.size, C.byref(got)))
+        self._last_frames = got.value
+        return out[: got.value * bins]
+
+    def get_peaks(self, threshold_ratio):
+        cap = max(getattr(self, "_last_frames", 0), 1)
+        out = np.empty(cap, dtype=np.uint16)
+        got = C.c_size_t(0)
+        _check(lib().sono_peaks_u16(self._handle(), float(threshold_ratio), _p(out, _u16p), cap, C.byref(got)))
+        return out[: got.value]
+
+    def get_peak_magnitudes(self, threshold_ratio):
+        cap = max(getattr(self, "_last_frames", 0), 1)
+        out = np.empty(cap, dtype=np.float32)
+        got = C.c_size_t(0)
+        _check(lib().sono_peak_mags_f32(self._handle(), float(threshold_ratio), _p(out), cap, C.byref(got)))
+        return out[: got.value]
+
+    def get_global_max(self):
+        return float(lib().sono_global_max(self._handle()))
+
+    # -- image path (cold) ----------------------------------------------------------
+    def set_color_map(self, colors):
+        c = np.ascontiguousarray(colors, dtype=np.uint8)
+        _check(lib().sono_engine_set_color_map(self._handle(), _p(c, _u8p), c.size))
+
+    def set_spectrum_config(self, scale, freq_min, freq_max):
+        _check(lib().sono_engine_set_spectrum_config(self._handle(), str(scale).encode(), float(freq_min),
+                                                     float(freq_max)))
+
+    def compute_spectrogram_image(self, audio_data, width, height, noverlap, gain_db, range_db):
+        x = _f32(audio_data)
+        out = np.zeros(int(width) * int(height) * 4, dtype=np.uint8)
+        _check(lib().sono_spectrogram_image(self._handle(), _p(x), x.size, int(width), int(height), int(noverlap),
+                                            float(gain_db), float(range_db), _p(out, _u8p), out.size))
+        return out
+
+    def release_memory(self):
+        _check(lib().sono_engine_release_memory(self._handle()))
+        self._last_frames = 0
+
+    # -- device-resident forms (batch / server use; no wasm counterpart) -------------
+    def stft_u8_dev(self, d_samples, n_streams, stream_stride, samples_per_stream, noverlap, gain_db, range_db,
+                    d_out, d_peak_bin=0, d_peak_mag=0, d_gmax_bits=0, stream=0):
+        """Launch the fused kernel over samples already in HBM.  Pointer arguments
+        are raw device addresses (e.g. torch.Tensor.data_ptr()); asynchronous."""
+        b = Batch(d_samples, n_streams, stream_stride, samples_per_stream)
+        _check(lib().sono_stft_u8_dev(self._handle(), C.byref(b), int(noverlap), float(gain_db), float(range_db),
+                                      d_out, d_peak_bin or None, d_peak_mag or None, d_gmax_bits or None,
+                                      stream or None))
+
+    def stft_mag_f32_dev(self, d_samples, n_streams, stream_stride, samples_per_stream, noverlap, d_out, stream=0):
+        b = Batch(d_samples, n_streams, stream_stride, samples_per_stream)
+        _check(lib().sono_stft_mag_f32_dev(self._handle(), C.byref(b), int(noverlap), d_out, stream or None))
+
+    def synchronize(self):
+        _check(lib().sono_engine_synchronize(self._handle()))
+
+
+class WaveformEngine:
+    """WaveformEngine of spectrogram_wasm.d.ts:142-211 (host only: O(n) max-abs scans)."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        _check(lib().sono_waveform_create(C.byref(h)))
+        self._h = h
+
+    def free(self):
+        if getattr(self, "_h", None):
+            lib().sono_waveform_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def resize(self, num_channels):
+        _check(lib().sono_waveform_resize(self._h, int(num_channels)))
+
+    def load_channel(self, channel_idx, data):
+        x = _f32(data)
+        _check(lib().sono_waveform_load_channel(self._h, int(channel_idx), _p(x), x.size))
+
+    def get_peaks_in_range(self, channel_idx, start_sample, end_sample, target_width):
+        out = np.empty(max(int(target_width), 1), dtype=np.float32)
+        got = C.c_size_t(0)
+        _check(lib().sono_waveform_peaks_in_range(self._h, int(channel_idx), int(start_sample), int(end_sample),
+                                                  int(target_width), _p(out), out.size, C.byref(got)))
+        return out[: got.value]
+
+    def get_channel_length(self, channel_idx):
+        return lib().sono_waveform_channel_length(self._h, int(channel_idx))
+
+    def get_num_channels(self):
+        return lib().sono_waveform_num_channels(self._h)
+
+    def clear(self):
+        _check(lib().sono_waveform_clear(self._h))
+
+    def release_memory(self):
+        _check(lib().sono_waveform_release_memory(self._h))
+
+
+def compute_power_spectrum(audio_data, sample_rate, fft_size, window_type, overlap_percent=None, device=-1):
+    """spectrogram_wasm.d.ts:226 / lib.rs:1019-1118 -> Float32Array of fft_size/2+1 dB values (or empty)."""
+    x = _f32(audio_data)
+    out = np.empty(int(fft_size) // 2 + 1, dtype=np.float32)
+    got = C.c_size_t(0)
+    _check(lib().sono_power_spectrum(_p(x), x.size, int(sample_rate), int(fft_size), str(window_type).encode(),
+                                     0 if overlap_percent is None else 1,
+                                     0.0 if overlap_percent is None else float(overlap_percent), int(device),
+                                     _p(out), out.size, C.byref(got)))
+    return out[: got.value]
+
+
+def find_peak_frequency_from_spectrum(spectrum, sample_rate, fft_size, flow_hz, fhigh_hz):
+    """spectrogram_wasm.d.ts:271 / lib.rs:1132-1179."""
+    s = _f32(spectrum)
+    return float(lib().sono_find_peak_frequency(_p(s), s.size, int(sample_rate), int(fft_size), float(flow_hz),
+                                                float(fhigh_hz)))
+
+
+def compute_wave_peaks(channel_data, num_peaks):
+    """spectrogram_wasm.d.ts:245 / lib.rs:794-824."""
+    x = _f32(channel_data)
+    out = np.empty(max(int(num_peaks), 1), dtype=np.float32)
+    got = C.c_size_t(0)
+    _check(lib().sono_wave_peaks(_p(x), x.size, int(num_peaks), _p(out), out.size, C.byref(got)))
+    return out[: got.value]
+
+
+def find_global_max(channel_data):
+    """spectrogram_wasm.d.ts:256 / lib.rs:834-840."""
+    x = _f32(channel_data)
+    return float(lib().sono_find_global_max(_p(x), x.size))

@@ -1,0 +1,77 @@
+"""Builds libsonostft.so (HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+  python -m spectrogram_amd.build          # incremental
+  python -m spectrogram_amd.build --force
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the
+resulting spectrogram_amd/lib/libsonostft.so travels to the GPU box as is.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "build")
+LIB = os.path.join(LIBDIR, "libsonostft.so")
+
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+HIP_SOURCES = ["sono_kernels.hip", "sono_tile.hip", "sono_capi.hip"]
+CXX_SOURCES = ["sono_host.cpp"]
+HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _all_headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "sonostft.h"))
+    return hs
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    headers = _all_headers()
+    objs = []
+    jobs = []
+    for src in HIP_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJDIR, src + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + headers):
+            jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
+    for src in CXX_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJDIR, src + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + headers):
+            jobs.append(["g++"] + CXX_FLAGS + ["-c", s, "-o", o])
+    procs = []
+    for cmd in jobs:
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("build failed: " + " ".join(cmd))
+    if jobs or force or not os.path.exists(LIB):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,622 @@
+// sono_capi.hip -- the C ABI of libsonostft (include/sonostft.h): engine objects,
+// device buffers, host<->device staging and kernel dispatch.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/sonostft.h"
+#include "sono_core.h"
+#include "sono_host.h"
+#include "sono_kernels.h"
+#include "sono_tables.h"
+#include "sono_tile.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    (void)hipGetLastError();   // clear the sticky error so that later calls report their own
+    return fail(e == hipErrorOutOfMemory ? SONO_ENOMEM : SONO_EDEVICE,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                              \
+    do {                                                           \
+        hipError_t _e = (expr);                                    \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);          \
+    } while (0)
+
+// A device allocation that only ever grows.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes; else p = nullptr;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Tables {
+    unsigned int N = 0;
+    float *d_window = nullptr;
+    float2 *d_tw_half = nullptr;   // N/2 entries
+    float2 *d_tw_full = nullptr;   // N/2 + 1 entries
+    sono::TileTables tile;         // extra tables of the register-tiled kernel (may be empty)
+    void release()
+    {
+        if (d_window) (void)hipFree(d_window);
+        if (d_tw_half) (void)hipFree(d_tw_half);
+        if (d_tw_full) (void)hipFree(d_tw_full);
+        sono::tile_tables_release(tile);
+        d_window = nullptr; d_tw_half = nullptr; d_tw_full = nullptr;
+    }
+};
+
+int build_tables(unsigned int N, const float *window, Tables &t)
+{
+    t.N = N;
+    std::vector<float2> twh = sono::make_twiddles(N / 2, N / 2);
+    std::vector<float2> twf = sono::make_twiddles(N, N / 2 + 1);
+    HIP_TRY(hipMalloc((void **)&t.d_window, N * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&t.d_tw_half, twh.size() * sizeof(float2)));
+    HIP_TRY(hipMalloc((void **)&t.d_tw_full, twf.size() * sizeof(float2)));
+    HIP_TRY(hipMemcpy(t.d_window, window, N * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.d_tw_half, twh.data(), twh.size() * sizeof(float2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.d_tw_full, twf.data(), twf.size() * sizeof(float2), hipMemcpyHostToDevice));
+    hipError_t e = sono::tile_tables_build(N, window, t.tile);
+    if (e != hipSuccess) return hip_fail(e, "tile_tables_build");
+    return SONO_OK;
+}
+
+bool force_generic()
+{
+    const char *v = std::getenv("SONO_FORCE_GENERIC");
+    return v && v[0] && v[0] != '0';
+}
+
+// Picks the kernel for one launch.  The register-tiled kernel covers the common
+// sizes; everything else (and SONO_FORCE_GENERIC=1, used by the tests to compare
+// the two) goes through the generic LDS-staged kernel.
+hipError_t dispatch_stft(int mode, const sono::StftArgs &a, const Tables &t, hipStream_t stream)
+{
+    if (!force_generic() && sono::tile_supports(mode, a, t.tile))
+        return sono::launch_stft_tile(mode, a, t.tile, stream);
+    return sono::launch_stft_generic(mode, a, stream);
+}
+
+class DeviceGuard {
+public:
+    explicit DeviceGuard(int dev) : ok_(false), prev_(-1)
+    {
+        if (hipGetDevice(&prev_) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (dev >= 0 && dev != prev_) {
+            if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return; }
+            changed_ = true;
+        }
+        ok_ = true;
+    }
+    ~DeviceGuard() { if (changed_) (void)hipSetDevice(prev_); }
+    bool ok() const { return ok_; }
+private:
+    bool ok_, changed_ = false;
+    int prev_;
+};
+
+}  // namespace
+
+struct sono_engine {
+    unsigned int N = 0;
+    int device = 0;
+    float alpha = 0.16f;
+    std::string window_name;
+    std::vector<float> window;
+    Tables tables;
+    hipStream_t stream = nullptr;
+    // device scratch of the host-pointer entry points
+    DevBuf d_in, d_out, d_peak_bin, d_peak_mag, d_gmax, d_mags, d_bank;
+    // filter bank (lib.rs:20-22)
+    std::vector<float> bank;
+    unsigned int num_filters = 0;
+    bool use_bank = false;
+    // state left behind by the last u8 call (lib.rs:24-26)
+    bool has_last = false;
+    std::vector<uint16_t> last_peak_bin;
+    std::vector<float> last_peak_mag;
+    float last_gmax = 0.0f;
+    // colour map / config (lib.rs:28-32)
+    std::vector<uint32_t> color_map;
+    std::string scale = "linear";
+    float freq_min = 0.0f, freq_max = 0.0f;
+};
+
+struct sono_waveform {
+    std::vector<std::vector<float>> channels;
+};
+
+extern "C" {
+
+const char *sono_last_error(void) { return g_err.c_str(); }
+
+uint32_t sono_abi_version(void) { return 1; }
+
+int sono_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+size_t sono_frames_for(size_t n, uint32_t fft_size, uint32_t noverlap)
+{
+    if (fft_size == 0 || noverlap >= fft_size) return 0;
+    const size_t step = fft_size - noverlap;
+    return n >= fft_size ? (n - fft_size) / step + 1 : 0;
+}
+
+int sono_engine_create(uint32_t fft_size, const char *window, int has_alpha, float alpha, int device,
+                       sono_engine **out)
+{
+    if (!out) return fail(SONO_EINVAL, "sono_engine_create: out is NULL");
+    *out = nullptr;
+    if (!sono::supported_fft_size(fft_size))
+        return fail(SONO_EINVAL, "sono_engine_create: fft_size must be a power of two in [256, 4096]");
+    if (sono_device_count() <= 0) return fail(SONO_EDEVICE, "sono_engine_create: no HIP device available");
+    int dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return hip_fail(hipGetLastError(), "hipGetDevice");
+    DeviceGuard guard(dev);
+    if (!guard.ok()) return fail(SONO_EDEVICE, "sono_engine_create: cannot select the device");
+    sono_engine *e = new (std::nothrow) sono_engine();
+    if (!e) return fail(SONO_ENOMEM, "sono_engine_create: out of host memory");
+    e->N = fft_size;
+    e->device = dev;
+    e->alpha = has_alpha ? alpha : 0.16f;                  // lib.rs:47
+    e->window_name = window ? window : "";
+    e->window.resize(fft_size);
+    sono::host_make_window(e->window_name.c_str(), fft_size, e->alpha, e->window.data());
+    int rc = build_tables(fft_size, e->window.data(), e->tables);
+    if (rc == SONO_OK && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+        rc = hip_fail(hipGetLastError(), "hipStreamCreate");
+    if (rc != SONO_OK) { sono_engine_destroy(e); return rc; }
+    *out = e;
+    return SONO_OK;
+}
+
+void sono_engine_destroy(sono_engine *e)
+{
+    if (!e) return;
+    DeviceGuard guard(e->device);
+    if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+    e->tables.release();
+    e->d_in.release(); e->d_out.release(); e->d_peak_bin.release(); e->d_peak_mag.release();
+    e->d_gmax.release(); e->d_mags.release(); e->d_bank.release();
+    delete e;
+}
+
+uint32_t sono_engine_fft_size(const sono_engine *e) { return e ? e->N : 0; }
+uint32_t sono_engine_freq_bins(const sono_engine *e) { return e ? e->N / 2 : 0; }
+uint32_t sono_engine_num_filters(const sono_engine *e) { return e ? e->num_filters : 0; }
+int sono_engine_device(const sono_engine *e) { return e ? e->device : -1; }
+
+int sono_engine_window_values(const sono_engine *e, float *out, size_t cap)
+{
+    if (!e || !out) return fail(SONO_EINVAL, "sono_engine_window_values: NULL argument");
+    if (cap < e->N) return fail(SONO_ECAPACITY, "sono_engine_window_values: buffer too small");
+    std::memcpy(out, e->window.data(), e->N * sizeof(float));
+    return SONO_OK;
+}
+
+int sono_engine_load_filter_bank(sono_engine *e, const float *w, size_t len, uint32_t num_filters)
+{
+    if (!e || (!w && len)) return fail(SONO_EINVAL, "sono_engine_load_filter_bank: NULL argument");
+    e->bank.assign(w, w + len);                            // lib.rs:91-93
+    e->num_filters = num_filters;
+    e->use_bank = true;
+    return SONO_OK;
+}
+
+int sono_engine_clear_filter_bank(sono_engine *e)
+{
+    if (!e) return fail(SONO_EINVAL, "sono_engine_clear_filter_bank: NULL engine");
+    e->bank.clear(); e->num_filters = 0; e->use_bank = false;
+    return SONO_OK;
+}
+
+int sono_engine_release_memory(sono_engine *e)
+{
+    if (!e) return fail(SONO_EINVAL, "sono_engine_release_memory: NULL engine");
+    DeviceGuard guard(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    e->bank.clear(); e->num_filters = 0; e->use_bank = false;       // lib.rs:683-692
+    e->color_map.clear();
+    e->has_last = false; e->last_peak_bin.clear(); e->last_peak_mag.clear(); e->last_gmax = 0.0f;
+    e->d_in.release(); e->d_out.release(); e->d_peak_bin.release(); e->d_peak_mag.release();
+    e->d_mags.release(); e->d_bank.release();
+    return SONO_OK;
+}
+
+int sono_engine_synchronize(sono_engine *e)
+{
+    if (!e) return fail(SONO_EINVAL, "sono_engine_synchronize: NULL engine");
+    DeviceGuard guard(e->device);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SONO_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+void fill_args(const sono_engine *e, const sono_batch &in, uint32_t noverlap, sono::StftArgs &a)
+{
+    std::memset(&a, 0, sizeof(a));
+    a.x = in.d_samples;
+    a.n_streams = in.n_streams;
+    a.stream_stride = in.stream_stride;
+    a.frames_per_stream = sono_frames_for(in.samples_per_stream, e->N, noverlap);
+    a.hop = e->N - noverlap;
+    a.N = e->N;
+    a.window = e->tables.d_window;
+    a.tw_half = e->tables.d_tw_half;
+    a.tw_full = e->tables.d_tw_full;
+    a.inv_n = 1.0f / (float)e->N;
+}
+
+int check_batch(const sono_engine *e, const sono_batch *in, uint32_t noverlap, const char *who)
+{
+    if (!e || !in) return fail(SONO_EINVAL, std::string(who) + ": NULL argument");
+    if (noverlap >= e->N) return fail(SONO_EINVAL, std::string(who) + ": noverlap must be < fft_size");
+    if (in->n_streams && in->samples_per_stream && !in->d_samples)
+        return fail(SONO_EINVAL, std::string(who) + ": d_samples is NULL");
+    if (in->n_streams > 1 && in->stream_stride < in->samples_per_stream)
+        return fail(SONO_EINVAL, std::string(who) + ": stream_stride < samples_per_stream");
+    return SONO_OK;
+}
+
+// Uploads the samples the frames actually touch.
+int stage_input(sono_engine *e, const float *x, size_t n, uint32_t noverlap, size_t frames)
+{
+    (void)n;
+    const size_t used = (frames - 1) * (size_t)(e->N - noverlap) + e->N;
+    HIP_TRY(e->d_in.reserve(used * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(e->d_in.p, x, used * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    return SONO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sono_stft_mag_f32_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap, float *d_out,
+                          void *hip_stream)
+{
+    int rc = check_batch(e, in, noverlap, "sono_stft_mag_f32_dev");
+    if (rc) return rc;
+    sono::StftArgs a;
+    fill_args(e, *in, noverlap, a);
+    if (a.n_streams * a.frames_per_stream == 0) return SONO_OK;
+    if (!d_out) return fail(SONO_EINVAL, "sono_stft_mag_f32_dev: d_out is NULL");
+    a.out_mag = d_out;
+    DeviceGuard guard(e->device);
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    HIP_TRY(dispatch_stft(sono::MODE_MAG, a, e->tables, s));
+    return SONO_OK;
+}
+
+int sono_stft_u8_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap, float gain_db,
+                     float range_db, uint8_t *d_out, uint16_t *d_peak_bin, float *d_peak_mag,
+                     uint32_t *d_gmax_bits, void *hip_stream)
+{
+    int rc = check_batch(e, in, noverlap, "sono_stft_u8_dev");
+    if (rc) return rc;
+    sono::StftArgs a;
+    fill_args(e, *in, noverlap, a);
+    if (a.n_streams * a.frames_per_stream == 0) return SONO_OK;
+    if (!d_out) return fail(SONO_EINVAL, "sono_stft_u8_dev: d_out is NULL");
+    const sono::Quant q = sono::make_quant(e->N, gain_db, range_db);
+    a.out_u8 = d_out; a.peak_bin = d_peak_bin; a.peak_mag = d_peak_mag; a.gmax_bits = d_gmax_bits;
+    a.q_a = q.a; a.q_c = q.c; a.q_floor = q.floor;
+    DeviceGuard guard(e->device);
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    HIP_TRY(dispatch_stft(sono::MODE_U8, a, e->tables, s));
+    return SONO_OK;
+}
+
+int sono_stft_mag_f32(sono_engine *e, const float *x, size_t n, uint32_t noverlap, float *out,
+                      size_t cap, size_t *frames)
+{
+    if (frames) *frames = 0;
+    if (!e || (!x && n)) return fail(SONO_EINVAL, "sono_stft_mag_f32: NULL argument");
+    if (noverlap >= e->N) return fail(SONO_EINVAL, "sono_stft_mag_f32: noverlap must be < fft_size");
+    const size_t F = sono_frames_for(n, e->N, noverlap), B = e->N / 2;
+    if (F == 0) return SONO_OK;                           // n < N: empty result, not an error
+    if (!out || cap < F * B) return fail(SONO_ECAPACITY, "sono_stft_mag_f32: output buffer too small");
+    DeviceGuard guard(e->device);
+    int rc = stage_input(e, x, n, noverlap, F);
+    if (rc) return rc;
+    HIP_TRY(e->d_out.reserve(F * B * sizeof(float)));
+    sono_batch b{(const float *)e->d_in.p, 1, n, n};
+    rc = sono_stft_mag_f32_dev(e, &b, noverlap, (float *)e->d_out.p, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, e->d_out.p, F * B * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (frames) *frames = F;
+    return SONO_OK;
+}
+
+int sono_stft_u8(sono_engine *e, const float *x, size_t n, uint32_t noverlap, float gain_db,
+                 float range_db, uint8_t *out, size_t cap, size_t *frames)
+{
+    if (frames) *frames = 0;
+    if (!e || (!x && n)) return fail(SONO_EINVAL, "sono_stft_u8: NULL argument");
+    if (noverlap >= e->N) return fail(SONO_EINVAL, "sono_stft_u8: noverlap must be < fft_size");
+    const size_t F = sono_frames_for(n, e->N, noverlap), B = e->N / 2;
+    const bool bank = e->use_bank && e->num_filters > 0;            // lib.rs:217-221
+    const size_t out_bins = bank ? e->num_filters : B;
+    // the call replaces the engine's peak state even when it yields no frames (lib.rs:299-301)
+    e->has_last = true; e->last_peak_bin.clear(); e->last_peak_mag.clear(); e->last_gmax = 0.0f;
+    if (F == 0) return SONO_OK;
+    if (!out || cap < F * out_bins) return fail(SONO_ECAPACITY, "sono_stft_u8: output buffer too small");
+    DeviceGuard guard(e->device);
+    int rc = stage_input(e, x, n, noverlap, F);
+    if (rc) return rc;
+    HIP_TRY(e->d_out.reserve(F * out_bins));
+    HIP_TRY(e->d_peak_bin.reserve(F * sizeof(uint16_t)));
+    HIP_TRY(e->d_peak_mag.reserve(F * sizeof(float)));
+    HIP_TRY(e->d_gmax.reserve(sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(e->d_gmax.p, 0, sizeof(uint32_t), e->stream));
+    sono_batch b{(const float *)e->d_in.p, 1, n, n};
+    if (!bank) {
+        rc = sono_stft_u8_dev(e, &b, noverlap, gain_db, range_db, (uint8_t *)e->d_out.p,
+                              (uint16_t *)e->d_peak_bin.p, (float *)e->d_peak_mag.p,
+                              (uint32_t *)e->d_gmax.p, nullptr);
+        if (rc) return rc;
+    } else {
+        HIP_TRY(e->d_mags.reserve(F * B * sizeof(float)));
+        rc = sono_stft_mag_f32_dev(e, &b, noverlap, (float *)e->d_mags.p, nullptr);
+        if (rc) return rc;
+        HIP_TRY(e->d_bank.reserve((e->bank.size() ? e->bank.size() : 1) * sizeof(float)));
+        if (!e->bank.empty())
+            HIP_TRY(hipMemcpyAsync(e->d_bank.p, e->bank.data(), e->bank.size() * sizeof(float),
+                                   hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(sono::launch_filterbank_u8((const float *)e->d_mags.p, F, (int)B, (const float *)e->d_bank.p,
+                                           e->bank.size(), (int)e->num_filters, gain_db, range_db,
+                                           (uint8_t *)e->d_out.p, (uint16_t *)e->d_peak_bin.p,
+                                           (float *)e->d_peak_mag.p, (uint32_t *)e->d_gmax.p, e->stream));
+    }
+    e->last_peak_bin.resize(F);
+    e->last_peak_mag.resize(F);
+    uint32_t gbits = 0;
+    HIP_TRY(hipMemcpyAsync(out, e->d_out.p, F * out_bins, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->last_peak_bin.data(), e->d_peak_bin.p, F * sizeof(uint16_t),
+                           hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->last_peak_mag.data(), e->d_peak_mag.p, F * sizeof(float),
+                           hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(&gbits, e->d_gmax.p, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    std::memcpy(&e->last_gmax, &gbits, 4);
+    if (frames) *frames = F;
+    return SONO_OK;
+}
+
+int sono_peaks_u16(const sono_engine *e, float ratio, uint16_t *out, size_t cap, size_t *count)
+{
+    if (count) *count = 0;
+    if (!e) return fail(SONO_EINVAL, "sono_peaks_u16: NULL engine");
+    const size_t F = e->last_peak_bin.size();
+    if (!e->has_last || F == 0 || !(e->last_gmax > 0.0f)) return SONO_OK;   // lib.rs:350-352
+    if (!out || cap < F) return fail(SONO_ECAPACITY, "sono_peaks_u16: output buffer too small");
+    const float threshold = e->last_gmax * ratio;                            // lib.rs:355
+    for (size_t f = 0; f < F; ++f)
+        out[f] = e->last_peak_mag[f] >= threshold ? e->last_peak_bin[f] : (uint16_t)0xFFFF;
+    if (count) *count = F;
+    return SONO_OK;
+}
+
+int sono_peak_mags_f32(const sono_engine *e, float ratio, float *out, size_t cap, size_t *count)
+{
+    if (count) *count = 0;
+    if (!e) return fail(SONO_EINVAL, "sono_peak_mags_f32: NULL engine");
+    const size_t F = e->last_peak_mag.size();
+    if (!e->has_last || F == 0 || !(e->last_gmax > 0.0f)) return SONO_OK;   // lib.rs:399-401
+    if (!out || cap < F) return fail(SONO_ECAPACITY, "sono_peak_mags_f32: output buffer too small");
+    const float threshold = e->last_gmax * ratio;
+    for (size_t f = 0; f < F; ++f)
+        out[f] = e->last_peak_mag[f] >= threshold ? e->last_peak_mag[f] : 0.0f;
+    if (count) *count = F;
+    return SONO_OK;
+}
+
+float sono_global_max(const sono_engine *e) { return e ? e->last_gmax : 0.0f; }
+
+int sono_engine_set_color_map(sono_engine *e, const uint8_t *rgba, size_t len)
+{
+    if (!e) return fail(SONO_EINVAL, "sono_engine_set_color_map: NULL engine");
+    if (len != 1024 || !rgba) return SONO_OK;                               // lib.rs:452-454
+    e->color_map.resize(256);
+    for (size_t i = 0; i < 256; ++i)
+        e->color_map[i] = ((uint32_t)rgba[4 * i] << 24) | ((uint32_t)rgba[4 * i + 1] << 16) |
+                          ((uint32_t)rgba[4 * i + 2] << 8) | (uint32_t)rgba[4 * i + 3];
+    return SONO_OK;
+}
+
+int sono_engine_set_spectrum_config(sono_engine *e, const char *scale, float fmin, float fmax)
+{
+    if (!e) return fail(SONO_EINVAL, "sono_engine_set_spectrum_config: NULL engine");
+    e->scale = scale ? scale : "";
+    e->freq_min = fmin; e->freq_max = fmax;
+    return SONO_OK;
+}
+
+int sono_spectrogram_image(sono_engine *e, const float *x, size_t n, uint32_t width, uint32_t height,
+                           uint32_t noverlap, float gain_db, float range_db, uint8_t *out, size_t cap)
+{
+    if (!e || (!x && n)) return fail(SONO_EINVAL, "sono_spectrogram_image: NULL argument");
+    const size_t bytes = (size_t)width * height * 4;
+    if (bytes && (!out || cap < bytes)) return fail(SONO_ECAPACITY, "sono_spectrogram_image: output buffer too small");
+    if (bytes) std::memset(out, 0, bytes);
+    if (width == 0 || height == 0 || e->color_map.empty()) return SONO_OK;  // lib.rs:504-506
+    if (noverlap >= e->N) return fail(SONO_EINVAL, "sono_spectrogram_image: noverlap must be < fft_size");
+    // (n - noverlap) / step of lib.rs:517-521 equals the usual frame count for n >= N
+    const size_t F = sono_frames_for(n, e->N, noverlap), B = e->N / 2;
+    if (F == 0) return SONO_OK;
+    std::vector<float> mags(F * B);
+    size_t got = 0;
+    int rc = sono_stft_mag_f32(e, x, n, noverlap, mags.data(), mags.size(), &got);
+    if (rc) return rc;
+    sono::host_render_image(mags.data(), F, B, e->bank.data(), e->bank.size(), e->num_filters, e->use_bank,
+                            e->color_map.data(), width, height, gain_db, range_db, out);
+    return SONO_OK;
+}
+
+int sono_power_spectrum(const float *x, size_t n, uint32_t sample_rate, uint32_t fft_size,
+                        const char *window, int has_overlap, float overlap_percent, int device,
+                        float *out, size_t cap, size_t *bins)
+{
+    (void)sample_rate;   // only sets the bin count, which is N/2+1 for every power-of-two N (lib.rs:1044-1046)
+    if (bins) *bins = 0;
+    if (n == 0) return SONO_OK;                                              // lib.rs:1026-1028
+    if (!x) return fail(SONO_EINVAL, "sono_power_spectrum: x is NULL");
+    if (!sono::supported_fft_size(fft_size))
+        return fail(SONO_EINVAL, "sono_power_spectrum: fft_size must be a power of two in [256, 4096]");
+    const size_t nb = fft_size / 2 + 1;
+    if (n < fft_size) return SONO_OK;                                        // no frame: empty (lib.rs:1101-1103)
+    if (!out || cap < nb) return fail(SONO_ECAPACITY, "sono_power_spectrum: output buffer too small");
+    if (sono_device_count() <= 0) return fail(SONO_EDEVICE, "sono_power_spectrum: no HIP device available");
+    DeviceGuard guard(device);
+    if (!guard.ok()) return fail(SONO_EDEVICE, "sono_power_spectrum: cannot select the device");
+    const size_t hop = sono::host_power_hop(fft_size, has_overlap != 0, overlap_percent);
+    const size_t F = (n - fft_size) / hop + 1;
+    std::vector<float> win(fft_size);
+    sono::host_make_window(window ? window : "", fft_size, 0.16f, win.data());   // lib.rs:1041
+    Tables t;
+    int rc = build_tables(fft_size, win.data(), t);
+    DevBuf d_x, d_pow, d_db;
+    auto cleanup = [&]() { t.release(); d_x.release(); d_pow.release(); d_db.release(); };
+    if (rc) { cleanup(); return rc; }
+    const size_t used = (F - 1) * hop + fft_size;
+    hipError_t he;
+    if ((he = d_x.reserve(used * sizeof(float))) != hipSuccess ||
+        (he = d_pow.reserve(F * nb * sizeof(float))) != hipSuccess ||
+        (he = d_db.reserve(nb * sizeof(float))) != hipSuccess ||
+        (he = hipMemcpy(d_x.p, x, used * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
+        cleanup();
+        return hip_fail(he, "sono_power_spectrum: staging");
+    }
+    sono::StftArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.x = (const float *)d_x.p; a.n_streams = 1; a.stream_stride = used; a.frames_per_stream = F;
+    a.hop = (unsigned int)hop; a.N = fft_size; a.window = t.d_window;
+    a.tw_half = t.d_tw_half; a.tw_full = t.d_tw_full; a.inv_n = 1.0f / (float)fft_size;
+    a.out_power = (float *)d_pow.p;
+    if ((he = sono::launch_stft_generic(sono::MODE_POWER, a, nullptr)) != hipSuccess ||
+        (he = sono::launch_power_reduce((const float *)d_pow.p, F, (int)nb, fft_size, (float *)d_db.p, nullptr)) != hipSuccess ||
+        (he = hipMemcpy(out, d_db.p, nb * sizeof(float), hipMemcpyDeviceToHost)) != hipSuccess) {
+        cleanup();
+        return hip_fail(he, "sono_power_spectrum: compute");
+    }
+    cleanup();
+    if (bins) *bins = nb;
+    return SONO_OK;
+}
+
+float sono_find_peak_frequency(const float *spectrum, size_t len, uint32_t sample_rate, uint32_t fft_size,
+                               float flow_hz, float fhigh_hz)
+{
+    if (!spectrum || fft_size == 0) return 0.0f;
+    return sono::host_find_peak_frequency(spectrum, len, sample_rate, fft_size, flow_hz, fhigh_hz);
+}
+
+int sono_wave_peaks(const float *x, size_t n, size_t num_peaks, float *out, size_t cap, size_t *count)
+{
+    if (count) *count = 0;
+    if (num_peaks == 0 || n == 0) return SONO_OK;                           // lib.rs:795-797
+    if (!x || !out) return fail(SONO_EINVAL, "sono_wave_peaks: NULL argument");
+    if (cap < num_peaks) return fail(SONO_ECAPACITY, "sono_wave_peaks: output buffer too small");
+    const size_t k = sono::host_wave_peaks(x, n, num_peaks, out);
+    if (count) *count = k;
+    return SONO_OK;
+}
+
+float sono_find_global_max(const float *x, size_t n) { return x ? sono::host_find_global_max(x, n) : 0.0f; }
+
+int sono_waveform_create(sono_waveform **out)
+{
+    if (!out) return fail(SONO_EINVAL, "sono_waveform_create: out is NULL");
+    *out = new (std::nothrow) sono_waveform();
+    return *out ? SONO_OK : fail(SONO_ENOMEM, "sono_waveform_create: out of host memory");
+}
+
+void sono_waveform_destroy(sono_waveform *w) { delete w; }
+
+int sono_waveform_resize(sono_waveform *w, size_t num_channels)
+{
+    if (!w) return fail(SONO_EINVAL, "sono_waveform_resize: NULL handle");
+    w->channels.clear();                                                    // lib.rs:866-869
+    w->channels.resize(num_channels);
+    return SONO_OK;
+}
+
+int sono_waveform_load_channel(sono_waveform *w, size_t idx, const float *x, size_t n)
+{
+    if (!w || (!x && n)) return fail(SONO_EINVAL, "sono_waveform_load_channel: NULL argument");
+    if (idx >= w->channels.size()) return SONO_OK;                          // silently ignored, lib.rs:880-882
+    w->channels[idx].assign(x, x + n);
+    return SONO_OK;
+}
+
+size_t sono_waveform_channel_length(const sono_waveform *w, size_t idx)
+{
+    return (w && idx < w->channels.size()) ? w->channels[idx].size() : 0;
+}
+
+size_t sono_waveform_num_channels(const sono_waveform *w) { return w ? w->channels.size() : 0; }
+
+int sono_waveform_clear(sono_waveform *w)
+{
+    if (!w) return fail(SONO_EINVAL, "sono_waveform_clear: NULL handle");
+    w->channels.clear();
+    return SONO_OK;
+}
+
+int sono_waveform_release_memory(sono_waveform *w) { return sono_waveform_clear(w); }
+
+int sono_waveform_peaks_in_range(const sono_waveform *w, size_t idx, size_t start_sample, size_t end_sample,
+                                 size_t target_width, float *out, size_t cap, size_t *count)
+{
+    if (count) *count = 0;
+    if (!w || !out) return fail(SONO_EINVAL, "sono_waveform_peaks_in_range: NULL argument");
+    const size_t need = target_width ? target_width : 1;
+    if (cap < need) return fail(SONO_ECAPACITY, "sono_waveform_peaks_in_range: output buffer too small");
+    if (idx >= w->channels.size() || target_width == 0) {                   // lib.rs:912-914
+        for (size_t i = 0; i < need; ++i) out[i] = 0.0f;
+        if (count) *count = need;
+        return SONO_OK;
+    }
+    const std::vector<float> &c = w->channels[idx];
+    const size_t k = sono::host_peaks_in_range(c.data(), c.size(), start_sample, end_sample, target_width, out);
+    if (count) *count = k;
+    return SONO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,318 @@
+// sono_core.h -- arithmetic shared by every STFT kernel of libsonostft.
+//
+// Everything here is written as __host__ __device__ so that the index math and
+// the butterflies can be exercised lane by lane in a plain g++ build (see
+// tests/host_emul) before a kernel ever runs on a GPU.  The GPU build is the
+// only one that ships; the host instantiation exists for that test alone.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <cstring>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SONO_HD __host__ __device__ __forceinline__
+#else
+#define SONO_HD inline
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+#endif
+
+namespace sono {
+
+enum Mode : int {
+    MODE_MAG = 0,    // frames x N/2 linear magnitudes           (lib.rs:113-161)
+    MODE_U8 = 1,     // frames x N/2 u8 dB codes + peak features (lib.rs:199-304,349-443)
+    MODE_POWER = 2,  // frames x (N/2+1) |X|^2 of mean-removed frames (lib.rs:1058-1094)
+};
+
+// Arguments common to the STFT kernels.  Frames are numbered globally:
+// g = stream * frames_per_stream + frame; frame f of stream s starts at sample
+// s * stream_stride + f * hop.  Output row g is contiguous after row g-1.
+struct StftArgs {
+    const float *x;
+    unsigned long long n_streams;
+    unsigned long long stream_stride;
+    unsigned long long frames_per_stream;
+    unsigned int hop;
+    unsigned int N;               // fft_size (real samples per frame)
+    const float *window;          // N floats
+    const float2 *tw_half;        // W_{N/2}^k = exp(-2*pi*i*k/(N/2)), k in [0, N/2)
+    const float2 *tw_full;        // W_N^k     = exp(-2*pi*i*k/N),     k in [0, N/2]
+    float *out_mag;               // MODE_MAG
+    uint8_t *out_u8;              // MODE_U8
+    uint16_t *peak_bin;           // MODE_U8, optional
+    float *peak_mag;              // MODE_U8, optional
+    unsigned int *gmax_bits;      // MODE_U8, optional: f32 bits, only ever raised
+    float *out_power;             // MODE_POWER
+    float inv_n;                  // 1/N: |2X| * inv_n = |X| * 2/N (lib.rs:150)
+    float q_a, q_c;               // code = trunc(q_a * log2(max(|2X|^2, q_floor)) + q_c), saturated to [0,255]
+    float q_floor;
+};
+
+SONO_HD float2 cadd(float2 a, float2 b) { return float2{a.x + b.x, a.y + b.y}; }
+SONO_HD float2 csub(float2 a, float2 b) { return float2{a.x - b.x, a.y - b.y}; }
+SONO_HD float2 cmul(float2 a, float2 w) { return float2{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+SONO_HD float2 mul_neg_i(float2 a) { return float2{a.y, -a.x}; }   // -i * a
+
+// Real-input split.  Z is the N/2-point DFT of z[n] = x[2n] + i x[2n+1];
+// returns 2*X[k] of the N-point DFT of x, given Z[k], Z[(N/2-k) mod N/2] and
+// w = W_N^k.  (X[k] = Xe + W_N^k Xo, Xe = (Zk + conj Zp)/2, Xo = -i (Zk - conj Zp)/2.)
+SONO_HD float2 real_split2(float2 zk, float2 zp, float2 w)
+{
+    const float er = zk.x + zp.x, ei = zk.y - zp.y;      // Zk + conj(Zp)
+    const float dr = zk.x - zp.x, di = zk.y + zp.y;      // Zk - conj(Zp)
+    // 2*Xo = -i * d = (di, -dr);  w * (di, -dr) = (w.x*di + w.y*dr, w.y*di - w.x*dr)
+    return float2{er + (w.x * di + w.y * dr), ei + (w.y * di - w.x * dr)};
+}
+
+// Quantiser constants for the dB -> u8 law of lib.rs:277-293, restated on
+// p = |2X|^2 = (mag * N)^2:   db = 20 log10(mag) = 10 log10(p) - 20 log10(N)
+//   code = (db - (-gain - range)) * 255/range = q_a * log2(p) + q_c
+// with the reference's floor mag >= 1e-10 carried over as p >= (1e-10 * N)^2.
+struct Quant { float a, c, floor; };
+inline Quant make_quant(unsigned int N, float gain_db, float range_db)
+{
+    const double k = 255.0 / (double)range_db;
+    const double ten_log10_2 = 3.010299956639812;       // 10*log10(2)
+    Quant q;
+    q.a = (float)(ten_log10_2 * k);
+    q.c = (float)((-20.0 * std::log10((double)N) + (double)gain_db + (double)range_db) * k);
+    const double fl = 1e-10 * (double)N;
+    q.floor = (float)(fl * fl);
+    return q;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+SONO_HD float fast_log2(float p) { return __builtin_amdgcn_logf(p); }   // v_log_f32 (log2, ~1 ulp)
+SONO_HD float fast_sqrt(float p) { return __builtin_amdgcn_sqrtf(p); }  // v_sqrt_f32 (~1 ulp)
+#else
+SONO_HD float fast_log2(float p) { return std::log2(p); }
+SONO_HD float fast_sqrt(float p) { return std::sqrt(p); }
+#endif
+
+// u8 code of one bin from p = |2X|^2.  Float -> int conversion truncates toward
+// zero like Rust's `as u8`; the clamps make the saturation explicit.
+SONO_HD unsigned int quantise(float p, float q_a, float q_c, float q_floor)
+{
+    const float pf = p > q_floor ? p : q_floor;
+    float v = q_a * fast_log2(pf) + q_c;
+    v = v > 0.0f ? v : 0.0f;          // also NaN -> 0
+    v = v < 255.0f ? v : 255.0f;
+    return (unsigned int)v;
+}
+
+// Ordering key for "largest magnitude, lowest bin on ties" (lib.rs:370-378):
+// magnitudes are >= 0, so their bit patterns order like the values.
+SONO_HD unsigned long long peak_key(float mag, unsigned int bin)
+{
+    unsigned int bits;
+#if defined(__HIP_DEVICE_COMPILE__)
+    bits = __float_as_uint(mag);
+#else
+    std::memcpy(&bits, &mag, 4);
+#endif
+    return ((unsigned long long)bits << 32) | (unsigned long long)(0xFFFFFFFFu - bin);
+}
+
+// ---------------------------------------------------------------------------
+// Generic path: one 256-thread workgroup transforms a slab of max(N/2, 1024)
+// complex points (1024/(N/2) frames for N <= 2048, one frame for N = 4096) with
+// a Stockham radix-4 (+ one radix-2 pass when log2(N/2) is odd) FFT staged in
+// LDS.  Each method is one barrier-delimited phase executed by thread `t`.
+// ---------------------------------------------------------------------------
+constexpr int GEN_THREADS = 256;
+constexpr int GEN_MAX_FPB = 8;      // frames per block at N = 256
+
+struct GenericShared {
+    float2 *buf0, *buf1;                       // 2 x slab complex
+    long long *frame_off;                      // [GEN_MAX_FPB] sample offset of the frame, -1 = past the end
+    unsigned long long *peak;                  // [GEN_MAX_FPB] peak_key per frame
+    float *dc;                                 // [GEN_MAX_FPB] mean of the windowed frame (MODE_POWER)
+};
+
+template <int MODE>
+struct GenericBlock {
+    const StftArgs &a;
+    GenericShared sh;
+    unsigned long long block;                  // blockIdx.x
+    int M, logM, slab, fpb;
+
+    SONO_HD GenericBlock(const StftArgs &args, GenericShared s, unsigned long long blk)
+        : a(args), sh(s), block(blk)
+    {
+        M = (int)(a.N >> 1);
+        logM = 0;
+        while ((1 << logM) < M) ++logM;
+        slab = M > 1024 ? M : 1024;
+        fpb = slab / M;
+    }
+
+    SONO_HD void phase_setup(int t) const
+    {
+        if (t < fpb) {
+            const unsigned long long total = a.n_streams * a.frames_per_stream;
+            const unsigned long long g = block * (unsigned long long)fpb + (unsigned long long)t;
+            long long off = -1;
+            if (g < total) {
+                const unsigned long long s = g / a.frames_per_stream;
+                const unsigned long long f = g - s * a.frames_per_stream;
+                off = (long long)(s * a.stream_stride + f * a.hop);
+            }
+            sh.frame_off[t] = off;
+            sh.peak[t] = peak_key(0.0f, 0u);
+            sh.dc[t] = 0.0f;
+        }
+    }
+
+    // z[n] = (x[2n] w[2n], x[2n+1] w[2n+1])
+    SONO_HD void phase_load(int t) const
+    {
+        for (int idx = t; idx < slab; idx += GEN_THREADS) {
+            const int fb = idx >> logM, n = idx & (M - 1);
+            const long long off = sh.frame_off[fb];
+            float2 z = float2{0.0f, 0.0f};
+            if (off >= 0) {
+                const float *xp = a.x + off + 2 * n;
+                z.x = xp[0] * a.window[2 * n];
+                z.y = xp[1] * a.window[2 * n + 1];
+            }
+            sh.buf0[idx] = z;
+        }
+    }
+
+    // Mean of the windowed frame, summed in sample order like lib.rs:1069-1073.
+    SONO_HD void phase_dc_sum(int t) const
+    {
+        if (t < fpb && sh.frame_off[t] >= 0) {
+            float s = 0.0f;
+            const float2 *z = sh.buf0 + t * M;
+            for (int n = 0; n < M; ++n) { s += z[n].x; s += z[n].y; }
+            sh.dc[t] = s / (float)a.N;
+        }
+    }
+    SONO_HD void phase_dc_sub(int t) const
+    {
+        for (int idx = t; idx < slab; idx += GEN_THREADS) {
+            const float m = sh.dc[idx >> logM];
+            float2 z = sh.buf0[idx];
+            z.x -= m; z.y -= m;
+            sh.buf0[idx] = z;
+        }
+    }
+
+    // One Stockham radix-4 pass; p = product of the radices already applied.
+    SONO_HD void phase_r4(int t, int p, const float2 *src, float2 *dst) const
+    {
+        const int quarter = M >> 2, logq = logM - 2;
+        int logp = 0;
+        while ((1 << logp) < p) ++logp;
+        const int tshift = logM - 2 - logp;            // twiddle step M/(4p)
+        for (int b = t; b < (slab >> 2); b += GEN_THREADS) {
+            const int fb = b >> logq, i = b & (quarter - 1);
+            const int k = i & (p - 1);
+            const int j = ((i - k) << 2) + k;
+            const float2 *s = src + fb * M;
+            float2 u0 = s[i], u1 = s[i + quarter], u2 = s[i + 2 * quarter], u3 = s[i + 3 * quarter];
+            if (p > 1) {
+                const int ti = k << tshift;
+                u1 = cmul(u1, a.tw_half[ti]);
+                u2 = cmul(u2, a.tw_half[2 * ti]);
+                u3 = cmul(u3, a.tw_half[3 * ti]);
+            }
+            const float2 v0 = cadd(u0, u2), v1 = csub(u0, u2), v2 = cadd(u1, u3), v3 = mul_neg_i(csub(u1, u3));
+            float2 *d = dst + fb * M + j;
+            d[0] = cadd(v0, v2);
+            d[p] = cadd(v1, v3);
+            d[2 * p] = csub(v0, v2);
+            d[3 * p] = csub(v1, v3);
+        }
+    }
+
+    // Final radix-2 pass (p = M/2) when log2(M) is odd.
+    SONO_HD void phase_r2(int t, const float2 *src, float2 *dst) const
+    {
+        const int half = M >> 1, logh = logM - 1;
+        for (int b = t; b < (slab >> 1); b += GEN_THREADS) {
+            const int fb = b >> logh, i = b & (half - 1);
+            const float2 *s = src + fb * M;
+            const float2 u0 = s[i];
+            const float2 u1 = cmul(s[i + half], a.tw_half[i]);
+            float2 *d = dst + fb * M;
+            d[i] = cadd(u0, u1);
+            d[i + half] = csub(u0, u1);
+        }
+    }
+
+    // Real split + output.  Z = finished N/2-point FFTs of the slab.
+    template <typename AtomicMax64>
+    SONO_HD void phase_epilogue(int t, const float2 *Z, AtomicMax64 atomic_max64) const
+    {
+        // each thread takes 4 consecutive bins so that u8 codes pack into one dword
+        for (int q = t; q < (slab >> 2); q += GEN_THREADS) {
+            const int fb = (q << 2) >> logM, k0 = (q << 2) & (M - 1);
+            if (sh.frame_off[fb] < 0) continue;
+            const unsigned long long g = block * (unsigned long long)fpb + (unsigned long long)fb;
+            const float2 *z = Z + fb * M;
+            float p[4];
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + r;
+                const float2 X2 = real_split2(z[k], z[(M - k) & (M - 1)], a.tw_full[k]);
+                p[r] = X2.x * X2.x + X2.y * X2.y;
+            }
+            if (MODE == MODE_MAG) {
+                float4 o;
+                o.x = fast_sqrt(p[0]) * a.inv_n; o.y = fast_sqrt(p[1]) * a.inv_n;
+                o.z = fast_sqrt(p[2]) * a.inv_n; o.w = fast_sqrt(p[3]) * a.inv_n;
+                *(float4 *)(a.out_mag + g * (unsigned long long)M + k0) = o;
+            } else if (MODE == MODE_U8) {
+                unsigned int packed = 0;
+                unsigned long long best = peak_key(0.0f, 0u);
+                for (int r = 0; r < 4; ++r) {
+                    packed |= quantise(p[r], a.q_a, a.q_c, a.q_floor) << (8 * r);
+                    const float mag = fast_sqrt(p[r]) * a.inv_n;
+                    if (mag > 0.0f) {                       // false for NaN, like `val > acc`
+                        const unsigned long long key = peak_key(mag, (unsigned int)(k0 + r));
+                        best = key > best ? key : best;
+                    }
+                }
+                *(unsigned int *)(a.out_u8 + g * (unsigned long long)M + k0) = packed;
+                atomic_max64(&sh.peak[fb], best);
+            } else {
+                float *o = a.out_power + g * (unsigned long long)(M + 1) + k0;
+                for (int r = 0; r < 4; ++r) o[r] = 0.25f * p[r];
+                if (k0 == 0) {                              // Nyquist bin: X[N/2] = Re Z0 - Im Z0
+                    const float ny = z[0].x - z[0].y;
+                    o[M] = ny * ny;
+                }
+            }
+        }
+    }
+
+    // Per-frame peak features out of the LDS keys (MODE_U8).
+    template <typename AtomicMaxU32>
+    SONO_HD void phase_features(int t, AtomicMaxU32 atomic_max_u32) const
+    {
+        if (t < fpb && sh.frame_off[t] >= 0) {
+            const unsigned long long g = block * (unsigned long long)fpb + (unsigned long long)t;
+            const unsigned long long key = sh.peak[t];
+            const unsigned int bits = (unsigned int)(key >> 32);
+            const unsigned int bin = 0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull);
+            if (a.peak_bin) a.peak_bin[g] = (uint16_t)bin;
+            if (a.peak_mag) {
+                float m;
+#if defined(__HIP_DEVICE_COMPILE__)
+                m = __uint_as_float(bits);
+#else
+                std::memcpy(&m, &bits, 4);
+#endif
+                a.peak_mag[g] = m;
+            }
+            if (a.gmax_bits) atomic_max_u32(a.gmax_bits, bits);
+        }
+    }
+};
+
+}  // namespace sono

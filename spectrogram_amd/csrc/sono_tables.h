@@ -1,0 +1,27 @@
+// sono_tables.h -- host-side builders of the constant tables the kernels read.
+#pragma once
+#include <cmath>
+#include <vector>
+
+#include "sono_core.h"
+
+namespace sono {
+
+// exp(-2*pi*i*k/len) for k in [0, count), computed in f64 and rounded once.
+inline std::vector<float2> make_twiddles(unsigned int len, unsigned int count)
+{
+    std::vector<float2> t(count);
+    for (unsigned int k = 0; k < count; ++k) {
+        const double a = -2.0 * 3.14159265358979323846 * (double)k / (double)len;
+        t[k].x = (float)std::cos(a);
+        t[k].y = (float)std::sin(a);
+    }
+    return t;
+}
+
+inline bool supported_fft_size(unsigned int n)
+{
+    return n >= 256 && n <= 4096 && (n & (n - 1)) == 0;
+}
+
+}  // namespace sono

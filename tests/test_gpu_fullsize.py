@@ -1,0 +1,119 @@
+"""Size-independent properties at the benchmark's full size (1 h at 384 kHz,
+FFT 1024, 75 % overlap: 5 399 997 frames), where running the oracle on
+everything would take minutes: spot frames against the oracle, exact
+amplitude-scaling and time-shift identities, and a checksum that must not
+depend on how the work is cut into launches."""
+import numpy as np
+import pytest
+
+import spectrogram_amd as sa
+from oracle import sono_oracle as so
+from spectrogram_amd import synth
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+N, V, H, SR = 1024, 768, 256, 384000
+SAMPLES = 3600 * SR
+
+
+@pytest.fixture(scope="module")
+def hour():
+    import torch
+    x = synth.chirp_torch(0, SAMPLES, SR, device="cuda")
+    F = sa.frames_for(SAMPLES, N, V)
+    assert F == 5399997
+    e = sa.SpectrogramEngine(N, "hann")
+    out = torch.empty(F * 512, dtype=torch.uint8, device="cuda")
+    pb = torch.empty(F, dtype=torch.int16, device="cuda")
+    pm = torch.empty(F, dtype=torch.float32, device="cuda")
+    gm = torch.zeros(1, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    e.stft_u8_dev(x.data_ptr(), 1, SAMPLES, SAMPLES, V, 20.0, 80.0, out.data_ptr(), pb.data_ptr(), pm.data_ptr(),
+                  gm.data_ptr(), st)
+    torch.cuda.synchronize()
+    yield dict(x=x, F=F, e=e, out=out.view(F, 512), pb=pb, pm=pm, gm=gm, torch=torch)
+    e.free()
+
+
+def test_spot_frames_against_oracle(hour):
+    torch = hour["torch"]
+    rng = np.random.default_rng(0)
+    # frames inside pulses (every 100 ms = 150 frames) and random ones
+    picks = sorted(set(list(rng.integers(0, hour["F"], 48)) + [0, hour["F"] - 1] + [150 * k + 3 for k in (1, 777, 30000)]))
+    o = so.OracleEngine(N, "hann")
+    nd = nt = 0
+    for f in picks:
+        xs = hour["x"][f * H: f * H + N].cpu().numpy()
+        ref = o.compute_spectrogram_u8(xs, V, 20.0, 80.0)
+        got = hour["out"][f].cpu().numpy()
+        a, b = parity.u8_diff(got, ref, f"frame {f}")
+        nd += a
+        nt += b
+        assert int(hour["pb"][f].item()) & 0xFFFF == int(o.get_peaks(0.0)[0])
+        assert abs(float(hour["pm"][f].item()) - float(o.get_peak_magnitudes(0.0)[0])) <= 1e-6 * o.get_global_max()
+    assert nd <= max(2, parity.U8_MAX_FRACTION * nt)
+
+
+def test_global_max_is_max_of_frame_peaks(hour):
+    torch = hour["torch"]
+    gmax = hour["gm"].view(torch.float32)[0].item()
+    assert gmax == hour["pm"].max().item() and gmax > 0.05
+
+
+def test_time_shift_identity(hour):
+    # the same launch started 7 hops later must reproduce rows 7.. bit for bit
+    torch = hour["torch"]
+    k, cnt = 7, 200000
+    n = (cnt - 1) * H + N
+    out = torch.empty(cnt * 512, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    xs = hour["x"][k * H: k * H + n]
+    hour["e"].stft_u8_dev(xs.data_ptr(), 1, n, n, V, 20.0, 80.0, out.data_ptr(), 0, 0, 0, st)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(cnt, 512), hour["out"][k:k + cnt])
+
+
+def test_launch_geometry_independent_checksum(hour):
+    # a sum over all u8 codes, computed from chunked launches with halo, equals the one-launch sum
+    torch = hour["torch"]
+    F = hour["F"]
+    total = hour["out"].to(torch.int64).sum().item() if F < 1000 else sum(
+        hour["out"][i:i + 500000].sum(dtype=torch.int64).item() for i in range(0, F, 500000))
+    st = torch.cuda.current_stream().cuda_stream
+    acc = 0
+    step = 1333333
+    buf = torch.empty(step * 512, dtype=torch.uint8, device="cuda")
+    for f0 in range(0, F, step):
+        f1 = min(f0 + step, F)
+        n = (f1 - f0 - 1) * H + N
+        xs = hour["x"][f0 * H: f0 * H + n]
+        hour["e"].stft_u8_dev(xs.data_ptr(), 1, n, n, V, 20.0, 80.0, buf.data_ptr(), 0, 0, 0, st)
+        torch.cuda.synchronize()
+        acc += buf[: (f1 - f0) * 512].sum(dtype=torch.int64).item()
+    assert acc == total
+
+
+def test_amplitude_scaling_identity(hour):
+    # scaling the input by 2^-3 scales every linear magnitude by exactly 2^-3
+    torch = hour["torch"]
+    cnt = 100000
+    n = (cnt - 1) * H + N
+    xs = hour["x"][:n].clone()
+    a = torch.empty(cnt * 512, dtype=torch.float32, device="cuda")
+    b = torch.empty(cnt * 512, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    hour["e"].stft_mag_f32_dev(xs.data_ptr(), 1, n, n, V, a.data_ptr(), st)
+    xs.mul_(0.125)
+    hour["e"].stft_mag_f32_dev(xs.data_ptr(), 1, n, n, V, b.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(a * 0.125, b)
+
+
+def test_pulse_frames_peak_on_the_sweep(hour):
+    # frames centred inside a pulse must peak between 30 and 80 kHz (bins 80..214 at 375 Hz/bin)
+    torch = hour["torch"]
+    pb = hour["pb"].to(torch.int32) & 0xFFFF
+    for pulse in (0, 5, 12345, 35999):
+        f = pulse * 150 + 2            # frame starting 2 hops into the pulse
+        assert 75 <= pb[f].item() <= 220, (pulse, pb[f].item())

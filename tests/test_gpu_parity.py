@@ -1,0 +1,240 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors from
+the reference wasm and against the CPU oracle.  Needs an MI355X: -m gpu."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import spectrogram_amd as sa
+from oracle import sono_oracle as so
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+PATHS = ["default", "generic"]
+
+
+@pytest.fixture(params=PATHS)
+def kernel_path(request, monkeypatch):
+    """Runs a test once through the normal kernel dispatch and once with the
+    generic LDS-staged kernel forced (SONO_FORCE_GENERIC is read per launch)."""
+    if request.param == "generic":
+        monkeypatch.setenv("SONO_FORCE_GENERIC", "1")
+    else:
+        monkeypatch.delenv("SONO_FORCE_GENERIC", raising=False)
+    return request.param
+
+
+def signal(n, seed, amp=0.3):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    return (amp * np.sin(0.2 * t + 1e-5 * t * t) + 0.01 * rng.standard_normal(n)).astype(np.float32)
+
+
+def test_device_present():
+    assert sa.device_count() >= 1
+
+
+def test_windows_bit_exact(golden):
+    g, meta = golden
+    for c in parity.cases(meta, "window"):
+        e = sa.SpectrogramEngine(c["fft"], c["window"], c["alpha"])
+        assert np.array_equal(e.get_window_values().view(np.uint32), g[c["name"] + "/window"].view(np.uint32)), c["name"]
+        assert e.get_fft_size() == c["fft"] and e.get_freq_bins() == c["fft"] // 2
+        e.free()
+
+
+def test_golden_stft_cases(golden, kernel_path):
+    g, meta = golden
+    nd = nt = 0
+    for c in parity.cases(meta, "stft"):
+        e = sa.SpectrogramEngine(c["fft"], c["window"], c["alpha"])
+        a, b = parity.run_stft_case(e, g, c)
+        e.free()
+        nd += a
+        nt += b
+    assert nt > 100000
+    assert nd <= parity.U8_MAX_FRACTION * nt, f"{nd} of {nt} u8 bins differ from the reference ({kernel_path})"
+
+
+def test_golden_power_spectrum(golden):
+    g, meta = golden
+    for c in parity.cases(meta, "power"):
+        n = c["name"]
+        s = sa.compute_power_spectrum(g[n + "/x"], c["sr"], c["fft"], c["window"], c["overlap"])
+        parity.check_power(s, g[n + "/spectrum"], n)
+        if len(s):
+            for q, want in zip(c["queries"], g[n + "/peakfreq"]):
+                got = sa.find_peak_frequency_from_spectrum(s, c["sr"], c["fft"], q[0], q[1])
+                # the peak frequency is a parabolic fit on dB values that agree to ~1e-4 dB
+                assert abs(got - float(want)) <= 2.0, (n, q, got, want)
+
+
+@pytest.mark.parametrize("N,V", [(256, 0), (256, 255), (512, 256), (512, 137), (1024, 768), (1024, 512),
+                                 (1024, 992), (1024, 819), (2048, 1536), (2048, 2047), (4096, 3891), (4096, 0)])
+def test_against_oracle(kernel_path, N, V):
+    H = N - V
+    frames = 37 if H > 4 else 300
+    x = signal(N + (frames - 1) * H + min(H - 1, 3), N + V)
+    o = so.OracleEngine(N, "hann")
+    e = sa.SpectrogramEngine(N, "hann")
+    parity.check_mag(e.compute_spectrogram(x, V), o.compute_spectrogram(x, V), N // 2, f"N={N} V={V}")
+    u8 = e.compute_spectrogram_u8(x, V, 20.0, 80.0)
+    ref = o.compute_spectrogram_u8(x, V, 20.0, 80.0)
+    nd, nt = parity.u8_diff(u8, ref, f"N={N} V={V}")
+    assert nd <= max(2, parity.U8_MAX_FRACTION * nt)
+    assert np.array_equal(e.get_peaks(0.4), o.get_peaks(0.4))
+    assert np.array_equal(e.get_peaks(0.0), o.get_peaks(0.0))
+    assert np.allclose(e.get_peak_magnitudes(0.0), o.get_peak_magnitudes(0.0), rtol=1e-6, atol=0)
+    assert abs(e.get_global_max() - o.get_global_max()) <= 1e-6 * o.get_global_max()
+    e.free()
+
+
+def test_empty_inputs_and_errors(kernel_path):
+    e = sa.SpectrogramEngine(1024, "hann")
+    assert len(e.get_peaks(0.4)) == 0 and len(e.get_peak_magnitudes(0.0)) == 0      # before any u8 call
+    assert e.get_global_max() == 0.0
+    short = np.ones(1023, np.float32)
+    assert len(e.compute_spectrogram(short, 768)) == 0                                # n < N: empty, no error
+    assert len(e.compute_spectrogram_u8(short, 768, 20.0, 80.0)) == 0
+    assert len(e.compute_spectrogram(np.zeros(0, np.float32), 0)) == 0
+    for bad in (1024, 1025, 5000):                                                   # reference panics (lib.rs:118-120)
+        with pytest.raises(sa.SonoError) as ei:
+            e.compute_spectrogram(np.ones(4096, np.float32), bad)
+        assert ei.value.status == sa.SONO_EINVAL
+    sil = np.zeros(1024 + 3 * 256, np.float32)
+    u8 = e.compute_spectrogram_u8(sil, 768, 20.0, 80.0)
+    assert len(u8) == 4 * 512 and not u8.any()
+    assert e.get_global_max() == 0.0 and len(e.get_peaks(0.0)) == 0                   # gmax <= 0: empty (lib.rs:350)
+    # a later call replaces the state; release_memory clears it
+    x = signal(1024 + 5 * 256, 3)
+    e.compute_spectrogram_u8(x, 768, 20.0, 80.0)
+    assert len(e.get_peaks(0.4)) == 6
+    e.release_memory()
+    assert len(e.get_peaks(0.4)) == 0 and e.get_global_max() == 0.0
+    e.free()
+    with pytest.raises(sa.SonoError):
+        e.get_fft_size()                                                             # use after free
+
+
+def test_u8_truncates_not_rounds(kernel_path):
+    # an impulse through a rectangular window: |X[k]| = a for every k
+    e = sa.SpectrogramEngine(256, "rectangular")
+    o = so.OracleEngine(256, "rectangular")
+    for target in (191.25, 127.5, 63.75, 10.5, 254.5):
+        db = target * 80.0 / 255.0 - 100.0
+        x = np.zeros(256, np.float32)
+        x[0] = 10 ** (db / 20.0) * 128.0
+        u8 = e.compute_spectrogram_u8(x, 0, 20.0, 80.0)
+        ref = o.compute_spectrogram_u8(x, 0, 20.0, 80.0)
+        assert np.array_equal(u8, ref) and u8[7] == int(target)
+    e.free()
+
+
+def test_clamps_and_extreme_parameters(kernel_path):
+    x = signal(1024 + 7 * 256, 9, amp=0.9)
+    x[2000:2100] = 0.0
+    for gain, rng in ((20.0, 80.0), (0.0, 100.0), (30.0, 60.0), (-10.0, 40.0), (60.0, 250.0)):
+        e = sa.SpectrogramEngine(1024, "hann")
+        o = so.OracleEngine(1024, "hann")
+        nd, nt = parity.u8_diff(e.compute_spectrogram_u8(x, 768, gain, rng), o.compute_spectrogram_u8(x, 768, gain, rng),
+                                f"gain={gain} range={rng}")
+        assert nd <= max(2, parity.U8_MAX_FRACTION * nt)
+        e.free()
+
+
+def test_filter_bank_quirk(golden):
+    g, meta = golden
+    c = [c for c in parity.cases(meta, "stft") if c["name"] == "bank256"][0]
+    e = sa.SpectrogramEngine(c["fft"], c["window"], c["alpha"])
+    parity.run_stft_case(e, g, c)
+    assert e.get_num_filters() == 16
+    e.clear_filter_bank()
+    assert e.get_num_filters() == 0
+    assert len(e.compute_spectrogram_u8(g["bank256/x"], c["noverlap"], 20.0, 80.0)) == 4 * 128
+    e.free()
+
+
+def test_image_path():
+    e = sa.SpectrogramEngine(256, "hann")
+    x = signal(256 + 40 * 64, 4)
+    img = e.compute_spectrogram_image(x, 32, 24, 192, 20.0, 80.0)
+    assert img.shape == (32 * 24 * 4,) and not img.any()          # no colour map: zeros (lib.rs:504-506)
+    e.set_color_map(np.zeros(10, np.uint8))                       # wrong size: ignored (lib.rs:452-454)
+    assert not e.compute_spectrogram_image(x, 32, 24, 192, 20.0, 80.0).any()
+    cmap = np.zeros((256, 4), np.uint8)
+    cmap[:, 0] = np.arange(256)
+    cmap[:, 3] = 255
+    e.set_color_map(cmap.ravel())
+    img = e.compute_spectrogram_image(x, 32, 24, 192, 20.0, 80.0).reshape(24, 32, 4)
+    assert (img[..., 3] == 255).all() and img[..., 0].max() > 100 and (img[..., 1] == 0).all()
+    # the tone (0.2 rad/sample ~ bin 8 of 128) sits near the bottom of the image, not the top
+    col = img[:, 5, 0].astype(int)
+    assert col[-4:].max() > col[:4].max()
+    e.free()
+
+
+def test_batch_dev_matches_single_streams(kernel_path):
+    import torch
+    N, V, per, stride, S = 1024, 768, 1024 + 21 * 256 + 17, 8192, 5
+    buf = np.zeros(S * stride, np.float32)
+    for s in range(S):
+        buf[s * stride: s * stride + per] = signal(per, 50 + s)
+    dx = torch.from_numpy(buf).cuda()
+    e = sa.SpectrogramEngine(N, "hann")
+    F = sa.frames_for(per, N, V)
+    out = torch.zeros(S * F * 512, dtype=torch.uint8, device="cuda")
+    pb = torch.zeros(S * F, dtype=torch.int16, device="cuda")
+    pm = torch.zeros(S * F, dtype=torch.float32, device="cuda")
+    gm = torch.zeros(1, dtype=torch.int32, device="cuda")
+    mag = torch.zeros(S * F * 512, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    e.stft_u8_dev(dx.data_ptr(), S, stride, per, V, 20.0, 80.0, out.data_ptr(), pb.data_ptr(), pm.data_ptr(),
+                  gm.data_ptr(), st)
+    e.stft_mag_f32_dev(dx.data_ptr(), S, stride, per, V, mag.data_ptr(), st)
+    torch.cuda.synchronize()
+    out, mag = out.cpu().numpy().reshape(S, -1), mag.cpu().numpy().reshape(S, -1)
+    pb = pb.cpu().numpy().view(np.uint16).reshape(S, F)
+    pm = pm.cpu().numpy().reshape(S, F)
+    gmax = gm.cpu().numpy().view(np.float32)[0]
+    best = 0.0
+    for s in range(S):
+        xs = buf[s * stride: s * stride + per]
+        assert np.array_equal(out[s], e.compute_spectrogram_u8(xs, V, 20.0, 80.0))     # same kernel: bit-exact
+        assert np.array_equal(pb[s], e.get_peaks(0.0)) and np.array_equal(pm[s], e.get_peak_magnitudes(0.0))
+        best = max(best, e.get_global_max())
+        assert np.array_equal(mag[s], e.compute_spectrogram(xs, V))
+    assert gmax == np.float32(best)
+    e.free()
+
+
+def test_chunks_with_halo_equal_one_call(kernel_path):
+    # time chunks that overlap by N - hop samples give the frames of the unchunked call bit for bit
+    N, V = 1024, 768
+    H = N - V
+    x = signal(N + 199 * H, 77)
+    e = sa.SpectrogramEngine(N, "hann")
+    whole = e.compute_spectrogram_u8(x, V, 20.0, 80.0).reshape(-1, 512)
+    gwhole = e.get_global_max()
+    parts, gm = [], 0.0
+    for f0 in range(0, 200, 64):
+        f1 = min(f0 + 64, 200)
+        chunk = x[f0 * H: (f1 - 1) * H + N]
+        parts.append(e.compute_spectrogram_u8(chunk, V, 20.0, 80.0).reshape(-1, 512))
+        gm = max(gm, e.get_global_max())
+    assert np.array_equal(np.concatenate(parts), whole) and gm == gwhole
+    e.free()
+
+
+def test_unaligned_input_pointer(kernel_path):
+    # a view that starts 4 bytes into an allocation: frames must not assume 16-byte alignment
+    N, V = 1024, 768
+    base = signal(N + 30 * 256 + 3, 5)
+    o = so.OracleEngine(N, "hann")
+    e = sa.SpectrogramEngine(N, "hann")
+    for shift in (1, 2, 3):
+        x = base[shift:]
+        parity.check_mag(e.compute_spectrogram(x, V), o.compute_spectrogram(x, V), 512, f"shift {shift}")
+    e.free()

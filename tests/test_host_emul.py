@@ -1,0 +1,107 @@
+"""The generic STFT workgroup, emulated phase by phase on the CPU
+(tests/host_emul), against the oracle.  This checks the kernel's index math and
+butterflies in the no-GPU suite; the same code runs as the HIP kernel on the GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import sono_oracle as so
+from tests import parity
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMUL_DIR = os.path.join(HERE, "host_emul")
+
+
+@pytest.fixture(scope="module")
+def emul():
+    lib = os.path.join(EMUL_DIR, "libemul.so")
+    srcs = [os.path.join(EMUL_DIR, f) for f in os.listdir(EMUL_DIR) if f.endswith(".cpp")]
+    deps = srcs + [os.path.join(HERE, "..", "spectrogram_amd", "csrc", h)
+                   for h in ("sono_core.h", "sono_tables.h", "sono_tile_core.h")
+                   if os.path.exists(os.path.join(HERE, "..", "spectrogram_amd", "csrc", h))]
+    if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-o", lib] + srcs)
+    return C.CDLL(lib)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def run_emul(L, fn, mode, x, N, V, window, gain=20.0, rng=80.0, n_streams=1, stride=None):
+    per = len(x) if stride is None else stride
+    H, B = N - V, N // 2
+    F = so.num_frames(per if n_streams > 1 else len(x), N, V)
+    T = F * n_streams
+    mag = np.zeros(T * B, np.float32)
+    u8 = np.zeros(T * B, np.uint8)
+    pb = np.zeros(T, np.uint16)
+    pm = np.zeros(T, np.float32)
+    gm = np.zeros(1, np.uint32)
+    pw = np.zeros(T * (B + 1), np.float32)
+    rc = getattr(L, fn)(C.c_int(mode), _p(x), C.c_ulonglong(n_streams), C.c_ulonglong(per), C.c_ulonglong(F),
+                        C.c_uint(H), C.c_uint(N), _p(window), C.c_float(gain), C.c_float(rng),
+                        _p(mag), _p(u8), _p(pb), _p(pm), _p(gm), _p(pw))
+    assert rc == 0
+    return dict(mag=mag, u8=u8, peak_bin=pb, peak_mag=pm, gmax=float(gm.view(np.float32)[0]), power=pw, F=F)
+
+
+def signal(n, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    return (0.3 * np.sin(0.2 * t + 1e-5 * t * t) + 0.01 * rng.standard_normal(n)).astype(np.float32)
+
+
+@pytest.mark.parametrize("N,V", [(256, 128), (512, 256), (1024, 768), (2048, 1536), (4096, 3891), (1024, 0)])
+def test_generic_block_matches_oracle(emul, N, V):
+    x = signal(N + 9 * (N - V) + 5, N)
+    e = so.OracleEngine(N, "hann")
+    r = run_emul(emul, "emul_generic", 0, x, N, V, e.window)
+    parity.check_mag(r["mag"], e.compute_spectrogram(x, V), N // 2, f"emul mag N={N}")
+    r = run_emul(emul, "emul_generic", 1, x, N, V, e.window)
+    ref = e.compute_spectrogram_u8(x, V, 20.0, 80.0)
+    nd, nt = parity.u8_diff(r["u8"], ref)
+    assert nd <= max(2, 1e-3 * nt)
+    assert np.array_equal(r["peak_bin"], e.get_peaks(0.0))
+    assert np.allclose(r["peak_mag"], e.get_peak_magnitudes(0.0), rtol=1e-6, atol=0)
+    assert abs(r["gmax"] - e.get_global_max()) <= 1e-6 * e.get_global_max()
+
+
+def test_generic_block_batch_layout(emul):
+    # three streams with a stride larger than their length: rows land stream-major
+    N, V, per, stride = 512, 384, 512 + 5 * 128, 2000
+    e = so.OracleEngine(N, "hamming")
+    buf = np.zeros(3 * stride, np.float32)
+    refs = []
+    for s in range(3):
+        xs = signal(per, 100 + s)
+        buf[s * stride: s * stride + per] = xs
+        refs.append(e.compute_spectrogram(xs, V))
+    H, B = N - V, N // 2
+    F = so.num_frames(per, N, V)
+    mag = np.zeros(3 * F * B, np.float32)
+    rc = emul.emul_generic(C.c_int(0), _p(buf), C.c_ulonglong(3), C.c_ulonglong(stride), C.c_ulonglong(F),
+                           C.c_uint(H), C.c_uint(N), _p(e.window), C.c_float(20), C.c_float(80),
+                           _p(mag), None, None, None, None, None)
+    assert rc == 0
+    parity.check_mag(mag, np.concatenate(refs), B, "batch")
+
+
+def test_generic_block_power_mode(emul):
+    N, hop = 1024, 256
+    x = signal(N + 6 * hop, 5) + np.float32(0.02)
+    w = so.create_window("hann", N)
+    r = run_emul(emul, "emul_generic", 2, x, N, N - hop, w)
+    F, B1 = r["F"], N // 2 + 1
+    p = r["power"].reshape(F, B1)
+    s = np.zeros(B1, np.float32)
+    for f in range(F):
+        s += p[f]
+    avg = s / np.float32(F)
+    psd = (np.sqrt(avg) ** 2) / np.float32(N)
+    db = 10 * np.log10(np.maximum(psd, 1e-16))
+    parity.check_power(db.astype(np.float32), so.compute_power_spectrum(x, 384000, N, "hann", 75.0), "emul power")
