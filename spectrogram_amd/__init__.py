@@ -258,7 +258,9 @@ class SpectrogramEngine:
     def stft_u8_dev(self, d_samples, n_streams, stream_stride, samples_per_stream, noverlap, gain_db, range_db,
                     d_out, d_peak_bin=0, d_peak_mag=0, d_gmax_bits=0, stream=0):
         """Launch the fused kernel over samples already in HBM.  Pointer arguments
-        are raw device addresses (e.g. torch.Tensor.data_ptr()); asynchronous."""
+        are raw device addresses (e.g. torch.Tensor.data_ptr()); asynchronous.
+        `stream` is a hipStream_t value (e.g. torch.cuda.Stream().cuda_stream); 0 or
+        None selects the engine's own stream, which `synchronize()` waits for."""
         b = Batch(d_samples, n_streams, stream_stride, samples_per_stream)
         _check(lib().sono_stft_u8_dev(self._handle(), C.byref(b), int(noverlap), float(gain_db), float(range_db),
                                       d_out, d_peak_bin or None, d_peak_mag or None, d_gmax_bits or None,

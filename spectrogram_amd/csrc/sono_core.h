@@ -65,7 +65,8 @@ SONO_HD float2 real_split2(float2 zk, float2 zp, float2 w)
     const float er = zk.x + zp.x, ei = zk.y - zp.y;      // Zk + conj(Zp)
     const float dr = zk.x - zp.x, di = zk.y + zp.y;      // Zk - conj(Zp)
     // 2*Xo = -i * d = (di, -dr);  w * (di, -dr) = (w.x*di + w.y*dr, w.y*di - w.x*dr)
-    return float2{er + (w.x * di + w.y * dr), ei + (w.y * di - w.x * dr)};
+    // written so that each component contracts into two fused multiply-adds
+    return float2{(er + w.y * dr) + w.x * di, (ei - w.x * dr) + w.y * di};
 }
 
 // Quantiser constants for the dB -> u8 law of lib.rs:277-293, restated on
@@ -99,8 +100,12 @@ SONO_HD unsigned int quantise(float p, float q_a, float q_c, float q_floor)
 {
     const float pf = p > q_floor ? p : q_floor;
     float v = q_a * fast_log2(pf) + q_c;
+#if defined(__HIP_DEVICE_COMPILE__)
+    v = __builtin_amdgcn_fmed3f(v, 0.0f, 255.0f);   // one v_med3_f32; a NaN comes out as 0
+#else
     v = v > 0.0f ? v : 0.0f;          // also NaN -> 0
     v = v < 255.0f ? v : 255.0f;
+#endif
     return (unsigned int)v;
 }
 
@@ -268,13 +273,14 @@ struct GenericBlock {
                 o.z = fast_sqrt(p[2]) * a.inv_n; o.w = fast_sqrt(p[3]) * a.inv_n;
                 *(float4 *)(a.out_mag + g * (unsigned long long)M + k0) = o;
             } else if (MODE == MODE_U8) {
+                // The peak is located on p = |2X|^2 (monotone in the magnitude, no sqrt per
+                // bin); the winner's magnitude is formed once per frame in phase_features.
                 unsigned int packed = 0;
                 unsigned long long best = peak_key(0.0f, 0u);
                 for (int r = 0; r < 4; ++r) {
                     packed |= quantise(p[r], a.q_a, a.q_c, a.q_floor) << (8 * r);
-                    const float mag = fast_sqrt(p[r]) * a.inv_n;
-                    if (mag > 0.0f) {                       // false for NaN, like `val > acc`
-                        const unsigned long long key = peak_key(mag, (unsigned int)(k0 + r));
+                    if (p[r] > 0.0f) {                      // false for NaN, like `val > acc`
+                        const unsigned long long key = peak_key(p[r], (unsigned int)(k0 + r));
                         best = key > best ? key : best;
                     }
                 }
@@ -300,17 +306,22 @@ struct GenericBlock {
             const unsigned long long key = sh.peak[t];
             const unsigned int bits = (unsigned int)(key >> 32);
             const unsigned int bin = 0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull);
-            if (a.peak_bin) a.peak_bin[g] = (uint16_t)bin;
-            if (a.peak_mag) {
-                float m;
+            float pmax;
 #if defined(__HIP_DEVICE_COMPILE__)
-                m = __uint_as_float(bits);
+            pmax = __uint_as_float(bits);
 #else
-                std::memcpy(&m, &bits, 4);
+            std::memcpy(&pmax, &bits, 4);
 #endif
-                a.peak_mag[g] = m;
-            }
-            if (a.gmax_bits) atomic_max_u32(a.gmax_bits, bits);
+            const float mag = fast_sqrt(pmax) * a.inv_n;
+            unsigned int mag_bits;
+#if defined(__HIP_DEVICE_COMPILE__)
+            mag_bits = __float_as_uint(mag);
+#else
+            std::memcpy(&mag_bits, &mag, 4);
+#endif
+            if (a.peak_bin) a.peak_bin[g] = (uint16_t)bin;
+            if (a.peak_mag) a.peak_mag[g] = mag;
+            if (a.gmax_bits) atomic_max_u32(a.gmax_bits, mag_bits);
         }
     }
 };

@@ -28,10 +28,11 @@ def hour():
     pb = torch.empty(F, dtype=torch.int16, device="cuda")
     pm = torch.empty(F, dtype=torch.float32, device="cuda")
     gm = torch.zeros(1, dtype=torch.int32, device="cuda")
-    st = torch.cuda.current_stream().cuda_stream
-    e.stft_u8_dev(x.data_ptr(), 1, SAMPLES, SAMPLES, V, 20.0, 80.0, out.data_ptr(), pb.data_ptr(), pm.data_ptr(),
-                  gm.data_ptr(), st)
     torch.cuda.synchronize()
+    # launches go to the engine's own stream (stream=None); synchronise around them
+    e.stft_u8_dev(x.data_ptr(), 1, SAMPLES, SAMPLES, V, 20.0, 80.0, out.data_ptr(), pb.data_ptr(), pm.data_ptr(),
+                  gm.data_ptr())
+    e.synchronize()
     yield dict(x=x, F=F, e=e, out=out.view(F, 512), pb=pb, pm=pm, gm=gm, torch=torch)
     e.free()
 
@@ -67,10 +68,10 @@ def test_time_shift_identity(hour):
     k, cnt = 7, 200000
     n = (cnt - 1) * H + N
     out = torch.empty(cnt * 512, dtype=torch.uint8, device="cuda")
-    st = torch.cuda.current_stream().cuda_stream
     xs = hour["x"][k * H: k * H + n]
-    hour["e"].stft_u8_dev(xs.data_ptr(), 1, n, n, V, 20.0, 80.0, out.data_ptr(), 0, 0, 0, st)
     torch.cuda.synchronize()
+    hour["e"].stft_u8_dev(xs.data_ptr(), 1, n, n, V, 20.0, 80.0, out.data_ptr())
+    hour["e"].synchronize()
     assert torch.equal(out.view(cnt, 512), hour["out"][k:k + cnt])
 
 
@@ -80,7 +81,6 @@ def test_launch_geometry_independent_checksum(hour):
     F = hour["F"]
     total = hour["out"].to(torch.int64).sum().item() if F < 1000 else sum(
         hour["out"][i:i + 500000].sum(dtype=torch.int64).item() for i in range(0, F, 500000))
-    st = torch.cuda.current_stream().cuda_stream
     acc = 0
     step = 1333333
     buf = torch.empty(step * 512, dtype=torch.uint8, device="cuda")
@@ -88,8 +88,9 @@ def test_launch_geometry_independent_checksum(hour):
         f1 = min(f0 + step, F)
         n = (f1 - f0 - 1) * H + N
         xs = hour["x"][f0 * H: f0 * H + n]
-        hour["e"].stft_u8_dev(xs.data_ptr(), 1, n, n, V, 20.0, 80.0, buf.data_ptr(), 0, 0, 0, st)
         torch.cuda.synchronize()
+        hour["e"].stft_u8_dev(xs.data_ptr(), 1, n, n, V, 20.0, 80.0, buf.data_ptr())
+        hour["e"].synchronize()
         acc += buf[: (f1 - f0) * 512].sum(dtype=torch.int64).item()
     assert acc == total
 
@@ -102,11 +103,13 @@ def test_amplitude_scaling_identity(hour):
     xs = hour["x"][:n].clone()
     a = torch.empty(cnt * 512, dtype=torch.float32, device="cuda")
     b = torch.empty(cnt * 512, dtype=torch.float32, device="cuda")
-    st = torch.cuda.current_stream().cuda_stream
-    hour["e"].stft_mag_f32_dev(xs.data_ptr(), 1, n, n, V, a.data_ptr(), st)
-    xs.mul_(0.125)
-    hour["e"].stft_mag_f32_dev(xs.data_ptr(), 1, n, n, V, b.data_ptr(), st)
     torch.cuda.synchronize()
+    hour["e"].stft_mag_f32_dev(xs.data_ptr(), 1, n, n, V, a.data_ptr())
+    hour["e"].synchronize()
+    xs.mul_(0.125)
+    torch.cuda.synchronize()
+    hour["e"].stft_mag_f32_dev(xs.data_ptr(), 1, n, n, V, b.data_ptr())
+    hour["e"].synchronize()
     assert torch.equal(a * 0.125, b)
 
 

@@ -190,11 +190,11 @@ def test_batch_dev_matches_single_streams(kernel_path):
     gm = torch.zeros(1, dtype=torch.int32, device="cuda")
     mag = torch.zeros(S * F * 512, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
-    st = torch.cuda.current_stream().cuda_stream
+    st = torch.cuda.Stream()                 # a caller-supplied HIP stream
     e.stft_u8_dev(dx.data_ptr(), S, stride, per, V, 20.0, 80.0, out.data_ptr(), pb.data_ptr(), pm.data_ptr(),
-                  gm.data_ptr(), st)
-    e.stft_mag_f32_dev(dx.data_ptr(), S, stride, per, V, mag.data_ptr(), st)
-    torch.cuda.synchronize()
+                  gm.data_ptr(), st.cuda_stream)
+    e.stft_mag_f32_dev(dx.data_ptr(), S, stride, per, V, mag.data_ptr(), st.cuda_stream)
+    st.synchronize()
     out, mag = out.cpu().numpy().reshape(S, -1), mag.cpu().numpy().reshape(S, -1)
     pb = pb.cpu().numpy().view(np.uint16).reshape(S, F)
     pm = pm.cpu().numpy().reshape(S, F)

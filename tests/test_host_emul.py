@@ -105,3 +105,38 @@ def test_generic_block_power_mode(emul):
     psd = (np.sqrt(avg) ** 2) / np.float32(N)
     db = 10 * np.log10(np.maximum(psd, 1e-16))
     parity.check_power(db.astype(np.float32), so.compute_power_spectrum(x, 384000, N, "hann", 75.0), "emul power")
+
+
+@pytest.mark.parametrize("N,V", [(1024, 768), (1024, 0), (1024, 1022), (512, 256), (512, 384), (256, 128), (256, 64)])
+def test_tile_wave_matches_oracle(emul, N, V):
+    H = N - V
+    x = signal(N + 10 * H + (H - 1 if H > 1 else 0), N + 1)
+    e = so.OracleEngine(N, "hann")
+    r = run_emul(emul, "emul_tile", 0, x, N, V, e.window)
+    parity.check_mag(r["mag"], e.compute_spectrogram(x, V), N // 2, f"tile mag N={N}")
+    r = run_emul(emul, "emul_tile", 1, x, N, V, e.window)
+    ref = e.compute_spectrogram_u8(x, V, 20.0, 80.0)
+    nd, nt = parity.u8_diff(r["u8"], ref)
+    assert nd <= max(2, 1e-3 * nt)
+    assert np.array_equal(r["peak_bin"], e.get_peaks(0.0))
+    assert np.allclose(r["peak_mag"], e.get_peak_magnitudes(0.0), rtol=1e-6, atol=0)
+    assert abs(r["gmax"] - e.get_global_max()) <= 1e-6 * e.get_global_max()
+
+
+def test_tile_wave_batch_with_partial_tiles(emul):
+    # 3 streams of 9 frames each: 9 is not a multiple of the 4 frames a wave holds at N=1024
+    N, V, per, stride = 1024, 768, 1024 + 8 * 256, 4000
+    e = so.OracleEngine(N, "hann")
+    buf = np.zeros(3 * stride, np.float32)
+    refs = []
+    for s in range(3):
+        xs = signal(per, 200 + s)
+        buf[s * stride: s * stride + per] = xs
+        refs.append(e.compute_spectrogram(xs, V))
+    F = so.num_frames(per, N, V)
+    mag = np.zeros(3 * F * 512, np.float32)
+    rc = emul.emul_tile(C.c_int(0), _p(buf), C.c_ulonglong(3), C.c_ulonglong(stride), C.c_ulonglong(F),
+                        C.c_uint(N - V), C.c_uint(N), _p(e.window), C.c_float(20), C.c_float(80),
+                        _p(mag), None, None, None, None, None)
+    assert rc == 0
+    parity.check_mag(mag, np.concatenate(refs), 512, "tile batch")
