@@ -84,7 +84,7 @@ int build_tables(unsigned int N, const float *window, Tables &t)
     HIP_TRY(hipMemcpy(t.d_window, window, N * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t.d_tw_half, twh.data(), twh.size() * sizeof(float2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t.d_tw_full, twf.data(), twf.size() * sizeof(float2), hipMemcpyHostToDevice));
-    hipError_t e = sono::tile_tables_build(N, window, t.tile);
+    hipError_t e = sono::tile_tables_build(N, t.tile);
     if (e != hipSuccess) return hip_fail(e, "tile_tables_build");
     return SONO_OK;
 }

@@ -1,21 +1,49 @@
 // sono_tile.hip -- register-tiled fused STFT kernel for fft sizes 256/512/1024.
 //
-// Persistent waves: a workgroup is four independent waves, each owning a private
-// 17 KB LDS image; a wave walks tiles wave_id, wave_id + n_waves, ... so that the
-// waves in flight at any moment read one contiguous stretch of samples (75 % of a
-// tile's samples are shared with its neighbours and are served by L2).  The only
-// data shared inside a workgroup is the read-only W_N^k table.  Loads of the next
-// tile are issued right after phase 1 has consumed the current one.
+// Persistent waves.  A workgroup is kWavesPerBlock independent waves, each owning
+// a private 8.25 KB LDS region that is first the pass-1 -> pass-2 exchange image
+// and then the bin-major power image; the only data shared inside a workgroup are
+// the read-only window and inter-pass twiddle tables, a row of zeros and the tile
+// counter.  One workgroup of twelve waves per CU, i.e. three waves per SIMD and
+// 168 VGPRs per lane: enough waves to keep the vector ALU issuing while others
+// sit in LDS or memory waits, without register spills.
+//
+// Tile walk: the tiles of a launch are cut into one contiguous range per XCD
+// (workgroups are dealt round-robin to the eight XCDs), and inside a range the
+// resident waves sweep forward together, so the 75 % of a tile's samples that it
+// shares with its neighbours is served by that XCD's L2 instead of being fetched
+// from HBM once per XCD.
 #include "sono_tile.h"
 
+#include <vector>
+
+#include "sono_tables.h"
 #include "sono_tile_core.h"
 
 namespace sono {
 
 namespace {
 
-constexpr int kWavesPerBlock = 4;
-constexpr int kBlocksPerCU = 2;
+// Overridable so that tools/expbuild.sh can sweep occupancy.
+#ifndef SONO_WPB
+#define SONO_WPB 12
+#endif
+#ifndef SONO_WPS
+#define SONO_WPS 3
+#endif
+constexpr int kWavesPerBlock = SONO_WPB;
+constexpr int kWavesPerSimd = SONO_WPS;
+constexpr int kBlocksPerCU = 4 * kWavesPerSimd / kWavesPerBlock;
+constexpr int kXcds = 8;
+
+// Diagnostic build (-DSONO_EXP_STAMPS, tools/expbuild.sh): every wave sums the
+// shader-clock cycles it spends in each phase; tools/kbench prints the totals.
+#ifdef SONO_EXP_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc[i] += now_ - last; last = now_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 struct LdsMax64 {
     __device__ void operator()(unsigned long long *p, unsigned long long v) const { atomicMax(p, v); }
@@ -29,46 +57,124 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_sched_barrier(0);      // and keeps one phase's arithmetic (and registers) out of the next
 }
 
-template <int LOG_M1, int MODE>
-__global__ __launch_bounds__(64 * kWavesPerBlock, kBlocksPerCU) void stft_tile_kernel(const StftArgs a,
-                                                                                     const tile::TileIter it)
+// Maximum over the 32 lanes of this lane's half of the wave, in every lane.
+__device__ __forceinline__ float half_wave_max(float v)
 {
-    using G = tile::Geo<LOG_M1>;
-    __shared__ __align__(16) float2 s_img[kWavesPerBlock * tile::kWaveLdsComplex];
-    __shared__ __align__(16) float2 s_tw[G::M];
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xf, 0xf, true)));   // row_ror:8
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x124, 0xf, 0xf, true)));   // row_ror:4
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x122, 0xf, 0xf, true)));   // row_ror:2
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x121, 0xf, 0xf, true)));   // row_ror:1
+    // rows 0/1 and 2/3 trade places: every lane then holds both rows' maxima of its half
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+template <int LOG_R1, int MODE>
+__global__ __launch_bounds__(64 * kWavesPerBlock, kWavesPerSimd) void stft_tile_kernel(const StftArgs a,
+                                                                                      const tile::TileIter it,
+                                                                                      const float2 *tw_rows)
+{
+    using G = tile::Geo<LOG_R1>;
+    __shared__ __align__(16) float s_img[kWavesPerBlock * tile::kRegionFloats];
+    __shared__ __align__(16) float2 s_tw[G::TW_ROWS * 32];
+    __shared__ __align__(16) float s_win[G::N];
     __shared__ unsigned long long s_peak[kWavesPerBlock * 16];
+    __shared__ unsigned int s_next;
+    __shared__ float s_meta[kWavesPerBlock * tile::kMetaFloats];
+    __shared__ __align__(16) float s_zero[G::BINS];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = threadIdx.x; i < G::M; i += blockDim.x) s_tw[i] = a.tw_full[i];
+    for (int i = threadIdx.x; i < G::TW_ROWS * 32; i += blockDim.x) s_tw[i] = tw_rows[i];
+    for (int i = threadIdx.x; i < G::N; i += blockDim.x) s_win[i] = a.window[i];
     if (threadIdx.x < kWavesPerBlock * 16) s_peak[threadIdx.x] = peak_key(0.0f, 0u);
+    if (threadIdx.x == 0) s_next = 0u;
+    for (int i = threadIdx.x; i < G::BINS; i += blockDim.x) s_zero[i] = 0.0f;
     __syncthreads();
 
-    float2 *img = s_img + wave * tile::kWaveLdsComplex;
-    unsigned long long *peak_slot = s_peak + wave * 16 + (lane >> LOG_M1);
-    const unsigned long long stride = (unsigned long long)gridDim.x * kWavesPerBlock;
-    unsigned long long t = (unsigned long long)blockIdx.x * kWavesPerBlock + wave;
+    float *img = s_img + wave * tile::kRegionFloats;
+    float *meta = s_meta + wave * tile::kMetaFloats;
+    unsigned long long *peak_slot = s_peak + wave * 16 + (lane >> (LOG_R1 - 1));
 
-    tile::TileLane<LOG_M1, MODE> L(a, lane);
-    if (t < it.n_tiles) L.load(t, it);
-    for (; t < it.n_tiles; t += stride) {
-        L.run_phase1(img);
-        if (t + stride < it.n_tiles) L.load(t + stride, it);      // prefetch: in flight during phases 2-3
-        wave_lds_fence();
+    // This workgroup's share of the tiles.  The launch is cut into one contiguous
+    // range per XCD; inside a range, groups of kWavesPerBlock consecutive tiles are
+    // dealt round-robin to the range's workgroups, so the resident workgroups sweep
+    // forward together.  Inside a workgroup (= all the waves of one CU) every wave
+    // claims the next unclaimed tile from an LDS counter: the SIMD favours its
+    // oldest wave, and with a fixed split the youngest waves would still be
+    // working long after the oldest had left.
+    const unsigned int parts = gridDim.x < (unsigned int)kXcds ? gridDim.x : (unsigned int)kXcds;
+    const unsigned int part = blockIdx.x % parts, lb = blockIdx.x / parts;
+    const unsigned int blocks_in_part = (gridDim.x - part + parts - 1) / parts;
+    const unsigned long long t_first = it.n_tiles * part / parts;
+    const unsigned long long t_count = it.n_tiles * (part + 1) / parts - t_first;
+    tile::TileLane<LOG_R1, MODE> L(a, lane);
+    auto claim = [&]() -> unsigned long long {          // -> index of the claimed tile inside the range
+        unsigned int c = 0;
+        if (lane == 0) c = atomicAdd(&s_next, 1u);
+        c = __builtin_amdgcn_readfirstlane(c);
+        const unsigned long long group = (unsigned long long)(c / kWavesPerBlock) * blocks_in_part + lb;
+        return group * kWavesPerBlock + c % kWavesPerBlock;
+    };
+    unsigned long long cur = claim();
+
+#ifdef SONO_EXP_STAMPS
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime(), rt_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long last = t_begin;
+#endif
+    while (cur < t_count) {
+        const unsigned long long t = t_first + cur;
+        const unsigned long long nxt = claim();           // returns while this tile is being worked on
         float re[32], im[32];
-        L.run_phase2_load(img, re, im);
+        {
+            float rr[32], ri[32];
+            L.load(t, it);
+            STAMP(0);
+            float ma[G::JPL], mb[G::JPL];
+            L.scan(ma, mb);
+            for (int jj = 0; jj < G::JPL; ++jj) { ma[jj] = half_wave_max(ma[jj]); mb[jj] = half_wave_max(mb[jj]); }
+            L.pass1(s_win, s_tw, ma, mb, rr, ri, meta);
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(1);
+            L.exchange_store(rr, img);
+            wave_lds_fence();
+            L.exchange_load(img, re);
+            wave_lds_fence();
+            L.exchange_store(ri, img);
+            wave_lds_fence();
+            L.exchange_load(img, im);
+            wave_lds_fence();
+            STAMP(2);
+        }
+        L.pass2_power(re, im, L.pass2_scale(meta), img);
         wave_lds_fence();
-        L.run_phase2_fft_store(re, im, img);
-        wave_lds_fence();
-        L.run_phase3(t, it, img, s_tw, peak_slot, LdsMax64());
+        STAMP(3);
+        L.epilogue(t, it, img, meta, s_zero, peak_slot, LdsMax64());
         if (MODE == MODE_U8) {
             wave_lds_fence();
-            L.run_phase4(t, it, peak_slot);
+            L.features(t, it, peak_slot);
         }
         wave_lds_fence();
+        STAMP(4);
+        cur = nxt;
     }
+#ifdef SONO_EXP_STAMPS
+    if (lane == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_stamps[i], acc[i]);
+        atomicAdd(&g_stamps[8], __builtin_amdgcn_s_memtime() - t_begin);
+        atomicAdd(&g_stamps[9], __builtin_amdgcn_s_memrealtime() - rt_begin);
+        atomicAdd(&g_stamps[10], 1ull);
+        atomicMax(&g_stamps[11], __builtin_amdgcn_s_memtime() - t_begin);
+        atomicMax(&g_stamps[12], __builtin_amdgcn_s_memrealtime());
+        atomicMin(&g_stamps[13], rt_begin);
+        atomicMax(&g_stamps[14], rt_begin);
+        atomicMin(&g_stamps[15], __builtin_amdgcn_s_memrealtime());
+    }
+#endif
     if (MODE == MODE_U8 && a.gmax_bits) {
         // wave-wide maximum of |2X|^2, then one atomic per wave on the magnitude's bit pattern
         float m = L.run_max;
@@ -77,10 +183,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kBlocksPerCU) void stft_tile_k
     }
 }
 
-template <int LOG_M1, int MODE>
-hipError_t launch_one(const StftArgs &a, hipStream_t stream)
+template <int LOG_R1, int MODE>
+hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, hipStream_t stream)
 {
-    using G = tile::Geo<LOG_M1>;
+    using G = tile::Geo<LOG_R1>;
     tile::TileIter it;
     const unsigned long long tps = (a.frames_per_stream + G::FPW - 1) / G::FPW;
     it.tiles_per_stream = (unsigned int)tps;
@@ -94,33 +200,52 @@ hipError_t launch_one(const StftArgs &a, hipStream_t stream)
     unsigned long long blocks = (it.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const unsigned long long resident = (unsigned long long)cus * kBlocksPerCU;
     if (blocks > resident) blocks = resident;
-    hipLaunchKernelGGL((stft_tile_kernel<LOG_M1, MODE>), dim3((unsigned int)blocks), dim3(64 * kWavesPerBlock), 0,
-                       stream, a, it);
+    hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, MODE>), dim3((unsigned int)blocks), dim3(64 * kWavesPerBlock), 0,
+                       stream, a, it, tw_rows);
     return hipGetLastError();
 }
 
 template <int MODE>
-hipError_t launch_mode(const StftArgs &a, hipStream_t stream)
+hipError_t launch_mode(const StftArgs &a, const float2 *tw_rows, hipStream_t stream)
 {
     switch (a.N) {
-    case 1024: return launch_one<4, MODE>(a, stream);
-    case 512: return launch_one<3, MODE>(a, stream);
-    case 256: return launch_one<2, MODE>(a, stream);
+    case 1024: return launch_one<5, MODE>(a, tw_rows, stream);
+    case 512: return launch_one<4, MODE>(a, tw_rows, stream);
+    case 256: return launch_one<3, MODE>(a, tw_rows, stream);
     default: return hipErrorInvalidValue;
     }
 }
 
 }  // namespace
 
-hipError_t tile_tables_build(unsigned int N, const float *, TileTables &t) { t.N = N; return hipSuccess; }
+#ifdef SONO_EXP_STAMPS
+extern "C" void sono_debug_stamps(unsigned long long *out)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
+    unsigned long long z[16] = {0};
+    z[13] = z[15] = ~0ull;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
+}
+#endif
+
+hipError_t tile_tables_build(unsigned int N, TileTables &t)
+{
+    t.N = N;
+    t.d_blob = nullptr;
+    if (N != 1024 && N != 512 && N != 256) return hipSuccess;
+    const std::vector<float2> rows = make_tile_twiddles(N);
+    hipError_t e = hipMalloc(&t.d_blob, rows.size() * sizeof(float2));
+    if (e != hipSuccess) { t.d_blob = nullptr; return e; }
+    return hipMemcpy(t.d_blob, rows.data(), rows.size() * sizeof(float2), hipMemcpyHostToDevice);
+}
+
 void tile_tables_release(TileTables &t) { if (t.d_blob) (void)hipFree(t.d_blob); t.d_blob = nullptr; }
 
-bool tile_supports(int mode, const StftArgs &a, const TileTables &)
+bool tile_supports(int mode, const StftArgs &a, const TileTables &t)
 {
     if (mode != MODE_MAG && mode != MODE_U8) return false;
     if (a.N != 1024 && a.N != 512 && a.N != 256) return false;
-    if ((a.hop & 1u) || (reinterpret_cast<uintptr_t>(a.x) & 7u)) return false;
-    if (a.n_streams > 1 && (a.stream_stride & 1ull)) return false;
+    if (!t.d_blob || t.N != a.N) return false;
     const unsigned long long tps = (a.frames_per_stream + 3) / 4;
     if (tps >= 0xFFFFFFFFull) return false;
     if (mode == MODE_MAG && (reinterpret_cast<uintptr_t>(a.out_mag) & 15u)) return false;
@@ -128,9 +253,10 @@ bool tile_supports(int mode, const StftArgs &a, const TileTables &)
     return true;
 }
 
-hipError_t launch_stft_tile(int mode, const StftArgs &a, const TileTables &, hipStream_t stream)
+hipError_t launch_stft_tile(int mode, const StftArgs &a, const TileTables &t, hipStream_t stream)
 {
-    return mode == MODE_MAG ? launch_mode<MODE_MAG>(a, stream) : launch_mode<MODE_U8>(a, stream);
+    const float2 *tw_rows = (const float2 *)t.d_blob;
+    return mode == MODE_MAG ? launch_mode<MODE_MAG>(a, tw_rows, stream) : launch_mode<MODE_U8>(a, tw_rows, stream);
 }
 
 }  // namespace sono

@@ -1,31 +1,61 @@
 // sono_tile_core.h -- per-lane arithmetic of the register-tiled STFT kernel.
 //
-// One wave64 transforms a tile of 1024 complex points = 2048 real samples' worth
-// of packed frames: 64/M1 frames of N = 64*M1 samples (M1 = 16, 8, 4 for
-// N = 1024, 512, 256).  A frame is packed as z[n] = x[2n] + i x[2n+1] (M = 32*M1
-// complex points) and transformed in two in-register passes with one exchange
-// through wave-private LDS in between:
+// One wave64 transforms FPW = 128/R1 real frames of N = 32*R1 samples
+// (R1 = 32, 16, 8 for N = 1024, 512, 256), two frames ("a pair": A = 2q, B = 2q+1)
+// at a time, with a two-pass real-input FFT that never forms the redundant half
+// of the spectrum:
 //
-//   phase 1  lane = (half h, n2 in [0,32)); registers = (frame of the half, n1):
-//            window, radix-M1 DFT over n1 (n = 32*n1 + n2), twiddle W_M^(n2*k1),
-//            write image T[frame][k1][n2]
-//   phase 2  lane = (frame, k1 in [0,M1)); registers = n2: radix-32 DFT over n2
-//            -> Z[k1 + M1*k2]; write image U[frame][k] in natural order
-//   phase 3  lane = (frame, l in [0,M1)) owns bins 4l + 4*M1*m + r (m < 8, r < 4):
-//            reads Z[k] and Z[M-k], real split, magnitude / dB / u8 / peak.
+//   X[k1 + R1*k2] = sum_{n2<32} W_32^(n2*k2) * W_N^(n2*k1) * Y[k1][n2],
+//   Y[k1][n2]     = sum_{n1<R1} xw[32*n1 + n2] * W_R1^(n1*k1)          (xw = x * window)
 //
-// Everything is __host__ __device__: tests/host_emul runs the three phases lane
-// by lane against an ordinary array standing in for LDS.
+//   pass 1  lane = (h, n2), R1 register points n1: ONE complex DFT-R1 of
+//           (xwA + i*xwB) per pair gives Y_A and Y_B by conjugate symmetry:
+//             2*Y_A[k1] = C[k1] + conj C[R1-k1],  2*Y_B[k1] = -i*(C[k1] - conj C[R1-k1])
+//           for k1 = 1..R1/2-1; the two real rows k1 = 0 and k1 = R1/2 of both
+//           frames ride together as (Y_A, Y_B) = (Re C, Im C).  Each row is
+//           multiplied by W_N^(n2*k1) and written to the wave's LDS image
+//           [row][n2], real parts first, imaginary parts in a second round over
+//           the same 8 KB.
+//   pass 2  lane = row (pair q, rho): rho = k1 in 1..R1/2-1 carries frame A,
+//           rho = R1/2 + k1 frame B, rho = 0 and rho = R1/2 the two shared real
+//           rows.  One complex DFT-32 over n2 leaves 2*X[k1 + R1*k2] in register
+//           k2; registers k2 >= 16 hold the conjugates of bins
+//           (R1-k1) + R1*(31-k2), so a lane ends with 32 distinct bins < N/2 of
+//           its frame and nothing is computed twice.  The shared rows hold
+//           DFT32(Y_A + i*Y_B); |2*X_A|^2 and |2*X_B|^2 of their 16 bins are
+//           |C[t] +- conj C[partner(t)]|^2, formed by the same instructions that
+//           square the frame rows (see pass2_power).
+//   power   every lane scatters its 32 values of |2X|^2 into a bin-major image;
+//           the epilogue reads it back four consecutive bins per lane:
+//           log2 -> dB -> u8 -> one dword store, running arg-max for the
+//           per-frame peak.
+//
+//   scale   A + iB in one DFT leaks rounding noise of the louder frame into the
+//           quieter one (about 1e-7 of the LOUDER frame's level).  Frame B is
+//           therefore multiplied by the power of two that brings its largest
+//           sample to A's binade before pass 1 and divided back right after the
+//           separation (both exact); the shared rows stay scaled through pass 2
+//           and their |2X_B|^2 is corrected by the squared factor.  A frame of
+//           exact zeros must come out as exact zeros: the epilogue reads such a
+//           frame's bins from a row of zeros instead of the power image.
+//
+// Everything is __host__ __device__: tests/host_emul runs the passes lane by
+// lane against an ordinary array standing in for LDS.
 #pragma once
 #include <type_traits>
 #include <utility>
 
 #include "sono_core.h"
 
+#ifndef SONO_EPI_UNROLL
+#define SONO_EPI_UNROLL 1
+#endif
+#define SONO_PRAGMA_(x) _Pragma(#x)
+#define SONO_PRAGMA(x) SONO_PRAGMA_(x)
 #if defined(__clang__)
-#define SONO_NO_UNROLL _Pragma("clang loop unroll(disable)")
+#define SONO_EPILOGUE_UNROLL SONO_PRAGMA(clang loop unroll_count(SONO_EPI_UNROLL))
 #else
-#define SONO_NO_UNROLL
+#define SONO_EPILOGUE_UNROLL
 #endif
 
 namespace sono {
@@ -114,200 +144,239 @@ SONO_HD void dft_bitrev_in(float (&re)[N], float (&im)[N])
 }
 
 // ---- tile geometry -----------------------------------------------------------
-constexpr int kRowStride = 34;                 // complex entries per image row: 32 + 2 pad (16-byte aligned, bank-conflict free)
-constexpr int kWaveLdsComplex = 64 * kRowStride;   // one wave's LDS image, in complex entries (17 408 B)
-
-template <int LOG_M1>
+template <int LOG_R1>
 struct Geo {
-    static constexpr int M1 = 1 << LOG_M1;     // pass-1 radix = lanes per frame
-    static constexpr int M = 32 * M1;          // complex points per frame
-    static constexpr int N = 2 * M;            // real samples per frame
-    static constexpr int FPW = 64 / M1;        // frames per wave
-    static constexpr int FPH = FPW / 2;        // frames per half-wave (phase 1)
+    static constexpr int R1 = 1 << LOG_R1;     // pass-1 radix = image rows per frame pair
+    static constexpr int N = 32 * R1;          // real samples per frame
+    static constexpr int BINS = N / 2;
+    static constexpr int HALF = R1 / 2;        // the Nyquist row of pass 1; lanes per frame in the epilogue
+    static constexpr int PPW = 64 / R1;        // frame pairs per wave
+    static constexpr int FPW = 2 * PPW;        // frames per wave
+    static constexpr int JPL = 32 / R1;        // pass-1 jobs (pairs) per lane
+    static constexpr int PROW = BINS + HALF;   // floats per frame in the power image: the pad puts the frames
+                                               // of one 32-lane store group on disjoint banks
+    static constexpr int TW_ROWS = HALF;       // twiddle rows k1 = 1..R1/2, 32 entries (n2) each
 };
 
-// Per-tile frame descriptor: sample offset of each of the wave's frames
-// (negative = frame does not exist), indexed by frame-in-wave.
-struct TileFrames {
-    long long off[16];
-};
+// A wave's LDS region is first the exchange image, then the power image.
+//
+// Exchange image: 64 rows (one per pass-2 lane) of 32 floats, no padding.  Row L
+// keeps its eight 16-byte chunks in the order chunk ^ ((L >> 1) & 7): the
+// 16-lane groups in which ds_read_b128 is serviced then touch 16 disjoint
+// 4-bank sets when every lane reads the same chunk of its own row, and a
+// pass-1 store (32 lanes, one row, 32 columns) still covers 32 distinct banks.
+constexpr int kRegionFloats = 2112;                     // max(64*32, FPW*PROW) = 8 448 B per wave
+SONO_HD int image_index(int row, int col) { return row * 32 + (col ^ (((row >> 1) & 7) << 2)); }
 
-// ---- phase 1 -------------------------------------------------------------------
-// in:   xr/xi[fr*M1 + n1] = samples 2n, 2n+1 (n = 32*n1 + n2) of frame h*FPH + fr
-//       wr/wi[n1]         = window at those positions
-//       tw_re/tw_im[k1]   = W_M^(n2*k1)
-// out:  image T: entry ((h*FPH + fr)*M1 + k1)*kRowStride + n2
-template <int LOG_M1>
-SONO_HD void phase1(int lane, const float (&xr)[32], const float (&xi)[32], const float (&wr)[Geo<LOG_M1>::M1],
-                    const float (&wi)[Geo<LOG_M1>::M1], const float (&tw_re)[Geo<LOG_M1>::M1],
-                    const float (&tw_im)[Geo<LOG_M1>::M1], float2 *T)
-{
-    using G = Geo<LOG_M1>;
-    const int h = lane >> 5, n2 = lane & 31;
-    static_for<0, G::FPH>([&](auto fr_) {
-        constexpr int fr = decltype(fr_)::value;
-        float re[G::M1], im[G::M1];
-        static_for<0, G::M1>([&](auto i_) {
-            constexpr int i = decltype(i_)::value, n1 = bitrev(i, LOG_M1);
-            re[i] = xr[fr * G::M1 + n1] * wr[n1];
-            im[i] = xi[fr * G::M1 + n1] * wi[n1];
-        });
-        dft_bitrev_in<G::M1>(re, im);
-        float2 *row = T + ((h * G::FPH + fr) * G::M1) * kRowStride + n2;
-        row[0] = float2{re[0], im[0]};
-        static_for<1, G::M1>([&](auto k_) {
-            constexpr int k1 = decltype(k_)::value;
-            const float yr = re[k1] * tw_re[k1] - im[k1] * tw_im[k1];
-            const float yi = re[k1] * tw_im[k1] + im[k1] * tw_re[k1];
-            row[k1 * kRowStride] = float2{yr, yi};
-        });
-    });
-}
+// Per-wave, per-tile side information handed from pass 1 to the later passes
+// through LDS: [pair q] = g^2, the factor that undoes frame B's scaling in
+// |2X_B|^2 of the pair's shared rows; [kMetaNonZero + frame] = 1 if the frame has
+// a non-zero sample, else 0.
+constexpr int kMetaNonZero = 8;
+constexpr int kMetaFloats = 24;
 
-// ---- phase 2 -------------------------------------------------------------------
-// lane = frame*M1 + k1 reads its image row (32 entries), runs the radix-32 DFT and
-// writes Z[k1 + M1*k2] to the natural-order image U[frame*M + k].
-template <int LOG_M1>
-SONO_HD void phase2_load(int lane, const float2 *T, float (&re)[32], float (&im)[32])
-{
-    const float4 *row = (const float4 *)(T + lane * kRowStride);     // row = frame*M1 + k1 = lane
-    static_for<0, 16>([&](auto j_) {
-        constexpr int j = decltype(j_)::value;
-        const float4 v = row[j];                                     // entries n2 = 2j, 2j+1
-        re[bitrev(2 * j, 5)] = v.x; im[bitrev(2 * j, 5)] = v.y;
-        re[bitrev(2 * j + 1, 5)] = v.z; im[bitrev(2 * j + 1, 5)] = v.w;
-    });
-}
+#if defined(__HIP_DEVICE_COMPILE__)
+SONO_HD int float_exponent(float v) { return __builtin_amdgcn_frexp_expf(v); }
+SONO_HD float pow2(int e) { return __builtin_amdgcn_ldexpf(1.0f, e); }
+#else
+SONO_HD int float_exponent(float v) { int e = 0; (void)std::frexp(v, &e); return e; }
+SONO_HD float pow2(int e) { return std::ldexp(1.0f, e); }
+#endif
 
-template <int LOG_M1>
-SONO_HD void phase2_store(int lane, const float (&re)[32], const float (&im)[32], float2 *U)
-{
-    using G = Geo<LOG_M1>;
-    const int frame = lane >> LOG_M1, k1 = lane & (G::M1 - 1);
-    float2 *u = U + frame * G::M + k1;
-    static_for<0, 32>([&](auto k_) {
-        constexpr int k2 = decltype(k_)::value;
-        u[k2 * G::M1] = float2{re[k2], im[k2]};
-    });
-}
-
-// ---- phase 3 -------------------------------------------------------------------
-// |2X[k]|^2 for the four bins k0..k0+3 (k0 = 4l + 4*M1*m) of the lane's frame.
-// Zf = U + frame*M; tw = W_N^k table (N/2 entries, 16-byte aligned).
-template <int LOG_M1>
-SONO_HD void phase3_group(const float2 *Zf, const float2 *tw, int k0, float (&p)[4])
-{
-    using G = Geo<LOG_M1>;
-    const float4 z01 = *(const float4 *)(Zf + k0), z23 = *(const float4 *)(Zf + k0 + 2);
-    const float4 w01 = *(const float4 *)(tw + k0), w23 = *(const float4 *)(tw + k0 + 2);
-    const int K = G::M - k0;                            // partner of k0 (mod M); partners of k0+1.. are K-1..
-    const float2 p0 = Zf[K & (G::M - 1)];
-    const float4 p21 = *(const float4 *)(Zf + K - 2);   // entries K-2, K-1 (K-2 is even: 16-byte aligned)
-    const float2 p3 = Zf[K - 3];
-    const float2 p2 = float2{p21.x, p21.y}, p1 = float2{p21.z, p21.w};
-    const float2 x0 = real_split2(float2{z01.x, z01.y}, p0, float2{w01.x, w01.y});
-    const float2 x1 = real_split2(float2{z01.z, z01.w}, p1, float2{w01.z, w01.w});
-    const float2 x2 = real_split2(float2{z23.x, z23.y}, p2, float2{w23.x, w23.y});
-    const float2 x3 = real_split2(float2{z23.z, z23.w}, p3, float2{w23.z, w23.w});
-    p[0] = x0.x * x0.x + x0.y * x0.y;
-    p[1] = x1.x * x1.x + x1.y * x1.y;
-    p[2] = x2.x * x2.x + x2.y * x2.y;
-    p[3] = x3.x * x3.x + x3.y * x3.y;
-}
-
-// ---- one lane of one wave ------------------------------------------------------
-// Tiles never straddle streams: stream s owns tiles [s*tps, (s+1)*tps), tile j of
-// a stream covers its frames j*FPW .. j*FPW + FPW-1 (the last tile may be partial).
+// Per-launch tile walk.  Tiles never straddle streams: stream s owns tiles
+// [s*tps, (s+1)*tps); tile j of a stream covers its frames j*FPW .. j*FPW+FPW-1
+// (the last tile of a stream may be partial).
 struct TileIter {
     unsigned int tiles_per_stream;     // ceil(frames_per_stream / FPW)
     unsigned long long n_tiles;        // n_streams * tiles_per_stream
 };
 
-template <int LOG_M1, int MODE>
+// ---- one lane of one wave ------------------------------------------------------
+template <int LOG_R1, int MODE>
 struct TileLane {
-    using G = Geo<LOG_M1>;
+    using G = Geo<LOG_R1>;
     const StftArgs &a;
     int lane;
-    // per-lane constants
-    float wr[G::M1], wi[G::M1];        // window at samples 64*n1 + 2*n2 (+1)
-    float t1r[G::M1], t1i[G::M1];      // W_M^(n2*k1)
-    // tile inputs (prefetched one tile ahead)
-    float xr[32], xi[32];
-    // running maximum of |2X|^2 over every frame this lane has seen (MODE_U8)
-    float run_max;
+    float xa[32], xb[32];              // samples of frames A / B of job jj at [jj*R1 + n1]
+    float run_max;                     // running maximum of |2X|^2 over every frame this lane has finished (MODE_U8)
 
-    SONO_HD TileLane(const StftArgs &args, int lane_) : a(args), lane(lane_), run_max(0.0f)
-    {
-        const int n2 = lane & 31;
-        static_for<0, G::M1>([&](auto n_) {
-            constexpr int n1 = decltype(n_)::value;
-            wr[n1] = a.window[64 * n1 + 2 * n2];
-            wi[n1] = a.window[64 * n1 + 2 * n2 + 1];
-            const float2 w = a.tw_half[(n2 * n1) & (G::M - 1)];
-            t1r[n1] = w.x; t1i[n1] = w.y;
-        });
-    }
+    SONO_HD TileLane(const StftArgs &args, int lane_) : a(args), lane(lane_), run_max(0.0f) {}
 
-    // Issues the loads of `tile` (phase-1 lane layout).  Frames past the end of a
+    // Issues the loads of `tile` (pass-1 lane layout).  Frames past the end of a
     // stream re-read the stream's frame 0; their results are never stored.
     SONO_HD void load(unsigned long long tile, const TileIter &it)
     {
         const unsigned long long s = tile / it.tiles_per_stream;
         const unsigned int j = (unsigned int)(tile - s * it.tiles_per_stream);
         const int h = lane >> 5, n2 = lane & 31;
-        const float *xs = a.x + s * a.stream_stride + 2 * n2;
-        static_for<0, G::FPH>([&](auto fr_) {
-            constexpr int fr = decltype(fr_)::value;
-            unsigned long long f = (unsigned long long)j * G::FPW + (unsigned int)(h * G::FPH + fr);
-            if (f >= a.frames_per_stream) f = 0;
-            const float2 *src = (const float2 *)(xs + f * a.hop);
-            static_for<0, G::M1>([&](auto n_) {
+        const float *xs = a.x + s * a.stream_stride + n2;
+        static_for<0, G::JPL>([&](auto jj_) {
+            constexpr int jj = decltype(jj_)::value;
+            unsigned long long fa = (unsigned long long)j * G::FPW + (unsigned int)(2 * (h * G::JPL + jj));
+            unsigned long long fb = fa + 1;
+            if (fa >= a.frames_per_stream) fa = 0;
+            if (fb >= a.frames_per_stream) fb = 0;
+            const float *pa = xs + fa * a.hop, *pb = xs + fb * a.hop;
+            static_for<0, G::R1>([&](auto n_) {
                 constexpr int n1 = decltype(n_)::value;
-                const float2 v = src[32 * n1];
-                xr[fr * G::M1 + n1] = v.x;
-                xi[fr * G::M1 + n1] = v.y;
+                xa[jj * G::R1 + n1] = pa[32 * n1];
+                xb[jj * G::R1 + n1] = pb[32 * n1];
             });
         });
     }
 
-    SONO_HD void run_phase1(float2 *img) { phase1<LOG_M1>(lane, xr, xi, wr, wi, t1r, t1i, img); }
-
-    SONO_HD void run_phase2_load(const float2 *img, float (&re)[32], float (&im)[32]) const
+    // Largest |sample| of this lane's column of frames A and B of each of its pairs.
+    SONO_HD void scan(float (&ma)[G::JPL], float (&mb)[G::JPL]) const
     {
-        phase2_load<LOG_M1>(lane, img, re, im);
+        static_for<0, G::JPL>([&](auto jj_) {
+            constexpr int jj = decltype(jj_)::value;
+            float va = 0.0f, vb = 0.0f;
+            static_for<0, G::R1 / 2>([&](auto n_) {
+                constexpr int n1 = 2 * decltype(n_)::value;
+                va = fmaxf(fmaxf(fabsf(xa[jj * G::R1 + n1]), fabsf(xa[jj * G::R1 + n1 + 1])), va);
+                vb = fmaxf(fmaxf(fabsf(xb[jj * G::R1 + n1]), fabsf(xb[jj * G::R1 + n1 + 1])), vb);
+            });
+            ma[jj] = va;
+            mb[jj] = vb;
+        });
     }
-    SONO_HD void run_phase2_fft_store(float (&re)[32], float (&im)[32], float2 *img) const
+
+    // Pass 1: scale B, window, DFT-R1 of A + iB, conjugate-symmetric separation,
+    // unscale B, twiddle.  ma / mb = largest |sample| of frames A / B of each pair
+    // over all 32 columns.  Leaves the 32 row values of the lane (rows rho of its JPL
+    // pairs, column n2) in rr / ri at [jj*R1 + rho].  win = the N window values;
+    // tw = table [k1-1][n2] of W_N^(n2*k1), k1 = 1..R1/2.  The lane of column 0
+    // records the pair's side information in `meta`.
+    SONO_HD void pass1(const float *win, const float2 *tw, const float (&ma)[G::JPL], const float (&mb)[G::JPL],
+                       float (&rr)[32], float (&ri)[32], float *meta) const
+    {
+        const int h = lane >> 5, n2 = lane & 31;
+        static_for<0, G::JPL>([&](auto jj_) {
+            constexpr int jj = decltype(jj_)::value;
+            int d = (ma[jj] > 0.0f && mb[jj] > 0.0f) ? float_exponent(ma[jj]) - float_exponent(mb[jj]) : 0;
+            d = d > 60 ? 60 : d < -60 ? -60 : d;
+            const float sb = pow2(d), gb = pow2(-d);
+            if (n2 == 0) {
+                const int q = h * G::JPL + jj;
+                meta[q] = gb * gb;
+                meta[kMetaNonZero + 2 * q] = ma[jj] > 0.0f ? 1.0f : 0.0f;
+                meta[kMetaNonZero + 2 * q + 1] = mb[jj] > 0.0f ? 1.0f : 0.0f;
+            }
+            float re[G::R1], im[G::R1];
+            static_for<0, G::R1>([&](auto i_) {
+                constexpr int i = decltype(i_)::value, n1 = bitrev(i, LOG_R1);
+                const float w = win[32 * n1 + n2];
+                re[i] = xa[jj * G::R1 + n1] * w;
+                im[i] = (xb[jj * G::R1 + n1] * sb) * w;
+            });
+            dft_bitrev_in<G::R1>(re, im);
+            rr[jj * G::R1] = re[0];
+            ri[jj * G::R1] = im[0];
+            {
+                const float2 t = tw[(G::HALF - 1) * 32 + n2];
+                rr[jj * G::R1 + G::HALF] = re[G::HALF] * t.x - im[G::HALF] * t.y;
+                ri[jj * G::R1 + G::HALF] = re[G::HALF] * t.y + im[G::HALF] * t.x;
+            }
+            static_for<1, G::HALF>([&](auto k_) {
+                constexpr int k1 = decltype(k_)::value;
+                const float2 t = tw[(k1 - 1) * 32 + n2];
+                const float ar = re[k1] + re[G::R1 - k1], ai = im[k1] - im[G::R1 - k1];   // 2 Y_A[k1]
+                const float br = (im[k1] + im[G::R1 - k1]) * gb, bi = (re[G::R1 - k1] - re[k1]) * gb;   // 2 Y_B[k1]
+                rr[jj * G::R1 + k1] = ar * t.x - ai * t.y;
+                ri[jj * G::R1 + k1] = ar * t.y + ai * t.x;
+                rr[jj * G::R1 + G::HALF + k1] = br * t.x - bi * t.y;
+                ri[jj * G::R1 + G::HALF + k1] = br * t.y + bi * t.x;
+            });
+        });
+    }
+
+    // One exchange round: every pass-1 lane stores one component of its 32 row
+    // values at column n2 (value i = jj*R1 + rho belongs to row 32*h + i) ...
+    SONO_HD void exchange_store(const float (&v)[32], float *img) const
+    {
+        const int h = lane >> 5, n2 = lane & 31;
+        float *base = img + 1024 * h;
+        static_for<0, 32>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            base[32 * i + (n2 ^ (((i >> 1) & 7) << 2))] = v[i];       // = img[image_index(32*h + i, n2)]
+        });
+    }
+    // ... and every pass-2 lane reads its row, placing column n2 where the DFT wants it.
+    SONO_HD void exchange_load(const float *img, float (&v)[32]) const
+    {
+        const float *row = img + 32 * lane;
+        const int f = ((lane >> 1) & 7) << 2;
+        static_for<0, 8>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            const float4 q = *(const float4 *)(row + ((4 * j) ^ f));
+            v[bitrev(4 * j, 5)] = q.x; v[bitrev(4 * j + 1, 5)] = q.y;
+            v[bitrev(4 * j + 2, 5)] = q.z; v[bitrev(4 * j + 3, 5)] = q.w;
+        });
+    }
+
+    // Pass 2 (after both exchange rounds): DFT-32 over n2, then |2X|^2 of the
+    // lane's 32 bins scattered into the bin-major power image P[frame][bin].
+    //
+    // A frame row (rho = k1 or R1/2 + k1) holds 2X[k1 + R1*t] in register t and
+    // conj 2X[(R1-k1) + R1*t] in register 31-t.  A shared row holds C = 2X_A' + i 2X_B'
+    // of both frames of the pair, where X' is conjugate-symmetric about register 0
+    // (rho = 0: bins R1*t) or about register -1/2 (rho = R1/2: bins R1/2 + R1*t):
+    //   |2X_A|^2 = |C[t] + conj C[p]|^2,  |2X_B|^2 = |C[t] - conj C[p]|^2,  p = (32-t)%32 or 31-t.
+    // One instruction stream serves all three kinds: with b = conj C[p] and a
+    // per-lane s (0 for frame rows, 1 for shared rows) the two stores are
+    // |C[t] + s b|^2 and g2 |s C[t] - b|^2 (g2 undoes frame B's scaling in a shared
+    // row and is 1 in a frame row).
+    SONO_HD float pass2_scale(const float *meta) const
+    {
+        return (lane & (G::HALF - 1)) == 0 ? meta[lane >> LOG_R1] : 1.0f;
+    }
+    SONO_HD void pass2_power(float (&re)[32], float (&im)[32], float g2, float *P) const
     {
         dft_bitrev_in<32>(re, im);
-        phase2_store<LOG_M1>(lane, re, im, img);
+        const int q = lane >> LOG_R1, rho = lane & (G::R1 - 1), k1 = rho & (G::HALF - 1);
+        const bool shared = k1 == 0, row0 = rho == 0;
+        const float s = shared ? 1.0f : 0.0f;
+        const int frame = 2 * q + (rho >> (LOG_R1 - 1));
+        float *row1 = P + (shared ? 2 * q * G::PROW + rho : frame * G::PROW + k1);
+        float *row2 = P + (shared ? (2 * q + 1) * G::PROW + rho : frame * G::PROW + G::R1 - k1);
+        static_for<0, 16>([&](auto t_) {
+            constexpr int t = decltype(t_)::value;
+            const float br = row0 ? re[(32 - t) & 31] : re[31 - t];
+            const float bi = row0 ? im[(32 - t) & 31] : im[31 - t];
+            const float er = re[t] + s * br, ei = im[t] - s * bi;
+            const float dr = s * re[t] - br, di = s * im[t] + bi;
+            row1[G::R1 * t] = er * er + ei * ei;
+            row2[G::R1 * t] = (dr * dr + di * di) * g2;
+        });
     }
 
-    // Real split + outputs for the lane's 32 bins.  `peak_slot` is the LDS word of
-    // the lane's frame (ordering key of the frame's largest |2X|^2).
+    // Epilogue: lane (frame, l) owns bins 4l + 2*R1*m + r (m < 8, r < 4) of its frame.
+    // zero_row = N/2 floats of 0.0, read in place of the power image for an all-zero frame.
+    // `peak_slot` is the LDS word of the lane's frame (ordering key of its largest |2X|^2).
     template <typename AtomicMax64>
-    SONO_HD void run_phase3(unsigned long long tile, const TileIter &it, const float2 *img, const float2 *tw,
-                            unsigned long long *peak_slot, AtomicMax64 atomic_max64)
+    SONO_HD void epilogue(unsigned long long tile, const TileIter &it, const float *P, const float *meta,
+                          const float *zero_row, unsigned long long *peak_slot, AtomicMax64 atomic_max64)
     {
         const unsigned long long s = tile / it.tiles_per_stream;
         const unsigned int j = (unsigned int)(tile - s * it.tiles_per_stream);
-        const int frame = lane >> LOG_M1, l = lane & (G::M1 - 1);
+        const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
         const unsigned long long f = (unsigned long long)j * G::FPW + (unsigned int)frame;
         const bool valid = f < a.frames_per_stream;
         const unsigned long long g = s * a.frames_per_stream + f;
-        const float2 *Zf = img + frame * G::M;
+        const float *row = (meta[kMetaNonZero + frame] != 0.0f ? P + frame * G::PROW : zero_row) + 4 * l;
         float best_p = 0.0f;
         unsigned int best_k = 0;
-        SONO_NO_UNROLL
+        SONO_EPILOGUE_UNROLL
         for (int m = 0; m < 8; ++m) {
-            const int k0 = 4 * l + 4 * G::M1 * m;
-            float p[4];
-            phase3_group<LOG_M1>(Zf, tw, k0, p);
+            const int k0 = 4 * l + 2 * G::R1 * m;
+            const float4 p4 = *(const float4 *)(row + 2 * G::R1 * m);
+            const float p[4] = {p4.x, p4.y, p4.z, p4.w};
             if (MODE == MODE_MAG) {
                 if (valid) {
                     float4 o;
                     o.x = fast_sqrt(p[0]) * a.inv_n; o.y = fast_sqrt(p[1]) * a.inv_n;
                     o.z = fast_sqrt(p[2]) * a.inv_n; o.w = fast_sqrt(p[3]) * a.inv_n;
-                    *(float4 *)(a.out_mag + g * (unsigned long long)G::M + k0) = o;
+                    *(float4 *)(a.out_mag + g * (unsigned long long)G::BINS + k0) = o;
                 }
             } else {
                 unsigned int packed = 0;
@@ -316,7 +385,7 @@ struct TileLane {
                     packed |= quantise(p[r], a.q_a, a.q_c, a.q_floor) << (8 * r);
                     if (p[r] > best_p) { best_p = p[r]; best_k = (unsigned int)(k0 + r); }   // strict >: first wins
                 });
-                if (valid) *(unsigned int *)(a.out_u8 + g * (unsigned long long)G::M + k0) = packed;
+                if (valid) *(unsigned int *)(a.out_u8 + g * (unsigned long long)G::BINS + k0) = packed;
             }
         }
         if (MODE == MODE_U8 && valid) {
@@ -327,9 +396,9 @@ struct TileLane {
 
     // After every lane of the frame has contributed: the frame's first lane emits
     // the features and clears the slot for the next tile.
-    SONO_HD void run_phase4(unsigned long long tile, const TileIter &it, unsigned long long *peak_slot) const
+    SONO_HD void features(unsigned long long tile, const TileIter &it, unsigned long long *peak_slot) const
     {
-        const int frame = lane >> LOG_M1, l = lane & (G::M1 - 1);
+        const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
         if (MODE != MODE_U8 || l != 0) return;
         const unsigned long long s = tile / it.tiles_per_stream;
         const unsigned int j = (unsigned int)(tile - s * it.tiles_per_stream);

@@ -63,26 +63,37 @@ def test_global_max_is_max_of_frame_peaks(hour):
 
 
 def test_time_shift_identity(hour):
-    # the same launch started 7 hops later must reproduce rows 7.. bit for bit
+    # The kernel transforms frames in pairs (2q, 2q+1).  The same launch started an even number of
+    # hops later keeps every pair together and must reproduce the rows bit for bit; started an odd
+    # number of hops later it pairs every frame with its other neighbour, which may move a result by
+    # one rounding step but never by more than the u8 tolerance.
     torch = hour["torch"]
-    k, cnt = 7, 200000
+    cnt = 200000
     n = (cnt - 1) * H + N
     out = torch.empty(cnt * 512, dtype=torch.uint8, device="cuda")
-    xs = hour["x"][k * H: k * H + n]
-    torch.cuda.synchronize()
-    hour["e"].stft_u8_dev(xs.data_ptr(), 1, n, n, V, 20.0, 80.0, out.data_ptr())
-    hour["e"].synchronize()
-    assert torch.equal(out.view(cnt, 512), hour["out"][k:k + cnt])
+    for k in (8, 7):
+        xs = hour["x"][k * H: k * H + n]
+        torch.cuda.synchronize()
+        hour["e"].stft_u8_dev(xs.data_ptr(), 1, n, n, V, 20.0, 80.0, out.data_ptr())
+        hour["e"].synchronize()
+        got, ref = out.view(cnt, 512), hour["out"][k:k + cnt]
+        if k % 2 == 0:
+            assert torch.equal(got, ref)
+        else:
+            d = (got.to(torch.int16) - ref.to(torch.int16)).abs()
+            assert d.max().item() <= parity.U8_MAX_LSB
+            assert (d > 0).sum().item() <= parity.U8_MAX_FRACTION * d.numel()
 
 
 def test_launch_geometry_independent_checksum(hour):
     # a sum over all u8 codes, computed from chunked launches with halo, equals the one-launch sum
+    # (chunks start on even frame numbers, which keeps the kernel's frame pairs together)
     torch = hour["torch"]
     F = hour["F"]
     total = hour["out"].to(torch.int64).sum().item() if F < 1000 else sum(
         hour["out"][i:i + 500000].sum(dtype=torch.int64).item() for i in range(0, F, 500000))
     acc = 0
-    step = 1333333
+    step = 1333334
     buf = torch.empty(step * 512, dtype=torch.uint8, device="cuda")
     for f0 in range(0, F, step):
         f1 = min(f0 + step, F)

@@ -140,3 +140,38 @@ def test_tile_wave_batch_with_partial_tiles(emul):
                         _p(mag), None, None, None, None, None)
     assert rc == 0
     parity.check_mag(mag, np.concatenate(refs), 512, "tile batch")
+
+
+@pytest.mark.parametrize("N,V", [(1024, 768), (512, 256), (256, 192)])
+def test_tile_wave_quiet_frames_next_to_loud_ones(emul, N, V):
+    # frames are transformed in pairs: a loud frame must not leak rounding noise into its quiet partner
+    H = N - V
+    rng = np.random.default_rng(3)
+    n = N + 23 * H
+    x = (1e-5 * rng.standard_normal(n)).astype(np.float32)
+    t = np.arange(n)
+    burst = (t > 9 * H) & (t < 9 * H + N // 2)
+    x[burst] += (0.8 * np.sin(0.7 * t[burst])).astype(np.float32)
+    e = so.OracleEngine(N, "hann")
+    r = run_emul(emul, "emul_tile", 0, x, N, V, e.window)
+    parity.check_mag(r["mag"], e.compute_spectrogram(x, V), N // 2, f"quiet/loud mag N={N}")
+    r = run_emul(emul, "emul_tile", 1, x, N, V, e.window)
+    nd, nt = parity.u8_diff(r["u8"], e.compute_spectrogram_u8(x, V, 20.0, 80.0))
+    assert nd <= max(2, 1e-3 * nt)
+    assert np.array_equal(r["peak_bin"], e.get_peaks(0.0))
+
+
+def test_tile_wave_all_zero_frames_stay_exactly_zero(emul):
+    N, V = 1024, 768
+    H = N - V
+    x = np.zeros(N + 15 * H, np.float32)
+    x[N + 2 * H:] = signal(len(x) - (N + 2 * H), 9)          # frames 0..2 see only zeros
+    e = so.OracleEngine(N, "hann")
+    r = run_emul(emul, "emul_tile", 0, x, N, V, e.window)
+    ref = e.compute_spectrogram(x, V)
+    assert not r["mag"][: 3 * 512].any() and not ref[: 3 * 512].any()
+    parity.check_mag(r["mag"], ref, 512, "zero frames")
+    r = run_emul(emul, "emul_tile", 1, x, N, V, e.window)
+    assert np.array_equal(r["u8"][: 3 * 512], e.compute_spectrogram_u8(x, V, 20.0, 80.0)[: 3 * 512])
+    assert np.array_equal(r["peak_bin"], e.get_peaks(0.0))
+    assert not r["peak_mag"][:3].any()

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Builds an experimental variant of libsonostft.so with extra compiler flags:
+#   tools/expbuild.sh <name> [-DSONO_...]   ->  gpurun_exp/lib_<name>.so
+set -e
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+name=$1; shift
+mkdir -p "$ROOT/gpurun_exp/obj_$name"
+cd "$ROOT/spectrogram_amd/csrc"
+for f in sono_kernels.hip sono_tile.hip sono_capi.hip; do
+  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize "$@" -c $f -o "$ROOT/gpurun_exp/obj_$name/$f.o" &
+done
+g++ -O2 -std=c++17 -fPIC -ffp-contract=off -c sono_host.cpp -o "$ROOT/gpurun_exp/obj_$name/sono_host.o" &
+wait
+hipcc -shared -fPIC --offload-arch=gfx950 -o "$ROOT/gpurun_exp/lib_$name.so" "$ROOT/gpurun_exp/obj_$name"/*.o
+rm -rf "$ROOT/gpurun_exp/obj_$name"
+echo "built gpurun_exp/lib_$name.so"
