@@ -155,6 +155,75 @@ int sono_stft_mag_f32_dev(sono_engine *e, const sono_batch *in, uint32_t noverla
 /* Blocks until the engine's stream is idle. */
 int sono_engine_synchronize(sono_engine *e);
 
+/* ---- detector front end ----------------------------------------------------
+ * The array passes of modules/batCallDetector.js that sit directly on the STFT
+ * output.  The wasm module has no export for them (the reference runs them as
+ * JavaScript loops over what compute_spectrogram returned); here they run on
+ * the GPU so that only segment lists and per-frame features leave HBM.  Numbers
+ * that the JavaScript holds as doubles are doubles here. */
+
+typedef struct sono_segment {      /* {start, end} sample range (fastScanSegmentsWasm) or */
+    uint64_t start, end;           /* {startFrame, endFrame} inclusive frames (detectCallSegments) */
+} sono_segment;
+
+typedef struct sono_frame_features {
+    int32_t peak_bin;   /* first bin of the largest dB value in [peak_b0, peak_b1]; -1 if the range is empty */
+    float peak_db;      /* that value (-inf if none) */
+    int32_t low_bin;    /* lowest bin <= low_max_bin with dB > low_threshold_db; -1 if none */
+    int32_t high_bin;   /* highest bin >= high_min_bin with dB > high_threshold_db; -1 if none */
+} sono_frame_features;
+
+/* fastScanSegmentsWasm (batCallDetector.js:878-949): STFT with 50 % overlap, a
+ * frame is active when the band energy sum of mag^2 over [minBin, maxBin] exceeds
+ * 10^(threshold_db/10) * fft_size * 0.25; maximal active runs become sample
+ * ranges {f0*hop, f1*hop + fft_size} (f1 = first inactive frame after the run),
+ * a run that reaches the last frame ends at n. */
+int sono_fast_scan_segments(sono_engine *e, const float *x, size_t n, double sample_rate, double flow_khz,
+                            double fhigh_khz, double threshold_db, sono_segment *out, size_t cap, size_t *count);
+
+/* generateSpectrogramWasm (batCallDetector.js:1296-1377): STFT with
+ * hop = floor(fft_size * hop_percent / 100), power in dB cropped to the bins
+ * [*min_bin, *min_bin + *num_bins).  out: frames x num_bins f32, frame-major.
+ * *frames == 0 stands for the reference's `null` (hop < 1, n < fft_size, empty band). */
+int sono_generate_spectrogram(sono_engine *e, const float *x, size_t n, double sample_rate, double flow_khz,
+                              double fhigh_khz, double hop_percent, float *out, size_t cap, size_t *frames,
+                              uint32_t *min_bin, uint32_t *num_bins);
+
+/* detectCallSegments (batCallDetector.js:1540-1598) over a host dB matrix. */
+int sono_detect_call_segments(sono_engine *e, const float *power_db, size_t frames, uint32_t num_bins,
+                              double call_threshold_db, sono_segment *out, size_t cap, size_t *count);
+
+/* Per-frame peak bin / first bin above / last bin above (batCallDetector.js:3520-3527,
+ * 3612-3630, 2509-2522, 2002-2038) over a host dB matrix.  out: frames records. */
+int sono_frame_features_db(sono_engine *e, const float *power_db, size_t frames, uint32_t num_bins,
+                           uint32_t peak_b0, uint32_t peak_b1, uint32_t low_max_bin, double low_threshold_db,
+                           uint32_t high_min_bin, double high_threshold_db, sono_frame_features *out, size_t cap);
+
+/* Device-resident building blocks of the four calls above (device pointers,
+ * asynchronous on hip_stream or the engine's stream). */
+int sono_detect_band_active_dev(sono_engine *e, const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin,
+                                uint32_t max_bin, double target_energy_sum, uint8_t *d_active,
+                                double *d_band_energy /* may be NULL */, void *hip_stream);
+int sono_detect_power_db_dev(sono_engine *e, const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin,
+                             uint32_t num_bins, float *d_db, void *hip_stream);
+/* d_max: one f32, the largest finite value of d_db (-inf if there is none). */
+int sono_detect_db_max_dev(sono_engine *e, const float *d_db, size_t count, float *d_max, void *hip_stream);
+int sono_detect_db_active_dev(sono_engine *e, const float *d_db, size_t frames, uint32_t num_bins,
+                              double threshold_db, uint8_t *d_active, void *hip_stream);
+int sono_detect_frame_features_dev(sono_engine *e, const float *d_db, size_t frames, uint32_t num_bins,
+                                   uint32_t peak_b0, uint32_t peak_b1, uint32_t low_max_bin, double low_threshold_db,
+                                   uint32_t high_min_bin, double high_threshold_db, sono_frame_features *d_out,
+                                   void *hip_stream);
+/* Maximal runs of non-zero flags, in increasing order: run i covers frames
+ * d_first[i] .. d_last[i] (both arrays need `frames/2 + 1` entries), *d_count runs.
+ * Synchronises the stream (it sizes a temporary from the result). */
+int sono_detect_runs_dev(sono_engine *e, const uint8_t *d_active, size_t frames, uint64_t *d_first,
+                         uint64_t *d_last, uint64_t *d_count, void *hip_stream);
+
+/* mergeAndPadSegments (batCallDetector.js:1028-1056).  Host only; sorts `segs` in place. */
+int sono_merge_and_pad_segments(sono_segment *segs, size_t count, uint64_t total_samples, double sample_rate,
+                                double padding_ms, sono_segment *out, size_t cap, size_t *out_count);
+
 /* ---- free functions ----------------------------------------------------- */
 
 /* compute_power_spectrum (wasm.d.ts:6; lib.rs:1019-1118).  has_overlap == 0

@@ -45,6 +45,19 @@ class Batch(C.Structure):
                 ("stream_stride", C.c_size_t), ("samples_per_stream", C.c_size_t)]
 
 
+class Segment(C.Structure):
+    """struct sono_segment."""
+    _fields_ = [("start", C.c_uint64), ("end", C.c_uint64)]
+
+
+class FrameFeatures(C.Structure):
+    """struct sono_frame_features."""
+    _fields_ = [("peak_bin", C.c_int32), ("peak_db", C.c_float), ("low_bin", C.c_int32), ("high_bin", C.c_int32)]
+
+
+_segp = C.POINTER(Segment)
+_ffp = C.POINTER(FrameFeatures)
+
 _lib = None
 
 _SIGNATURES = {
@@ -76,6 +89,27 @@ _SIGNATURES = {
     "sono_stft_u8_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_float, C.c_float,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sono_stft_mag_f32_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_void_p, C.c_void_p]),
+    "sono_fast_scan_segments": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,
+                                          _segp, C.c_size_t, _szp]),
+    "sono_generate_spectrogram": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_double, C.c_double, C.c_double,
+                                            C.c_double, _f32p, C.c_size_t, _szp, _u32p, _u32p]),
+    "sono_detect_call_segments": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_uint32, C.c_double, _segp, C.c_size_t,
+                                            _szp]),
+    "sono_frame_features_db": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_double, C.c_uint32, C.c_double, _ffp, C.c_size_t]),
+    "sono_merge_and_pad_segments": (C.c_int, [_segp, C.c_size_t, C.c_uint64, C.c_double, C.c_double, _segp, C.c_size_t,
+                                              _szp]),
+    "sono_detect_band_active_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sono_detect_power_db_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                           C.c_void_p, C.c_void_p]),
+    "sono_detect_db_max_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "sono_detect_db_active_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_double, C.c_void_p,
+                                            C.c_void_p]),
+    "sono_detect_frame_features_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                 C.c_uint32, C.c_double, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p]),
+    "sono_detect_runs_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
     "sono_power_spectrum": (C.c_int, [_f32p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_char_p, C.c_int,
                                       C.c_float, C.c_int, _f32p, C.c_size_t, _szp]),
     "sono_find_peak_frequency": (C.c_float, [_f32p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_float, C.c_float]),
@@ -94,6 +128,24 @@ _SIGNATURES = {
 }
 
 
+def _share_torch_hip_runtime():
+    """PyTorch wheels carry their own libamdhip64.so.N with the same soname as the
+    system ROCm's.  Whichever copy a process loads first serves every later
+    user; if libsonostft pulled in the system copy first, a later `import torch`
+    would run on a HIP runtime it was not built with and see no GPU.  So when
+    PyTorch is installed, its copy is loaded before libsonostft."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """The loaded libsonostft.so.  Raises if the in-tree build is missing."""
     global _lib
@@ -102,6 +154,7 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -m spectrogram_amd.build` "
                 "(hipcc, gfx950).  There is no CPU fallback.")
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)

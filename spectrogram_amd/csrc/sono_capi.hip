@@ -14,12 +14,13 @@
 
 #include "../../include/sonostft.h"
 #include "sono_core.h"
+#include "sono_engine.h"
 #include "sono_host.h"
 #include "sono_kernels.h"
 #include "sono_tables.h"
 #include "sono_tile.h"
 
-namespace {
+namespace sono {
 
 thread_local std::string g_err;
 
@@ -36,42 +37,15 @@ int hip_fail(hipError_t e, const char *what)
                 std::string(what) + ": " + hipGetErrorString(e));
 }
 
-#define HIP_TRY(expr)                                              \
-    do {                                                           \
-        hipError_t _e = (expr);                                    \
-        if (_e != hipSuccess) return hip_fail(_e, #expr);          \
-    } while (0)
+}  // namespace sono
 
-// A device allocation that only ever grows.
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e == hipSuccess) cap = bytes; else p = nullptr;
-        return e;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
+using sono::DevBuf;
+using sono::DeviceGuard;
+using sono::Tables;
+using sono::fail;
+using sono::hip_fail;
 
-struct Tables {
-    unsigned int N = 0;
-    float *d_window = nullptr;
-    float2 *d_tw_half = nullptr;   // N/2 entries
-    float2 *d_tw_full = nullptr;   // N/2 + 1 entries
-    sono::TileTables tile;         // extra tables of the register-tiled kernel (may be empty)
-    void release()
-    {
-        if (d_window) (void)hipFree(d_window);
-        if (d_tw_half) (void)hipFree(d_tw_half);
-        if (d_tw_full) (void)hipFree(d_tw_full);
-        sono::tile_tables_release(tile);
-        d_window = nullptr; d_tw_half = nullptr; d_tw_full = nullptr;
-    }
-};
+namespace {
 
 int build_tables(unsigned int N, const float *window, Tables &t)
 {
@@ -105,50 +79,7 @@ hipError_t dispatch_stft(int mode, const sono::StftArgs &a, const Tables &t, hip
     return sono::launch_stft_generic(mode, a, stream);
 }
 
-class DeviceGuard {
-public:
-    explicit DeviceGuard(int dev) : ok_(false), prev_(-1)
-    {
-        if (hipGetDevice(&prev_) != hipSuccess) { (void)hipGetLastError(); return; }
-        if (dev >= 0 && dev != prev_) {
-            if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return; }
-            changed_ = true;
-        }
-        ok_ = true;
-    }
-    ~DeviceGuard() { if (changed_) (void)hipSetDevice(prev_); }
-    bool ok() const { return ok_; }
-private:
-    bool ok_, changed_ = false;
-    int prev_;
-};
-
 }  // namespace
-
-struct sono_engine {
-    unsigned int N = 0;
-    int device = 0;
-    float alpha = 0.16f;
-    std::string window_name;
-    std::vector<float> window;
-    Tables tables;
-    hipStream_t stream = nullptr;
-    // device scratch of the host-pointer entry points
-    DevBuf d_in, d_out, d_peak_bin, d_peak_mag, d_gmax, d_mags, d_bank;
-    // filter bank (lib.rs:20-22)
-    std::vector<float> bank;
-    unsigned int num_filters = 0;
-    bool use_bank = false;
-    // state left behind by the last u8 call (lib.rs:24-26)
-    bool has_last = false;
-    std::vector<uint16_t> last_peak_bin;
-    std::vector<float> last_peak_mag;
-    float last_gmax = 0.0f;
-    // colour map / config (lib.rs:28-32)
-    std::vector<uint32_t> color_map;
-    std::string scale = "linear";
-    float freq_min = 0.0f, freq_max = 0.0f;
-};
 
 struct sono_waveform {
     std::vector<std::vector<float>> channels;
@@ -156,7 +87,7 @@ struct sono_waveform {
 
 extern "C" {
 
-const char *sono_last_error(void) { return g_err.c_str(); }
+const char *sono_last_error(void) { return sono::g_err.c_str(); }
 
 uint32_t sono_abi_version(void) { return 1; }
 
@@ -210,6 +141,8 @@ void sono_engine_destroy(sono_engine *e)
     e->tables.release();
     e->d_in.release(); e->d_out.release(); e->d_peak_bin.release(); e->d_peak_mag.release();
     e->d_gmax.release(); e->d_mags.release(); e->d_bank.release();
+    e->d_db.release(); e->d_flags.release(); e->d_edges.release(); e->d_runs.release();
+    e->d_count.release(); e->d_select_tmp.release();
     delete e;
 }
 
@@ -252,6 +185,7 @@ int sono_engine_release_memory(sono_engine *e)
     e->has_last = false; e->last_peak_bin.clear(); e->last_peak_mag.clear(); e->last_gmax = 0.0f;
     e->d_in.release(); e->d_out.release(); e->d_peak_bin.release(); e->d_peak_mag.release();
     e->d_mags.release(); e->d_bank.release();
+    e->d_db.release(); e->d_flags.release(); e->d_edges.release(); e->d_runs.release(); e->d_select_tmp.release();
     return SONO_OK;
 }
 

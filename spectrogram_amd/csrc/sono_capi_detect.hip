@@ -1,0 +1,293 @@
+// sono_capi_detect.hip -- C ABI of the detector front end (include/sonostft.h):
+// the array passes of modules/batCallDetector.js that follow the STFT.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/sonostft.h"
+#include "sono_detect.h"
+#include "sono_engine.h"
+
+using sono::DeviceGuard;
+using sono::fail;
+using sono::hip_fail;
+
+namespace {
+
+hipStream_t pick(sono_engine *e, void *hip_stream) { return hip_stream ? (hipStream_t)hip_stream : e->stream; }
+
+// Runs of non-zero flags -> host vectors of first / last frame.
+int runs_to_host(sono_engine *e, const uint8_t *d_active, size_t frames, std::vector<uint64_t> &first,
+                 std::vector<uint64_t> &last)
+{
+    first.clear(); last.clear();
+    if (frames == 0) return SONO_OK;
+    const size_t cap = frames / 2 + 1;
+    HIP_TRY(e->d_runs.reserve(2 * cap * sizeof(uint64_t)));
+    HIP_TRY(e->d_count.reserve(2 * sizeof(uint64_t)));
+    uint64_t *d_first = (uint64_t *)e->d_runs.p, *d_last = d_first + cap;
+    int rc = sono_detect_runs_dev(e, d_active, frames, d_first, d_last, (uint64_t *)e->d_count.p, nullptr);
+    if (rc) return rc;
+    uint64_t n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, e->d_count.p, sizeof(n), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    first.resize(n); last.resize(n);
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(first.data(), d_first, n * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(last.data(), d_last, n * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return SONO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sono_detect_band_active_dev(sono_engine *e, const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin,
+                                uint32_t max_bin, double target, uint8_t *d_active, double *d_band_energy,
+                                void *hip_stream)
+{
+    if (!e || (frames && (!d_mags || !d_active))) return fail(SONO_EINVAL, "sono_detect_band_active_dev: NULL argument");
+    if (bins == 0) return fail(SONO_EINVAL, "sono_detect_band_active_dev: bins is 0");
+    DeviceGuard guard(e->device);
+    HIP_TRY(sono::launch_band_active(d_mags, frames, bins, min_bin, max_bin, target, d_active, d_band_energy,
+                                     pick(e, hip_stream)));
+    return SONO_OK;
+}
+
+int sono_detect_power_db_dev(sono_engine *e, const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin,
+                             uint32_t num_bins, float *d_db, void *hip_stream)
+{
+    if (!e || (frames && num_bins && (!d_mags || !d_db))) return fail(SONO_EINVAL, "sono_detect_power_db_dev: NULL argument");
+    if ((uint64_t)min_bin + num_bins > bins) return fail(SONO_EINVAL, "sono_detect_power_db_dev: band exceeds the bins");
+    DeviceGuard guard(e->device);
+    HIP_TRY(sono::launch_power_db(d_mags, frames, bins, min_bin, num_bins, e->N, d_db, pick(e, hip_stream)));
+    return SONO_OK;
+}
+
+int sono_detect_db_max_dev(sono_engine *e, const float *d_db, size_t count, float *d_max, void *hip_stream)
+{
+    if (!e || !d_max || (count && !d_db)) return fail(SONO_EINVAL, "sono_detect_db_max_dev: NULL argument");
+    DeviceGuard guard(e->device);
+    hipStream_t s = pick(e, hip_stream);
+    // the running maximum is kept as an order-preserving integer key in the caller's word and decoded in place
+    const uint32_t floor_key = sono::detect_key(-INFINITY);
+    HIP_TRY(hipMemcpyAsync(d_max, &floor_key, sizeof(floor_key), hipMemcpyHostToDevice, s));
+    HIP_TRY(sono::launch_db_max(d_db, count, (uint32_t *)d_max, s));
+    uint32_t key = 0;
+    HIP_TRY(hipMemcpyAsync(&key, d_max, sizeof(key), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const float v = sono::detect_unkey(key);
+    HIP_TRY(hipMemcpyAsync(d_max, &v, sizeof(v), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SONO_OK;
+}
+
+int sono_detect_db_active_dev(sono_engine *e, const float *d_db, size_t frames, uint32_t num_bins, double threshold_db,
+                              uint8_t *d_active, void *hip_stream)
+{
+    if (!e || (frames && (!d_db || !d_active))) return fail(SONO_EINVAL, "sono_detect_db_active_dev: NULL argument");
+    DeviceGuard guard(e->device);
+    HIP_TRY(sono::launch_db_active(d_db, frames, num_bins, threshold_db, d_active, pick(e, hip_stream)));
+    return SONO_OK;
+}
+
+int sono_detect_frame_features_dev(sono_engine *e, const float *d_db, size_t frames, uint32_t num_bins,
+                                   uint32_t peak_b0, uint32_t peak_b1, uint32_t low_max_bin, double low_thr,
+                                   uint32_t high_min_bin, double high_thr, sono_frame_features *d_out,
+                                   void *hip_stream)
+{
+    if (!e || (frames && (!d_db || !d_out))) return fail(SONO_EINVAL, "sono_detect_frame_features_dev: NULL argument");
+    DeviceGuard guard(e->device);
+    HIP_TRY(sono::launch_frame_features(d_db, frames, num_bins, peak_b0, peak_b1, low_max_bin, low_thr, high_min_bin,
+                                        high_thr, d_out, pick(e, hip_stream)));
+    return SONO_OK;
+}
+
+int sono_detect_runs_dev(sono_engine *e, const uint8_t *d_active, size_t frames, uint64_t *d_first, uint64_t *d_last,
+                         uint64_t *d_count, void *hip_stream)
+{
+    if (!e || !d_count || (frames && (!d_active || !d_first || !d_last)))
+        return fail(SONO_EINVAL, "sono_detect_runs_dev: NULL argument");
+    if (frames > 0x7FFFFFFFull) return fail(SONO_EINVAL, "sono_detect_runs_dev: more than 2^31-1 frames");
+    DeviceGuard guard(e->device);
+    hipStream_t s = pick(e, hip_stream);
+    if (frames == 0) {
+        HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint64_t), s));
+        return SONO_OK;
+    }
+    HIP_TRY(e->d_edges.reserve(2 * frames));
+    uint8_t *d_is_start = (uint8_t *)e->d_edges.p, *d_is_end = d_is_start + frames;
+    HIP_TRY(sono::launch_run_edges(d_active, frames, d_is_start, d_is_end, s));
+    size_t temp = 0;
+    HIP_TRY(sono::select_flagged(nullptr, temp, d_is_start, d_first, d_count, frames, s));
+    HIP_TRY(e->d_select_tmp.reserve(temp ? temp : 1));
+    HIP_TRY(sono::select_flagged(e->d_select_tmp.p, temp, d_is_start, d_first, d_count, frames, s));
+    HIP_TRY(sono::select_flagged(e->d_select_tmp.p, temp, d_is_end, d_last, d_count, frames, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SONO_OK;
+}
+
+int sono_fast_scan_segments(sono_engine *e, const float *x, size_t n, double sample_rate, double flow_khz,
+                            double fhigh_khz, double threshold_db, sono_segment *out, size_t cap, size_t *count)
+{
+    if (count) *count = 0;
+    if (!e || (!x && n)) return fail(SONO_EINVAL, "sono_fast_scan_segments: NULL argument");
+    const uint32_t N = e->N, hop = N / 2, noverlap = N - hop, bins = N / 2;      // js:882-886
+    const double freq_res = sample_rate / (double)N;                             // js:889
+    const double lo = std::floor(flow_khz * 1000.0 / freq_res), hi = std::ceil(fhigh_khz * 1000.0 / freq_res);
+    const size_t F = sono_frames_for(n, N, noverlap);
+    if (F == 0) return SONO_OK;
+    if (!(hi >= lo) || hi < 0.0) return SONO_OK;                                 // empty band: no frame can be active
+    const uint32_t min_bin = lo > 0.0 ? (lo > 4.0e9 ? 0xFFFFFFFFu : (uint32_t)lo) : 0u;
+    const uint32_t max_bin = hi > 4.0e9 ? 0xFFFFFFFFu : (uint32_t)hi;
+    const double target = std::pow(10.0, threshold_db / 10.0) * (double)N * 0.25;   // js:906-909
+    DeviceGuard guard(e->device);
+    const size_t used = (F - 1) * (size_t)hop + N;
+    HIP_TRY(e->d_in.reserve(used * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(e->d_in.p, x, used * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e->d_mags.reserve(F * bins * sizeof(float)));
+    HIP_TRY(e->d_flags.reserve(F));
+    sono_batch b{(const float *)e->d_in.p, 1, used, used};
+    int rc = sono_stft_mag_f32_dev(e, &b, noverlap, (float *)e->d_mags.p, nullptr);
+    if (rc) return rc;
+    // a band whose first flat index lies past the frame row still indexes the flat array (js:918-921)
+    rc = sono_detect_band_active_dev(e, (const float *)e->d_mags.p, F, bins, min_bin, max_bin, target,
+                                     (uint8_t *)e->d_flags.p, nullptr, nullptr);
+    if (rc) return rc;
+    std::vector<uint64_t> first, last;
+    rc = runs_to_host(e, (const uint8_t *)e->d_flags.p, F, first, last);
+    if (rc) return rc;
+    if (first.size() > cap || (first.size() && !out)) return fail(SONO_ECAPACITY, "sono_fast_scan_segments: output buffer too small");
+    for (size_t i = 0; i < first.size(); ++i) {
+        out[i].start = first[i] * hop;                                           // js:930-933
+        out[i].end = last[i] + 1 < F ? (last[i] + 1) * hop + N : (uint64_t)n;    // js:937,945
+    }
+    if (count) *count = first.size();
+    return SONO_OK;
+}
+
+int sono_generate_spectrogram(sono_engine *e, const float *x, size_t n, double sample_rate, double flow_khz,
+                              double fhigh_khz, double hop_percent, float *out, size_t cap, size_t *frames,
+                              uint32_t *min_bin_out, uint32_t *num_bins_out)
+{
+    if (frames) *frames = 0;
+    if (min_bin_out) *min_bin_out = 0;
+    if (num_bins_out) *num_bins_out = 0;
+    if (!e || (!x && n)) return fail(SONO_EINVAL, "sono_generate_spectrogram: NULL argument");
+    const uint32_t N = e->N, bins = N / 2;
+    const double hop_d = std::floor((double)N * (hop_percent / 100.0));           // js:1306
+    if (!(hop_d >= 1.0) || (size_t)N > n) return SONO_OK;                         // js:1309-1312 -> null
+    const uint32_t hop = hop_d >= (double)N ? N : (uint32_t)hop_d;
+    if (hop >= N + 1u || N - hop >= N) return SONO_OK;
+    const uint32_t noverlap = N - hop;                                            // hop == N gives noverlap 0
+    const double freq_res = sample_rate / (double)N;
+    const size_t F = sono_frames_for(n, N, noverlap);
+    if (F < 1) return SONO_OK;
+    const double lo = std::max(0.0, std::floor(flow_khz * 1000.0 / freq_res));   // js:1328-1330
+    const double hi = std::min((double)(bins - 1), std::floor(fhigh_khz * 1000.0 / freq_res));
+    if (!(hi - lo + 1.0 > 0.0)) return SONO_OK;                                   // js:1332-1335 -> null
+    const uint32_t min_bin = (uint32_t)lo, nb = (uint32_t)(hi - lo + 1.0);
+    if (!out || cap < F * nb) return fail(SONO_ECAPACITY, "sono_generate_spectrogram: output buffer too small");
+    DeviceGuard guard(e->device);
+    const size_t used = (F - 1) * (size_t)hop + N;
+    HIP_TRY(e->d_in.reserve(used * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(e->d_in.p, x, used * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e->d_mags.reserve(F * bins * sizeof(float)));
+    HIP_TRY(e->d_db.reserve(F * nb * sizeof(float)));
+    sono_batch b{(const float *)e->d_in.p, 1, used, used};
+    int rc = sono_stft_mag_f32_dev(e, &b, noverlap, (float *)e->d_mags.p, nullptr);
+    if (rc) return rc;
+    rc = sono_detect_power_db_dev(e, (const float *)e->d_mags.p, F, bins, min_bin, nb, (float *)e->d_db.p, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, e->d_db.p, F * nb * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (frames) *frames = F;
+    if (min_bin_out) *min_bin_out = min_bin;
+    if (num_bins_out) *num_bins_out = nb;
+    return SONO_OK;
+}
+
+int sono_detect_call_segments(sono_engine *e, const float *power_db, size_t frames, uint32_t num_bins,
+                              double call_threshold_db, sono_segment *out, size_t cap, size_t *count)
+{
+    if (count) *count = 0;
+    if (!e || (frames && num_bins && !power_db)) return fail(SONO_EINVAL, "sono_detect_call_segments: NULL argument");
+    if (frames == 0) return SONO_OK;
+    DeviceGuard guard(e->device);
+    const size_t total = frames * (size_t)num_bins;
+    HIP_TRY(e->d_db.reserve((total ? total : 1) * sizeof(float)));
+    HIP_TRY(e->d_flags.reserve(frames));
+    HIP_TRY(e->d_gmax.reserve(sizeof(uint32_t)));
+    if (total) HIP_TRY(hipMemcpyAsync(e->d_db.p, power_db, total * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    int rc = sono_detect_db_max_dev(e, (const float *)e->d_db.p, total, (float *)e->d_gmax.p, nullptr);
+    if (rc) return rc;
+    float gmax = 0.0f;
+    HIP_TRY(hipMemcpy(&gmax, e->d_gmax.p, sizeof(gmax), hipMemcpyDeviceToHost));
+    const double threshold = (double)gmax + call_threshold_db;                   // js:1553
+    rc = sono_detect_db_active_dev(e, (const float *)e->d_db.p, frames, num_bins, threshold, (uint8_t *)e->d_flags.p,
+                                   nullptr);
+    if (rc) return rc;
+    std::vector<uint64_t> first, last;
+    rc = runs_to_host(e, (const uint8_t *)e->d_flags.p, frames, first, last);
+    if (rc) return rc;
+    if (first.size() > cap || (first.size() && !out)) return fail(SONO_ECAPACITY, "sono_detect_call_segments: output buffer too small");
+    for (size_t i = 0; i < first.size(); ++i) { out[i].start = first[i]; out[i].end = last[i]; }   // js:1580-1594
+    if (count) *count = first.size();
+    return SONO_OK;
+}
+
+int sono_frame_features_db(sono_engine *e, const float *power_db, size_t frames, uint32_t num_bins, uint32_t peak_b0,
+                           uint32_t peak_b1, uint32_t low_max_bin, double low_thr, uint32_t high_min_bin,
+                           double high_thr, sono_frame_features *out, size_t cap)
+{
+    if (!e || (frames && (!power_db || !out))) return fail(SONO_EINVAL, "sono_frame_features_db: NULL argument");
+    if (cap < frames) return fail(SONO_ECAPACITY, "sono_frame_features_db: output buffer too small");
+    if (frames == 0) return SONO_OK;
+    DeviceGuard guard(e->device);
+    const size_t total = frames * (size_t)num_bins;
+    HIP_TRY(e->d_db.reserve((total ? total : 1) * sizeof(float)));
+    HIP_TRY(e->d_out.reserve(frames * sizeof(sono_frame_features)));
+    if (total) HIP_TRY(hipMemcpyAsync(e->d_db.p, power_db, total * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    int rc = sono_detect_frame_features_dev(e, (const float *)e->d_db.p, frames, num_bins, peak_b0, peak_b1, low_max_bin,
+                                            low_thr, high_min_bin, high_thr, (sono_frame_features *)e->d_out.p, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, e->d_out.p, frames * sizeof(sono_frame_features), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return SONO_OK;
+}
+
+int sono_merge_and_pad_segments(sono_segment *segs, size_t count, uint64_t total_samples, double sample_rate,
+                                double padding_ms, sono_segment *out, size_t cap, size_t *out_count)
+{
+    if (out_count) *out_count = 0;
+    if (count == 0) return SONO_OK;                                              // js:1029
+    if (!segs || !out) return fail(SONO_EINVAL, "sono_merge_and_pad_segments: NULL argument");
+    const double pad_d = std::round((padding_ms / 1000.0) * sample_rate);        // Math.round, js:1031
+    const int64_t pad = (int64_t)pad_d;
+    std::stable_sort(segs, segs + count, [](const sono_segment &a, const sono_segment &b) { return a.start < b.start; });
+    auto lo = [&](const sono_segment &s) { const int64_t v = (int64_t)s.start - pad; return v > 0 ? v : (int64_t)0; };
+    auto hi = [&](const sono_segment &s) { const int64_t v = (int64_t)s.end + pad; return v < (int64_t)total_samples ? v : (int64_t)total_samples; };
+    size_t k = 0;
+    int64_t cur_start = lo(segs[0]), cur_end = hi(segs[0]);
+    for (size_t i = 1; i < count; ++i) {
+        const int64_t ns = lo(segs[i]), ne = hi(segs[i]);
+        if (ns <= cur_end) {
+            cur_end = ne > cur_end ? ne : cur_end;
+        } else {
+            if (k >= cap) return fail(SONO_ECAPACITY, "sono_merge_and_pad_segments: output buffer too small");
+            out[k].start = (uint64_t)cur_start; out[k].end = (uint64_t)cur_end; ++k;
+            cur_start = ns; cur_end = ne;
+        }
+    }
+    if (k >= cap) return fail(SONO_ECAPACITY, "sono_merge_and_pad_segments: output buffer too small");
+    out[k].start = (uint64_t)cur_start; out[k].end = (uint64_t)cur_end; ++k;
+    if (out_count) *out_count = k;
+    return SONO_OK;
+}
+
+}  // extern "C"

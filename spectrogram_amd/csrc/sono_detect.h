@@ -1,0 +1,64 @@
+// sono_detect.h -- kernels of the detector front end: the array passes of
+// modules/batCallDetector.js that sit directly on the STFT output.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <cstring>
+
+#include "../../include/sonostft.h"
+
+namespace sono {
+
+// batCallDetector.js:913-927.  The reference indexes the flat magnitude array, so a
+// band that runs past a frame's last bin continues into the next frame's first
+// bins (and stops at the end of the array); kept as is.
+hipError_t launch_band_active(const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin, uint32_t max_bin,
+                              double target_energy_sum, uint8_t *d_active, double *d_band_energy, hipStream_t s);
+
+// batCallDetector.js:1347-1363: dB = 10 log10(max(mag^2 / fft_size, 1e-16)) in f64, stored as f32.
+hipError_t launch_power_db(const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin, uint32_t nb,
+                           uint32_t fft_size, float *d_db, hipStream_t s);
+
+// batCallDetector.js:1544-1550.  *d_max_key must hold sono_detect_key(-inf) before the launch.
+hipError_t launch_db_max(const float *d_db, size_t count, uint32_t *d_max_key, hipStream_t s);
+
+// batCallDetector.js:1556-1567.
+hipError_t launch_db_active(const float *d_db, size_t frames, uint32_t nb, double threshold_db, uint8_t *d_active,
+                            hipStream_t s);
+
+// batCallDetector.js:3520-3527,3612-3630 (peak), 2509-2522 (lowest bin above), 2002-2038 (highest bin above).
+hipError_t launch_frame_features(const float *d_db, size_t frames, uint32_t nb, uint32_t peak_b0, uint32_t peak_b1,
+                                 uint32_t low_max_bin, double low_threshold_db, uint32_t high_min_bin,
+                                 double high_threshold_db, sono_frame_features *d_out, hipStream_t s);
+
+// First / last frame of every maximal run of non-zero flags, as two flag arrays.
+hipError_t launch_run_edges(const uint8_t *d_active, size_t frames, uint8_t *d_is_start, uint8_t *d_is_end,
+                            hipStream_t s);
+
+// Ordered compaction: indices f (ascending) with d_flags[f] != 0 -> d_out, their number -> *d_count.
+// Call with d_temp == nullptr to get the temporary size.
+hipError_t select_flagged(void *d_temp, size_t &temp_bytes, const uint8_t *d_flags, uint64_t *d_out,
+                          uint64_t *d_count, size_t frames, hipStream_t s);
+
+// Order-preserving map f32 -> u32 (so that atomicMax on the key is a float max) and back.
+__host__ __device__ inline uint32_t detect_key(float v)
+{
+    uint32_t b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    b = __float_as_uint(v);
+#else
+    std::memcpy(&b, &v, 4);
+#endif
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+inline float detect_unkey(uint32_t k)
+{
+    const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    float v;
+    std::memcpy(&v, &b, 4);
+    return v;
+}
+
+}  // namespace sono

@@ -1,0 +1,206 @@
+// sono_detect.hip -- detector front-end kernels (see sono_detect.h).  All of them
+// are single passes over frames x bins arrays in HBM: one wave64 per frame row,
+// lanes striding over the bins, so every load is a coalesced 256-byte row piece.
+#include "sono_detect.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <cstring>
+
+namespace sono {
+
+namespace {
+
+constexpr int kThreads = 256;                       // 4 rows per workgroup
+constexpr int kRowsPerBlock = kThreads / 64;
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kThreads) void band_active_kernel(const float *mags, size_t frames, uint32_t bins,
+                                                               uint32_t min_bin, uint32_t max_bin, double target,
+                                                               uint8_t *active, double *band_energy)
+{
+    const size_t f = (size_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (f >= frames) return;
+    const size_t total = frames * (size_t)bins;
+    const size_t lo = f * bins + min_bin;
+    size_t hi = f * bins + max_bin;                 // inclusive; the flat index may run into the next frame
+    if (hi >= total) hi = total - 1;
+    double acc = 0.0;
+    for (size_t i = lo + lane; i <= hi && lo <= hi; i += 64) {
+        const double m = (double)mags[i];
+        acc += m * m;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        active[f] = acc > target ? 1 : 0;
+        if (band_energy) band_energy[f] = acc;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void power_db_kernel(const float *mags, size_t frames, uint32_t bins,
+                                                            uint32_t min_bin, uint32_t nb, double fft_size, float *db)
+{
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= frames * (size_t)nb) return;
+    const size_t f = i / nb;
+    const uint32_t b = (uint32_t)(i - f * nb);
+    const double m = (double)mags[f * bins + min_bin + b];
+    const double psd = (m * m) / fft_size;
+    db[i] = (float)(10.0 * log10(psd > 1e-16 ? psd : 1e-16));
+}
+
+__global__ __launch_bounds__(kThreads) void db_max_kernel(const float *db, size_t count, uint32_t *max_key)
+{
+    __shared__ uint32_t s_key[kThreads / 64];
+    uint32_t best = 0;                              // below every key
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (size_t)gridDim.x * kThreads) {
+        const float v = db[i];
+        if (v == v) { const uint32_t k = detect_key(v); best = k > best ? k : best; }    // Math.max over finite dB values
+    }
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(best, o, 64); best = other > best ? other : best; }
+    if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kThreads / 64; ++w) best = s_key[w] > best ? s_key[w] : best;
+        if (best) atomicMax(max_key, best);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void db_active_kernel(const float *db, size_t frames, uint32_t nb,
+                                                             double threshold, uint8_t *active)
+{
+    const size_t f = (size_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (f >= frames) return;
+    const float *row = db + f * nb;
+    bool any = false;
+    for (uint32_t b = lane; b < nb; b += 64) any = any || ((double)row[b] > threshold);
+    const unsigned long long m = __ballot(any);
+    if (lane == 0) active[f] = m ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kThreads) void frame_features_kernel(const float *db, size_t frames, uint32_t nb,
+                                                                  uint32_t peak_b0, uint32_t peak_b1,
+                                                                  uint32_t low_max_bin, double low_thr,
+                                                                  uint32_t high_min_bin, double high_thr,
+                                                                  sono_frame_features *out)
+{
+    const size_t f = (size_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (f >= frames) return;
+    const float *row = db + f * nb;
+    // peak: first bin holding the largest value (strict > from -infinity, NaN never wins)
+    float best = -INFINITY;
+    int best_bin = -1;
+    int low = 0x7FFFFFFF, high = -1;
+    for (uint32_t b = lane; b < nb; b += 64) {
+        const float v = row[b];
+        if (b >= peak_b0 && b <= peak_b1 && v > best) { best = v; best_bin = (int)b; }
+        if (b <= low_max_bin && (double)v > low_thr && (int)b < low) low = (int)b;
+        if (b >= high_min_bin && (double)v > high_thr) high = (int)b;       // b ascends: keeps the last
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int ob = __shfl_xor(best_bin, o, 64);
+        const bool take = ob >= 0 && (best_bin < 0 || ov > best || (ov == best && ob < best_bin));
+        if (take) { best = ov; best_bin = ob; }
+        const int ol = __shfl_xor(low, o, 64), oh = __shfl_xor(high, o, 64);
+        low = ol < low ? ol : low;
+        high = oh > high ? oh : high;
+    }
+    if (lane == 0) {
+        sono_frame_features r;
+        r.peak_bin = best_bin;
+        r.peak_db = best;
+        r.low_bin = low == 0x7FFFFFFF ? -1 : low;
+        r.high_bin = high;
+        out[f] = r;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void run_edges_kernel(const uint8_t *active, size_t frames, uint8_t *is_start,
+                                                             uint8_t *is_end)
+{
+    const size_t f = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (f >= frames) return;
+    const bool a = active[f] != 0;
+    const bool prev = f > 0 && active[f - 1] != 0;
+    const bool next = f + 1 < frames && active[f + 1] != 0;
+    is_start[f] = a && !prev;
+    is_end[f] = a && !next;
+}
+
+unsigned int rows_grid(size_t frames) { return (unsigned int)((frames + kRowsPerBlock - 1) / kRowsPerBlock); }
+
+}  // namespace
+
+hipError_t launch_band_active(const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin, uint32_t max_bin,
+                              double target, uint8_t *d_active, double *d_band_energy, hipStream_t s)
+{
+    if (frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(band_active_kernel, dim3(rows_grid(frames)), dim3(kThreads), 0, s, d_mags, frames, bins, min_bin,
+                       max_bin, target, d_active, d_band_energy);
+    return hipGetLastError();
+}
+
+hipError_t launch_power_db(const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin, uint32_t nb,
+                           uint32_t fft_size, float *d_db, hipStream_t s)
+{
+    const size_t count = frames * (size_t)nb;
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(power_db_kernel, dim3((unsigned int)((count + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                       d_mags, frames, bins, min_bin, nb, (double)fft_size, d_db);
+    return hipGetLastError();
+}
+
+hipError_t launch_db_max(const float *d_db, size_t count, uint32_t *d_max_key, hipStream_t s)
+{
+    if (count == 0) return hipSuccess;
+    size_t blocks = (count + kThreads - 1) / kThreads;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(db_max_kernel, dim3((unsigned int)blocks), dim3(kThreads), 0, s, d_db, count, d_max_key);
+    return hipGetLastError();
+}
+
+hipError_t launch_db_active(const float *d_db, size_t frames, uint32_t nb, double threshold_db, uint8_t *d_active,
+                            hipStream_t s)
+{
+    if (frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(db_active_kernel, dim3(rows_grid(frames)), dim3(kThreads), 0, s, d_db, frames, nb, threshold_db,
+                       d_active);
+    return hipGetLastError();
+}
+
+hipError_t launch_frame_features(const float *d_db, size_t frames, uint32_t nb, uint32_t peak_b0, uint32_t peak_b1,
+                                 uint32_t low_max_bin, double low_thr, uint32_t high_min_bin, double high_thr,
+                                 sono_frame_features *d_out, hipStream_t s)
+{
+    if (frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(frame_features_kernel, dim3(rows_grid(frames)), dim3(kThreads), 0, s, d_db, frames, nb, peak_b0,
+                       peak_b1, low_max_bin, low_thr, high_min_bin, high_thr, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_run_edges(const uint8_t *d_active, size_t frames, uint8_t *d_is_start, uint8_t *d_is_end,
+                            hipStream_t s)
+{
+    if (frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(run_edges_kernel, dim3((unsigned int)((frames + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                       d_active, frames, d_is_start, d_is_end);
+    return hipGetLastError();
+}
+
+hipError_t select_flagged(void *d_temp, size_t &temp_bytes, const uint8_t *d_flags, uint64_t *d_out, uint64_t *d_count,
+                          size_t frames, hipStream_t s)
+{
+    hipcub::CountingInputIterator<uint64_t> idx(0);
+    return hipcub::DeviceSelect::Flagged(d_temp, temp_bytes, idx, d_flags, d_out, d_count, (int)frames, s);
+}
+
+}  // namespace sono

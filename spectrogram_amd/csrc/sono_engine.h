@@ -1,0 +1,104 @@
+// sono_engine.h -- internals shared by the translation units that implement the
+// C ABI (sono_capi.hip, sono_capi_detect.hip): error reporting, device buffers
+// and the engine object behind the opaque sono_engine handle.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/sonostft.h"
+#include "sono_core.h"
+#include "sono_tile.h"
+
+namespace sono {
+
+// Records the calling thread's error message and returns `code`.
+int fail(int code, const std::string &msg);
+// Maps a HIP error to a status code, clears HIP's sticky error and records the message.
+int hip_fail(hipError_t e, const char *what);
+
+#define HIP_TRY(expr)                                                    \
+    do {                                                                 \
+        hipError_t _e = (expr);                                          \
+        if (_e != hipSuccess) return ::sono::hip_fail(_e, #expr);        \
+    } while (0)
+
+// A device allocation that only ever grows.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes; else p = nullptr;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Tables {
+    unsigned int N = 0;
+    float *d_window = nullptr;
+    float2 *d_tw_half = nullptr;   // N/2 entries
+    float2 *d_tw_full = nullptr;   // N/2 + 1 entries
+    TileTables tile;               // inter-pass twiddles of the register-tiled kernel (may be empty)
+    void release()
+    {
+        if (d_window) (void)hipFree(d_window);
+        if (d_tw_half) (void)hipFree(d_tw_half);
+        if (d_tw_full) (void)hipFree(d_tw_full);
+        tile_tables_release(tile);
+        d_window = nullptr; d_tw_half = nullptr; d_tw_full = nullptr;
+    }
+};
+
+// Makes `dev` (if >= 0) the current HIP device for the lifetime of the guard.
+class DeviceGuard {
+public:
+    explicit DeviceGuard(int dev) : ok_(false), prev_(-1)
+    {
+        if (hipGetDevice(&prev_) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (dev >= 0 && dev != prev_) {
+            if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return; }
+            changed_ = true;
+        }
+        ok_ = true;
+    }
+    ~DeviceGuard() { if (changed_) (void)hipSetDevice(prev_); }
+    bool ok() const { return ok_; }
+private:
+    bool ok_, changed_ = false;
+    int prev_;
+};
+
+}  // namespace sono
+
+struct sono_engine {
+    unsigned int N = 0;
+    int device = 0;
+    float alpha = 0.16f;
+    std::string window_name;
+    std::vector<float> window;
+    sono::Tables tables;
+    hipStream_t stream = nullptr;
+    // device scratch of the host-pointer entry points
+    sono::DevBuf d_in, d_out, d_peak_bin, d_peak_mag, d_gmax, d_mags, d_bank;
+    // device scratch of the detector front end (sono_capi_detect.hip)
+    sono::DevBuf d_db, d_flags, d_edges, d_runs, d_count, d_select_tmp;
+    // filter bank (lib.rs:20-22)
+    std::vector<float> bank;
+    unsigned int num_filters = 0;
+    bool use_bank = false;
+    // state left behind by the last u8 call (lib.rs:24-26)
+    bool has_last = false;
+    std::vector<uint16_t> last_peak_bin;
+    std::vector<float> last_peak_mag;
+    float last_gmax = 0.0f;
+    // colour map / config (lib.rs:28-32)
+    std::vector<uint32_t> color_map;
+    std::string scale = "linear";
+    float freq_min = 0.0f, freq_max = 0.0f;
+};

@@ -1,0 +1,86 @@
+"""Detector front end on the GPU (spectrogram_amd.detector -> libsonostft)
+against the golden vectors of the reference's JavaScript and the numpy oracle."""
+import numpy as np
+import pytest
+
+import spectrogram_amd as sa
+from oracle import detector_oracle as do
+from oracle import sono_oracle as so
+from spectrogram_amd import detector as det
+from tests.test_detector_oracle import G, META, pairs
+
+pytestmark = pytest.mark.gpu
+
+
+def seg_pairs(segs, a, b):
+    return [(s[a], s[b]) for s in segs]
+
+
+@pytest.mark.parametrize("c", META, ids=[c["name"] for c in META])
+def test_detector_matches_reference(c):
+    n = c["name"]
+    x = G[n + "/x"]
+    e = sa.SpectrogramEngine(c["fft"], c["window"])
+    segs = det.fast_scan_segments(e, x, c["sr"], c["flow_khz"], c["fhigh_khz"], c["scan_threshold_db"])
+    assert seg_pairs(segs, "start", "end") == pairs(G[n + "/scan"])                     # call boundaries: exact
+    merged = det.merge_and_pad_segments(segs, len(x), c["sr"], c["padding_ms"])
+    assert seg_pairs(merged, "startSample", "endSample") == pairs(G[n + "/merged"])
+    sp = det.generate_spectrogram(e, x, c["sr"], c["flow_khz"], c["fhigh_khz"], c["hop_percent"])
+    F, nb = (int(v) for v in G[n + "/shape"])
+    if F == 0:
+        assert sp is None
+        e.free()
+        return
+    assert sp["powerMatrix"].shape == (F, nb) and sp["powerMatrix"].dtype == np.float32
+    ref = G[n + "/db"].reshape(F, nb)
+    live = ref > ref.max(axis=1, keepdims=True) - 70.0
+    assert np.abs(sp["powerMatrix"] - ref)[live].max() <= 0.01                          # dB
+    assert np.array_equal(sp["timeFrames"], G[n + "/time"]) and np.array_equal(sp["freqBins"], G[n + "/freq"])
+    assert sp["freqResolution"] == G[n + "/freqres"][0]
+    calls = det.detect_call_segments(e, sp["powerMatrix"], c["call_threshold_db"])
+    assert seg_pairs(calls, "startFrame", "endFrame") == pairs(G[n + "/calls"])
+    calls = det.detect_call_segments(e, ref, c["call_threshold_db"])
+    assert seg_pairs(calls, "startFrame", "endFrame") == pairs(G[n + "/calls"])
+    e.free()
+
+
+def test_frame_features_match_oracle():
+    c = next(m for m in META if m["name"] == "pulses384k")
+    F, nb = (int(v) for v in G["pulses384k/shape"])
+    db = G["pulses384k/db"].reshape(F, nb)
+    e = sa.SpectrogramEngine(1024, "hann")
+    peak = float(db.max())
+    for (b0, b1, lmax, lthr, hmin, hthr) in [(0, nb - 1, nb - 1, peak - 27.0, 0, peak - 24.0),
+                                            (10, 150, 120, peak - 40.0, 30, peak - 10.0),
+                                            (50, 40, 0, -1000.0, nb - 1, 1000.0)]:
+        got = det.frame_features(e, db, b0, b1, lmax, lthr, hmin, hthr)
+        ref = do.frame_features(db, b0, b1, lmax, lthr, hmin, hthr)
+        for a, b in zip(got, ref):
+            assert a.dtype == b.dtype and np.array_equal(a, b)
+    e.free()
+
+
+def test_runs_edge_cases():
+    e = sa.SpectrogramEngine(256, "hann")
+    rng = np.random.default_rng(7)
+    for F in (1, 2, 63, 64, 65, 1000, 4097):
+        for kind in ("none", "all", "alternate", "random"):
+            active = {"none": np.zeros(F, bool), "all": np.ones(F, bool), "alternate": np.arange(F) % 2 == 0,
+                      "random": rng.random(F) < 0.3}[kind]
+            # a dB matrix whose row maximum is 0 where active and -50 elsewhere; one loud row pins the global max
+            db = np.full((F + 1, 5), -80.0, np.float32)
+            db[:F, 2] = np.where(active, 0.0, -50.0)
+            db[F, 1] = 10.0
+            got = det.detect_call_segments(e, db, -24.0)
+            want = do.runs(list(active) + [True])
+            assert seg_pairs(got, "startFrame", "endFrame") == want, (F, kind)
+    assert det.detect_call_segments(e, np.zeros((0, 4), np.float32)) == []
+    e.free()
+
+
+def test_merge_and_pad_is_host_only_and_sorts():
+    segs = [{"start": 5000, "end": 6000}, {"start": 100, "end": 300}, {"start": 6100, "end": 6500}]
+    got = det.merge_and_pad_segments(segs, 7000, 1000.0, 50.0)
+    assert seg_pairs(got, "startSample", "endSample") == do.merge_and_pad_segments(
+        [(s["start"], s["end"]) for s in segs], 7000, 1000.0, 50.0)
+    assert det.merge_and_pad_segments([], 10, 1.0, 1.0) == []

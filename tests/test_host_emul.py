@@ -107,7 +107,7 @@ def test_generic_block_power_mode(emul):
     parity.check_power(db.astype(np.float32), so.compute_power_spectrum(x, 384000, N, "hann", 75.0), "emul power")
 
 
-@pytest.mark.parametrize("N,V", [(1024, 768), (1024, 0), (1024, 1022), (512, 256), (512, 384), (256, 128), (256, 64)])
+@pytest.mark.parametrize("N,V", [(1024, 768), (1024, 512), (1024, 992), (1024, 0), (1024, 1022), (512, 256), (512, 384), (256, 128), (256, 192), (256, 64)])
 def test_tile_wave_matches_oracle(emul, N, V):
     H = N - V
     x = signal(N + 10 * H + (H - 1 if H > 1 else 0), N + 1)
