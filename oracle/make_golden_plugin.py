@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Capture golden vectors of the spectrogram plugin's frame contract from the
+reference's own JavaScript (getFrequencies of modules/spectrogram.esm.js) driving
+the reference wasm.  TEST INFRASTRUCTURE ONLY; runs in the build container.
+
+  python oracle/make_golden_plugin.py      # rewrites tests/golden/golden_plugin.json
+"""
+import base64
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+from make_golden import chirp, tone, white  # noqa: E402
+
+WASM = os.environ.get("SONO_REF_WASM", "/root/reference/modules/spectrogram_wasm_bg.wasm")
+PLUGIN_JS = os.environ.get("SONO_REF_PLUGIN", "/root/reference/modules/spectrogram.esm.js")
+OUT = os.path.join(ROOT, "tests", "golden", "golden_plugin.json")
+
+
+def build_cases():
+    cases, bufs, pos = [], [], [0]
+
+    def add(name, channels, sr, fft, noverlap=0, canvas_width=800, peak_mode=True, peak_threshold=0.4,
+            split=False, gain=20.0, rng=80.0, window="hann"):
+        chs = []
+        for x in channels:
+            x = np.ascontiguousarray(x, np.float32)
+            chs.append([pos[0], int(x.size)])
+            bufs.append(x)
+            pos[0] += x.size
+        cases.append(dict(name=name, channels=chs, sr=sr, fft=fft, window=window, noverlap=noverlap,
+                          canvas_width=canvas_width, peak_mode=peak_mode, peak_threshold=peak_threshold,
+                          split_channels=split, gain_db=gain, range_db=rng))
+
+    sr = 384000
+    add("mono_auto_overlap", [chirp(9000, sr, 61, t0=0.002)], sr, 512, noverlap=0, canvas_width=40)
+    add("mono_fixed_overlap", [chirp(6000, sr, 62, t0=0.001)], sr, 512, noverlap=256, peak_threshold=0.8)
+    add("stereo_split", [chirp(5000, sr, 63, t0=0.001), tone(5000, sr, 45000.0, amp=0.2, noise=1e-3, seed=64)],
+        sr, 256, noverlap=128, split=True, peak_threshold=0.1)
+    add("stereo_unsplit", [chirp(4000, sr, 65, t0=0.001), white(4000, 66)], sr, 256, noverlap=192, split=False,
+        peak_mode=False)
+    add("quiet_frames", [np.concatenate([1e-6 * white(3000, 67, 1.0), tone(3000, sr, 30000.0, amp=0.5)])], sr, 512,
+        noverlap=384, peak_threshold=0.4)
+    add("wide_canvas", [chirp(1150, sr, 68, t0=0.0005)], sr, 1024, noverlap=0, canvas_width=2000, peak_mode=False)
+    return cases, np.concatenate(bufs)
+
+
+def main():
+    cases, inputs = build_cases()
+    with tempfile.TemporaryDirectory() as work:
+        json.dump(cases, open(os.path.join(work, "cases.json"), "w"))
+        inputs.tofile(os.path.join(work, "inputs.bin"))
+        node = ["node"]
+        ver = subprocess.check_output(["node", "--version"]).decode().strip()
+        if int(ver.lstrip("v").split(".")[0]) < 16:
+            node += ["--experimental-wasm-mv", "--experimental-wasm-anyref"]
+        subprocess.check_call(node + [os.path.join(HERE, "plugin_driver.js"), WASM, PLUGIN_JS, work])
+        res = json.load(open(os.path.join(work, "outputs.json")))
+    out = []
+    for c in cases:
+        r = res[c["name"]]
+        chans = [base64.b64encode(inputs[o:o + n].tobytes()).decode() for o, n in c["channels"]]
+        frames = []
+        for ch in r["frames"]:
+            rows = [np.frombuffer(base64.b64decode(f), np.uint8) for f in ch]
+            flat = np.concatenate(rows) if rows else np.zeros(0, np.uint8)
+            frames.append({"count": len(rows), "u8": base64.b64encode(flat.tobytes()).decode()})
+        c2 = {k: v for k, v in c.items() if k != "channels"}
+        c2.update(x=chans, frames=frames, peaks=r["peaks"])
+        out.append(c2)
+        print(f"  {c['name']}: channels {len(frames)} frames {[f['count'] for f in frames]} "
+              f"peak lists {[sum(len(p) for p in ch) for ch in r['peaks']]}")
+    json.dump(out, open(OUT, "w"))
+    print(f"wrote {OUT}: {os.path.getsize(OUT)} bytes")
+
+
+if __name__ == "__main__":
+    sys.exit(main())
