@@ -1,0 +1,40 @@
+// sonoradar_gpu.js -- the module shell SonoRadar imports in place of
+// modules/spectrogram_wasm.js when it runs under Node on a GPU box: same export
+// names as the wasm-bindgen glue (modules/spectrogram_wasm.d.ts:4-335), backed by
+// the N-API addon sonostft.node -> libsonostft.so -> HIP kernels.
+//
+//   const wasm = require('./napi/sonoradar_gpu.js');
+//   await wasm.default();                       // init(): resolves at once, nothing to fetch or compile
+//   const e = new wasm.SpectrogramEngine(1024, 'hann', null);
+//
+// There is no CPU fallback here: without the addon or without a GPU the
+// constructor throws, which is what batCallDetector's own wasm -> JS fallback
+// (batCallDetector.js:858-870) keys on.
+'use strict';
+const path = require('path');
+
+const addon = require(path.join(__dirname, 'sonostft.node'));
+
+class SpectrogramEngine extends addon.SpectrogramEngine {}
+class WaveformEngine extends addon.WaveformEngine {}
+if (typeof Symbol.dispose === 'symbol') {
+  SpectrogramEngine.prototype[Symbol.dispose] = SpectrogramEngine.prototype.free;
+  WaveformEngine.prototype[Symbol.dispose] = WaveformEngine.prototype.free;
+}
+
+// init(module_or_path?) / initSync(module): the wasm glue instantiates the module here
+// (spectrogram_wasm.d.ts:324-334); the addon is ready as soon as it is loaded.
+function initSync() { return module.exports; }
+function init() { return Promise.resolve(module.exports); }
+
+module.exports = {
+  default: init,
+  initSync,
+  SpectrogramEngine,
+  WaveformEngine,
+  compute_power_spectrum: addon.compute_power_spectrum,
+  find_peak_frequency_from_spectrum: addon.find_peak_frequency_from_spectrum,
+  compute_wave_peaks: addon.compute_wave_peaks,
+  find_global_max: addon.find_global_max,
+  device_count: addon.device_count,          // not in the wasm surface: lets a batch driver size its worker pool
+};

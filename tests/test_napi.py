@@ -1,0 +1,108 @@
+"""The Node N-API addon (napi/): its export surface on any machine, and on a GPU
+its results against the Python binding of the same library and the oracle."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ADDON = os.path.join(ROOT, "napi", "sonostft.node")
+
+# The export surface of the reference's wasm-bindgen module (modules/spectrogram_wasm.d.ts:4-271, 324-334).
+MODULE_EXPORTS = ["default", "initSync", "SpectrogramEngine", "WaveformEngine", "compute_power_spectrum",
+                  "find_peak_frequency_from_spectrum", "compute_wave_peaks", "find_global_max"]
+ENGINE_METHODS = ["free", "get_fft_size", "get_freq_bins", "get_num_filters", "get_window_values", "load_filter_bank",
+                  "clear_filter_bank", "compute_spectrogram", "compute_spectrogram_u8", "get_peaks",
+                  "get_peak_magnitudes", "get_global_max", "set_color_map", "set_spectrum_config",
+                  "compute_spectrogram_image", "release_memory"]
+WAVEFORM_METHODS = ["free", "resize", "load_channel", "get_peaks_in_range", "get_channel_length", "get_num_channels",
+                    "clear", "release_memory"]
+
+
+def need_node():
+    if shutil.which("node") is None:
+        pytest.skip("node is not installed")
+    if not os.path.exists(ADDON):
+        from napi import build_addon
+        if build_addon.build() is None:
+            pytest.skip("Node headers are not installed: the addon cannot be built here")
+
+
+def node(script):
+    return subprocess.check_output(["node", "-e", script], cwd=ROOT, stderr=subprocess.STDOUT, timeout=120).decode()
+
+
+def test_addon_presents_the_wasm_module_surface():
+    need_node()
+    out = json.loads(node("""
+        const w = require('./napi/sonoradar_gpu.js');
+        const own = (c) => Object.getOwnPropertyNames(Object.getPrototypeOf(c.prototype));
+        const x = new Float32Array([0.1, -0.5, 0.3, 0.2]);
+        const we = new w.WaveformEngine(); we.resize(2); we.load_channel(1, x);
+        const r = {exports: Object.keys(w), engine: own(w.SpectrogramEngine), wave: own(w.WaveformEngine),
+                   gmax: w.find_global_max(x), peaks: Array.from(w.compute_wave_peaks(x, 2)),
+                   chans: we.get_num_channels(), len: [we.get_channel_length(0), we.get_channel_length(1)],
+                   range: Array.from(we.get_peaks_in_range(1, 0, 4, 2)),
+                   peakfreq: w.find_peak_frequency_from_spectrum(new Float32Array([0, 1, 5, 2, 0]), 8000, 8, 0, 4000)};
+        we.free();
+        try { we.clear(); } catch (e) { r.after_free = e.message; }
+        w.default().then((m) => { r.init_ok = m === w && w.initSync() === w; console.log(JSON.stringify(r)); });
+    """))
+    assert set(MODULE_EXPORTS) <= set(out["exports"])
+    assert set(ENGINE_METHODS) <= set(out["engine"]) and set(WAVEFORM_METHODS) <= set(out["wave"])
+    assert out["init_ok"] and out["gmax"] == 0.5 and out["peaks"] == [0.5, np.float32(0.3)]
+    assert out["chans"] == 2 and out["len"] == [0, 4] and out["range"] == [0.5, np.float32(0.3)]
+    assert out["after_free"] == "null pointer passed to rust"
+    assert abs(out["peakfreq"] - (2 + 1 / 14) * 1000) < 1e-3     # parabola through (1, 5, 2) dB around bin 2 of 1000 Hz bins (lib.rs:1163-1172)
+
+
+def test_addon_without_gpu_throws_instead_of_falling_back():
+    need_node()
+    import spectrogram_amd as sa
+    if sa.device_count() > 0:
+        pytest.skip("a GPU is present")
+    out = node("""
+        const w = require('./napi/sonoradar_gpu.js');
+        try { new w.SpectrogramEngine(1024, 'hann', null); console.log('constructed'); } catch (e) { console.log('threw: ' + e.message); }
+    """)
+    assert out.startswith("threw: ") and "no HIP device" in out
+
+
+@pytest.mark.gpu
+def test_addon_results_equal_python_binding_and_oracle(tmp_path):
+    need_node()
+    import spectrogram_amd as sa
+    from oracle import sono_oracle as so
+    from tests import parity
+    from tests.test_gpu_parity import signal
+    N, V, sr = 1024, 768, 384000
+    x = signal(N + 40 * 256 + 9, 123)
+    x.tofile(tmp_path / "x.f32")
+    job = dict(input=str(tmp_path / "x.f32"), fft=N, window="hann", noverlap=V, gain=20.0, range=80.0, ratio=0.4, sr=sr,
+               out=str(tmp_path))
+    (tmp_path / "job.json").write_text(json.dumps(job))
+    subprocess.check_call(["node", os.path.join(ROOT, "napi", "run_case.js"), str(tmp_path / "job.json")], timeout=120)
+    meta = json.loads((tmp_path / "meta.json").read_text())
+    rd = lambda name, dt: np.fromfile(tmp_path / name, dtype=dt)
+    e = sa.SpectrogramEngine(N, "hann")
+    o = so.OracleEngine(N, "hann")
+    assert meta["fft"] == N and meta["bins"] == 512 and meta["filters"] == 0 and meta["peaks_before"] == 0
+    assert np.array_equal(rd("window.f32", np.float32), e.get_window_values())
+    assert np.array_equal(rd("mag.f32", np.float32), e.compute_spectrogram(x, V))           # same library: bit-exact
+    assert np.array_equal(rd("u8.u8", np.uint8), e.compute_spectrogram_u8(x, V, 20.0, 80.0))
+    assert np.array_equal(rd("peaks.u16", np.uint16), e.get_peaks(0.4))
+    assert np.array_equal(rd("peakmags.f32", np.float32), e.get_peak_magnitudes(0.4))
+    assert meta["gmax"] == e.get_global_max()
+    parity.check_mag(rd("mag.f32", np.float32), o.compute_spectrogram(x, V), 512, "addon mag")
+    nd, nt = parity.u8_diff(rd("u8.u8", np.uint8), o.compute_spectrogram_u8(x, V, 20.0, 80.0), "addon u8")
+    assert nd <= max(2, parity.U8_MAX_FRACTION * nt)
+    assert np.array_equal(rd("peaks.u16", np.uint16), o.get_peaks(0.4))
+    spec = rd("power.f32", np.float32)
+    parity.check_power(spec, so.compute_power_spectrum(x, sr, N, "hann", 75.0), "addon power spectrum")
+    assert meta["peakfreq"] == sa.find_peak_frequency_from_spectrum(spec, sr, N, 10000, 120000)
+    assert "noverlap must be < fft_size" in meta["noverlap_error"]        # the reference panics here (lib.rs:118-120)
+    assert meta["after_free"] == "null pointer passed to rust"
+    e.free()
