@@ -11,6 +11,7 @@ import numpy as np
 from . import FrameFeatures as _FrameFeatures, Segment as _Segment, _check, _f32, _p, lib
 
 __all__ = ["fast_scan_segments", "merge_and_pad_segments", "generate_spectrogram", "detect_call_segments",
+           "process_full_file_front_end",
            "frame_features", "DEFAULT_DETECTION_CONFIG"]
 
 # the two members of DEFAULT_DETECTION_CONFIG (batCallDetector.js:3-45) these passes read
@@ -100,3 +101,43 @@ def frame_features(engine, power_matrix, peak_b0, peak_b1, low_max_bin, low_thre
     a = np.frombuffer(out, dtype=np.dtype([("peak_bin", "<i4"), ("peak_db", "<f4"), ("low_bin", "<i4"),
                                            ("high_bin", "<i4")]), count=F)
     return a["peak_bin"].copy(), a["peak_db"].copy(), a["low_bin"].copy(), a["high_bin"].copy()
+
+
+def process_full_file_front_end(engine, full_audio, sample_rate, flow_khz, fhigh_khz, threshold_db=-60, padding_ms=5,
+                                hop_percent=None, call_threshold_db=None, min_call_duration_ms=0.0):
+    """The array stages of processFullFile (batCallDetector.js:584-735) in their order: fast scan ->
+    merge & pad -> per ROI: analysis spectrogram -> call segments -> peak of every segment.  The serial
+    measurement stage that follows in the reference (auto high-pass, measureFrequencyParameters) is not
+    part of this library.  -> list of candidate calls:
+    {'roi', 'startSample', 'startFrame', 'endFrame', 'startTime_s', 'endTime_s', 'duration_ms',
+     'peakFrame', 'peakTime_s', 'peakFreq_kHz', 'peakPower_dB'} with times measured from the start of the file."""
+    x = _f32(full_audio)
+    raw = fast_scan_segments(engine, x, sample_rate, flow_khz, fhigh_khz, threshold_db)            # js:594
+    if not raw:
+        return []
+    merged = merge_and_pad_segments(raw, x.size, sample_rate, padding_ms)                          # js:601
+    calls = []
+    for roi, seg in enumerate(merged):
+        audio = x[seg["startSample"]:seg["endSample"]]                                             # js:612
+        spec = generate_spectrogram(engine, audio, sample_rate, flow_khz, fhigh_khz, hop_percent)  # js:617
+        if spec is None:
+            continue
+        power, t, fb = spec["powerMatrix"], spec["timeFrames"], spec["freqBins"]
+        segments = detect_call_segments(engine, power, call_threshold_db)                          # js:677
+        if not segments:
+            continue
+        nb = power.shape[1]
+        peak_bin, peak_db, _, _ = frame_features(engine, power, 0, nb - 1, 0, np.inf, nb, np.inf)
+        t0 = seg["startSample"] / sample_rate
+        for s in segments:
+            f0, f1 = s["startFrame"], s["endFrame"]
+            if t[f1] - t[f0] < min_call_duration_ms / 1000:                                         # js:688-690
+                continue
+            pf = f0 + int(np.argmax(peak_db[f0:f1 + 1]))           # first frame holding the segment's largest bin (js:696-705)
+            calls.append({
+                "roi": roi, "startSample": seg["startSample"], "startFrame": f0, "endFrame": f1,
+                "startTime_s": t0 + t[f0], "endTime_s": t0 + t[f1], "duration_ms": (t[f1] - t[f0]) * 1000,
+                "peakFrame": pf, "peakTime_s": t0 + t[pf], "peakFreq_kHz": float(fb[peak_bin[pf]]) / 1000,
+                "peakPower_dB": float(peak_db[pf]),
+            })
+    return calls

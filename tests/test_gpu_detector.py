@@ -84,3 +84,27 @@ def test_merge_and_pad_is_host_only_and_sorts():
     assert seg_pairs(got, "startSample", "endSample") == do.merge_and_pad_segments(
         [(s["start"], s["end"]) for s in segs], 7000, 1000.0, 50.0)
     assert det.merge_and_pad_segments([], 10, 1.0, 1.0) == []
+
+
+def test_front_end_pipeline_matches_oracle_composition():
+    # fast scan -> merge & pad -> per ROI spectrogram -> call segments -> segment peaks, GPU vs the pinned oracle stages
+    from oracle.make_golden import chirp
+    sr, flow, fhigh = 384000, 10.0, 128.0
+    x = chirp(120000, sr, 91, period=0.06, t0=0.01)
+    e = sa.SpectrogramEngine(1024, "hann")
+    o = so.OracleEngine(1024, "hann")
+    got = det.process_full_file_front_end(e, x, sr, flow, fhigh, threshold_db=-60, padding_ms=10)
+    want = []
+    merged = do.merge_and_pad_segments(do.fast_scan_segments(o, x, sr, flow, fhigh, -60), len(x), sr, 10)
+    for roi, (s0, s1) in enumerate(merged):
+        sp = do.generate_spectrogram(o, x[s0:s1], sr, flow, fhigh, 3.125)
+        for f0, f1 in do.detect_call_segments(sp["powerMatrix"], -24.0):
+            seg = sp["powerMatrix"][f0:f1 + 1]
+            pf, pb = np.unravel_index(int(np.argmax(seg)), seg.shape)
+            want.append((roi, s0, f0, f1, f0 + int(pf), float(sp["freqBins"][pb]) / 1000))
+    assert len(got) == len(want) >= 5
+    for g, w in zip(got, want):
+        assert (g["roi"], g["startSample"], g["startFrame"], g["endFrame"], g["peakFrame"]) == w[:5]
+        assert g["peakFreq_kHz"] == w[5]
+        assert abs(g["duration_ms"] - (g["endFrame"] - g["startFrame"]) * 32 / sr * 1000) < 1e-9
+    e.free()

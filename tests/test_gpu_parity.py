@@ -238,3 +238,24 @@ def test_unaligned_input_pointer(kernel_path):
         x = base[shift:]
         parity.check_mag(e.compute_spectrogram(x, V), o.compute_spectrogram(x, V), 512, f"shift {shift}")
     e.free()
+
+
+def test_time_chunks_of_the_sharding_layer_equal_one_call(kernel_path):
+    # one recording cut into 3 chunks the way sharding.frame_chunks cuts it for 3 GPUs: rows bit-identical to
+    # the unchunked call, global maximum = max over the chunks (the value reduce_global_max all-reduces)
+    from spectrogram_amd import sharding as sh
+    N, V = 512, 384
+    H = N - V
+    x = signal(N + 333 * H + 11, 31)
+    e = sa.SpectrogramEngine(N, "hamming")
+    whole = e.compute_spectrogram_u8(x, V, 20.0, 80.0).reshape(-1, N // 2)
+    gwhole, pk = e.get_global_max(), e.get_peak_magnitudes(0.0)
+    parts, gm, pks = [], 0.0, []
+    for fr in sh.frame_chunks(whole.shape[0], 3):
+        s0, s1 = sh.chunk_samples(fr, N, H)
+        parts.append(e.compute_spectrogram_u8(x[s0:s1], V, 20.0, 80.0).reshape(-1, N // 2))
+        gm = max(gm, e.get_global_max())
+        pks.append(e.get_peak_magnitudes(0.0))
+    assert np.array_equal(np.concatenate(parts), whole) and gm == gwhole
+    assert np.array_equal(np.concatenate(pks), pk)
+    e.free()
