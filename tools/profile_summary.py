@@ -48,3 +48,31 @@ for f in find("*/**/*counter_collection.csv"):
     for c in sorted(acc):
         k = max(len(disp[c]), 1)
         print(f"{os.path.basename(os.path.dirname(os.path.dirname(f))) if False else ''}{c:28s} {acc[c]/k:18.1f}   (dispatches {k})")
+
+# HBM traffic per dispatch for bench.py's roofline.traffic.  rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.
+# On gfx950 FETCH_SIZE tallies each 128-byte read request as 64 bytes, so read bytes = 2 x FETCH_SIZE; that the
+# factor applies to this kernel's loads is confirmed by the result itself: without it the kernel would have
+# fetched less than the samples it provably reads once.  WRITE_SIZE is exact.
+import json
+
+vals = {}
+for f in find("*/**/*counter_collection.csv"):
+    acc, disp = {}, {}
+    for r in csv.DictReader(open(f)):
+        if KEY in r.get("Kernel_Name", ""):
+            c = r["Counter_Name"]
+            acc[c] = acc.get(c, 0.0) + float(r["Counter_Value"])
+            disp.setdefault(c, set()).add(r["Dispatch_Id"])
+    for c in acc:
+        vals[c] = acc[c] / max(len(disp[c]), 1)
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    read_b, write_b = 2.0 * vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
+    out_json = {"fft_size": 1024, "noverlap": 768, "seconds": 3600, "fetch_size_kib": vals["FETCH_SIZE"],
+                "write_size_kib": vals["WRITE_SIZE"], "read_bytes": read_b, "write_bytes": write_b,
+                "hbm_bytes": read_b + write_b,
+                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per dispatch of the STFT kernel; "
+                          "reads = 2 x FETCH_SIZE (gfx950 counts a 128-B request as 64 B), writes = WRITE_SIZE"}
+    with open(os.path.join(out, "hbm_traffic.json"), "w") as fh:
+        json.dump(out_json, fh, indent=1)
+    print()
+    print(f"== HBM traffic per dispatch: read {read_b/1e9:.3f} GB + write {write_b/1e9:.3f} GB = {(read_b+write_b)/1e9:.3f} GB ==")
