@@ -224,6 +224,38 @@ int sono_detect_runs_dev(sono_engine *e, const uint8_t *d_active, size_t frames,
 int sono_merge_and_pad_segments(sono_segment *segs, size_t count, uint64_t total_samples, double sample_rate,
                                 double padding_ms, sono_segment *out, size_t cap, size_t *out_count);
 
+/* ---- WAV / PCM ingest -------------------------------------------------------
+ * The application gets its samples from the browser (WebAudio decodeAudioData,
+ * wavesurfer.esm.js:67-70) after sniffing the RIFF header itself
+ * (modules/fileLoader.js:7-63).  A batch driver has no browser: these calls walk
+ * the chunks the same way and convert interleaved PCM to one f32 channel on the
+ * GPU (integer PCM is divided by 2^(bits-1), as WebAudio does). */
+
+typedef struct sono_wav_info {
+    uint32_t format_tag;        /* 1 = integer PCM, 3 = IEEE float, 0xFFFE = extensible (sub-format in the first two GUID bytes) */
+    uint32_t channels;
+    uint32_t sample_rate;       /* fileLoader.js:20 */
+    uint32_t bits_per_sample;   /* fileLoader.js:47 */
+    uint64_t data_offset;       /* byte offset of the first sample */
+    uint64_t data_bytes;        /* size of the data chunk, clipped to the buffer */
+    uint64_t frames;            /* samples per channel = data_bytes / (channels * bits/8) (fileLoader.js:55-57) */
+    uint64_t guano_offset;      /* 'guan' metadata chunk (modules/guanoReader.js), 0 if absent */
+    uint64_t guano_bytes;
+} sono_wav_info;
+
+/* Host only.  SONO_EINVAL if the buffer is not RIFF/WAVE or has no fmt/data chunk. */
+int sono_wav_parse(const uint8_t *bytes, size_t len, sono_wav_info *info);
+
+/* d_pcm: `frames` interleaved sample frames of `channels` channels in HBM, 8/16/24/32-bit integer
+ * (is_float == 0) or 32-bit float (is_float != 0); d_out: `frames` f32 samples of `channel`. */
+int sono_pcm_to_f32_dev(sono_engine *e, const void *d_pcm, size_t frames, uint32_t channels, uint32_t channel,
+                        uint32_t bits_per_sample, int is_float, float *d_out, void *hip_stream);
+
+/* Host convenience: parse, upload the data chunk, convert one channel, copy it back.
+ * *count = frames; cap in floats. */
+int sono_wav_decode_channel(sono_engine *e, const uint8_t *bytes, size_t len, uint32_t channel, float *out,
+                            size_t cap, size_t *count, sono_wav_info *info /* may be NULL */);
+
 /* ---- free functions ----------------------------------------------------- */
 
 /* compute_power_spectrum (wasm.d.ts:6; lib.rs:1019-1118).  has_overlap == 0

@@ -15,7 +15,7 @@ import numpy as np
 
 __all__ = [
     "SpectrogramEngine", "WaveformEngine", "compute_power_spectrum",
-    "find_peak_frequency_from_spectrum", "compute_wave_peaks", "find_global_max",
+    "find_peak_frequency_from_spectrum", "compute_wave_peaks", "find_global_max", "wav_info", "decode_wav",
     "frames_for", "device_count", "lib", "LIB_PATH", "SonoError",
 ]
 
@@ -53,6 +53,13 @@ class Segment(C.Structure):
 class FrameFeatures(C.Structure):
     """struct sono_frame_features."""
     _fields_ = [("peak_bin", C.c_int32), ("peak_db", C.c_float), ("low_bin", C.c_int32), ("high_bin", C.c_int32)]
+
+
+class WavInfo(C.Structure):
+    """struct sono_wav_info."""
+    _fields_ = [("format_tag", C.c_uint32), ("channels", C.c_uint32), ("sample_rate", C.c_uint32),
+                ("bits_per_sample", C.c_uint32), ("data_offset", C.c_uint64), ("data_bytes", C.c_uint64),
+                ("frames", C.c_uint64), ("guano_offset", C.c_uint64), ("guano_bytes", C.c_uint64)]
 
 
 _segp = C.POINTER(Segment)
@@ -110,6 +117,11 @@ _SIGNATURES = {
                                                  C.c_uint32, C.c_double, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p]),
     "sono_detect_runs_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
+    "sono_wav_parse": (C.c_int, [_u8p, C.c_size_t, C.POINTER(WavInfo)]),
+    "sono_pcm_to_f32_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                      C.c_void_p, C.c_void_p]),
+    "sono_wav_decode_channel": (C.c_int, [C.c_void_p, _u8p, C.c_size_t, C.c_uint32, _f32p, C.c_size_t, _szp,
+                                          C.POINTER(WavInfo)]),
     "sono_power_spectrum": (C.c_int, [_f32p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_char_p, C.c_int,
                                       C.c_float, C.c_int, _f32p, C.c_size_t, _szp]),
     "sono_find_peak_frequency": (C.c_float, [_f32p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_float, C.c_float]),
@@ -405,3 +417,23 @@ def find_global_max(channel_data):
     """spectrogram_wasm.d.ts:256 / lib.rs:834-840."""
     x = _f32(channel_data)
     return float(lib().sono_find_global_max(_p(x), x.size))
+
+
+def wav_info(data):
+    """RIFF chunk walk of modules/fileLoader.js:7-63 over the bytes of a .wav file -> dict (host only)."""
+    b = np.frombuffer(data, dtype=np.uint8)
+    info = WavInfo()
+    _check(lib().sono_wav_parse(_p(b, _u8p), b.size, C.byref(info)))
+    return {k: int(getattr(info, k)) for k, _ in WavInfo._fields_}
+
+
+def decode_wav(engine, data, channel=0):
+    """One channel of a .wav file as float32 (what AudioBuffer.getChannelData gives the application):
+    the data chunk is uploaded and converted on the engine's GPU.  -> (samples, info dict)."""
+    b = np.frombuffer(data, dtype=np.uint8)
+    meta = wav_info(data)
+    out = np.empty(max(meta["frames"], 1), dtype=np.float32)
+    got = C.c_size_t(0)
+    _check(lib().sono_wav_decode_channel(engine._handle(), _p(b, _u8p), b.size, int(channel), _p(out), out.size,
+                                         C.byref(got), None))
+    return out[: got.value], meta

@@ -261,6 +261,82 @@ int sono_frame_features_db(sono_engine *e, const float *power_db, size_t frames,
     return SONO_OK;
 }
 
+int sono_wav_parse(const uint8_t *b, size_t len, sono_wav_info *info)
+{
+    if (!b || !info) return fail(SONO_EINVAL, "sono_wav_parse: NULL argument");
+    std::memset(info, 0, sizeof(*info));
+    if (len < 12 || std::memcmp(b, "RIFF", 4) != 0 || std::memcmp(b + 8, "WAVE", 4) != 0)
+        return fail(SONO_EINVAL, "sono_wav_parse: not a RIFF/WAVE buffer");
+    auto u16 = [&](size_t p) { return (uint32_t)b[p] | ((uint32_t)b[p + 1] << 8); };
+    auto u32 = [&](size_t p) { return u16(p) | (u16(p + 2) << 16); };
+    bool have_fmt = false, have_data = false;
+    size_t pos = 12;                                                             // fileLoader.js:11
+    while (pos + 8 <= len) {                                                     // fileLoader.js:12
+        const uint32_t size = u32(pos + 4);
+        if (std::memcmp(b + pos, "fmt ", 4) == 0 && pos + 8 + 16 <= len) {
+            info->format_tag = u16(pos + 8);
+            info->channels = u16(pos + 10);                                      // fileLoader.js:45
+            info->sample_rate = u32(pos + 12);                                   // fileLoader.js:20,46
+            info->bits_per_sample = u16(pos + 22);                               // fileLoader.js:47
+            if (info->format_tag == 0xFFFEu && size >= 26 && pos + 8 + 26 <= len) info->format_tag = u16(pos + 8 + 24);
+            have_fmt = true;
+        } else if (std::memcmp(b + pos, "data", 4) == 0 && !have_data) {
+            info->data_offset = pos + 8;
+            info->data_bytes = std::min<uint64_t>(size, len - (pos + 8));
+            have_data = true;
+        } else if (std::memcmp(b + pos, "guan", 4) == 0) {
+            info->guano_offset = pos + 8;
+            info->guano_bytes = std::min<uint64_t>(size, len - (pos + 8));
+        }
+        pos += 8 + (size_t)size;                                                 // fileLoader.js:22-23
+        if (size % 2 == 1) pos += 1;
+    }
+    if (!have_fmt || !have_data) return fail(SONO_EINVAL, "sono_wav_parse: fmt or data chunk missing");
+    const uint32_t bytes = info->bits_per_sample / 8;
+    if (info->channels == 0 || bytes == 0 || bytes > 4 || (info->format_tag != 1 && info->format_tag != 3) ||
+        (info->format_tag == 3 && bytes != 4))
+        return fail(SONO_EINVAL, "sono_wav_parse: unsupported sample format");
+    info->frames = info->data_bytes / ((uint64_t)info->channels * bytes);         // fileLoader.js:55-57
+    return SONO_OK;
+}
+
+int sono_pcm_to_f32_dev(sono_engine *e, const void *d_pcm, size_t frames, uint32_t channels, uint32_t channel,
+                        uint32_t bits, int is_float, float *d_out, void *hip_stream)
+{
+    if (!e || (frames && (!d_pcm || !d_out))) return fail(SONO_EINVAL, "sono_pcm_to_f32_dev: NULL argument");
+    if (channels == 0 || channel >= channels || bits % 8 || bits == 0 || bits > 32 || (is_float && bits != 32))
+        return fail(SONO_EINVAL, "sono_pcm_to_f32_dev: bad sample format or channel");
+    DeviceGuard guard(e->device);
+    HIP_TRY(sono::launch_pcm_to_f32(d_pcm, frames, channels, channel, bits, is_float, d_out, pick(e, hip_stream)));
+    return SONO_OK;
+}
+
+int sono_wav_decode_channel(sono_engine *e, const uint8_t *bytes, size_t len, uint32_t channel, float *out, size_t cap,
+                            size_t *count, sono_wav_info *info_out)
+{
+    if (count) *count = 0;
+    if (!e) return fail(SONO_EINVAL, "sono_wav_decode_channel: NULL engine");
+    sono_wav_info info;
+    int rc = sono_wav_parse(bytes, len, &info);
+    if (rc) return rc;
+    if (info_out) *info_out = info;
+    if (channel >= info.channels) return fail(SONO_EINVAL, "sono_wav_decode_channel: no such channel");
+    if (info.frames == 0) return SONO_OK;
+    if (!out || cap < info.frames) return fail(SONO_ECAPACITY, "sono_wav_decode_channel: output buffer too small");
+    DeviceGuard guard(e->device);
+    const size_t used = info.frames * info.channels * (info.bits_per_sample / 8);
+    HIP_TRY(e->d_in.reserve(used));
+    HIP_TRY(e->d_out.reserve(info.frames * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(e->d_in.p, bytes + info.data_offset, used, hipMemcpyHostToDevice, e->stream));
+    rc = sono_pcm_to_f32_dev(e, e->d_in.p, info.frames, info.channels, channel, info.bits_per_sample,
+                             info.format_tag == 3, (float *)e->d_out.p, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, e->d_out.p, info.frames * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (count) *count = info.frames;
+    return SONO_OK;
+}
+
 int sono_merge_and_pad_segments(sono_segment *segs, size_t count, uint64_t total_samples, double sample_rate,
                                 double padding_ms, sono_segment *out, size_t cap, size_t *out_count)
 {

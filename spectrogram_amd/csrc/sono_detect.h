@@ -42,6 +42,10 @@ hipError_t launch_run_edges(const uint8_t *d_active, size_t frames, uint8_t *d_i
 hipError_t select_flagged(void *d_temp, size_t &temp_bytes, const uint8_t *d_flags, uint64_t *d_out,
                           uint64_t *d_count, size_t frames, hipStream_t s);
 
+// Interleaved PCM -> one f32 channel.  Integer samples are divided by 2^(bits-1); 8-bit WAV is unsigned.
+hipError_t launch_pcm_to_f32(const void *d_pcm, size_t frames, uint32_t channels, uint32_t channel, uint32_t bits,
+                             int is_float, float *d_out, hipStream_t s);
+
 // Order-preserving map f32 -> u32 (so that atomicMax on the key is a float max) and back.
 __host__ __device__ inline uint32_t detect_key(float v)
 {

@@ -136,6 +136,31 @@ __global__ __launch_bounds__(kThreads) void run_edges_kernel(const uint8_t *acti
     is_end[f] = a && !next;
 }
 
+__global__ __launch_bounds__(kThreads) void pcm_to_f32_kernel(const uint8_t *pcm, size_t frames, uint32_t channels,
+                                                              uint32_t channel, uint32_t bytes_per_sample, int is_float,
+                                                              float *out)
+{
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= frames) return;
+    const uint8_t *p = pcm + (i * channels + channel) * (size_t)bytes_per_sample;
+    float v;
+    if (is_float) {
+        uint32_t b = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        v = __uint_as_float(b);
+    } else if (bytes_per_sample == 1) {
+        v = ((float)p[0] - 128.0f) * (1.0f / 128.0f);
+    } else if (bytes_per_sample == 2) {
+        v = (float)(int16_t)((uint16_t)p[0] | ((uint16_t)p[1] << 8)) * (1.0f / 32768.0f);
+    } else if (bytes_per_sample == 3) {
+        const int32_t s = (int32_t)(((uint32_t)p[0] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 24)) >> 8;
+        v = (float)s * (1.0f / 8388608.0f);
+    } else {
+        const int32_t s = (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
+        v = (float)s * (1.0f / 2147483648.0f);
+    }
+    out[i] = v;
+}
+
 unsigned int rows_grid(size_t frames) { return (unsigned int)((frames + kRowsPerBlock - 1) / kRowsPerBlock); }
 
 }  // namespace
@@ -193,6 +218,15 @@ hipError_t launch_run_edges(const uint8_t *d_active, size_t frames, uint8_t *d_i
     if (frames == 0) return hipSuccess;
     hipLaunchKernelGGL(run_edges_kernel, dim3((unsigned int)((frames + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                        d_active, frames, d_is_start, d_is_end);
+    return hipGetLastError();
+}
+
+hipError_t launch_pcm_to_f32(const void *d_pcm, size_t frames, uint32_t channels, uint32_t channel, uint32_t bits,
+                             int is_float, float *d_out, hipStream_t s)
+{
+    if (frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(pcm_to_f32_kernel, dim3((unsigned int)((frames + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                       (const uint8_t *)d_pcm, frames, channels, channel, bits / 8, is_float, d_out);
     return hipGetLastError();
 }
 

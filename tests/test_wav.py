@@ -1,0 +1,91 @@
+"""WAV / PCM ingest: the RIFF chunk walk on any machine, the GPU conversion against numpy.
+The reference decodes in the browser (WebAudio), so there is no reference vector for the sample
+scaling: integer PCM / 2^(bits-1) is the WebAudio convention -- parity unpinned."""
+import struct
+
+import numpy as np
+import pytest
+
+import spectrogram_amd as sa
+
+
+def make_wav(samples, sr, bits, channels=1, is_float=False, extra_chunks=(), odd_pad_chunk=True):
+    """samples: int array (frames x channels) already in the sample type's range, or float32."""
+    a = np.asarray(samples).reshape(-1, channels)
+    if is_float:
+        data = a.astype("<f4").tobytes()
+    elif bits == 8:
+        data = a.astype(np.uint8).tobytes()
+    elif bits == 16:
+        data = a.astype("<i2").tobytes()
+    elif bits == 24:
+        v = a.astype("<i4").reshape(-1)
+        data = b"".join(struct.pack("<i", int(x))[:3] for x in v)
+    else:
+        data = a.astype("<i4").tobytes()
+    fmt = struct.pack("<HHIIHH", 3 if is_float else 1, channels, sr, sr * channels * bits // 8, channels * bits // 8, bits)
+    chunks = [(b"fmt ", fmt)]
+    if odd_pad_chunk:
+        chunks.append((b"LIST", b"abc"))                 # odd size: the walk must skip the pad byte (fileLoader.js:23)
+    chunks += list(extra_chunks) + [(b"data", data)]
+    body = b"WAVE"
+    for cid, payload in chunks:
+        body += cid + struct.pack("<I", len(payload)) + payload + (b"\0" if len(payload) % 2 else b"")
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def test_wav_parse_walks_chunks_like_the_reference():
+    x = (np.arange(10) * 1000 - 5000).astype(np.int16)
+    w = make_wav(np.stack([x, -x], axis=1), 384000, 16, channels=2, extra_chunks=[(b"guan", b"GUANO|Version:1.0\n")])
+    info = sa.wav_info(w)
+    assert info["sample_rate"] == 384000 and info["channels"] == 2 and info["bits_per_sample"] == 16
+    assert info["frames"] == 10 and info["format_tag"] == 1 and info["data_bytes"] == 40
+    assert w[info["data_offset"]:info["data_offset"] + 4] == struct.pack("<hh", -5000, 5000)
+    assert w[info["guano_offset"]:info["guano_offset"] + info["guano_bytes"]] == b"GUANO|Version:1.0\n"
+    # a data chunk that claims more bytes than the file holds is clipped
+    cut = sa.wav_info(w[:-8])
+    assert cut["frames"] == 8
+    for bad in (b"", b"RIFF\0\0\0\0WAVX", w[:20]):
+        with pytest.raises(sa.SonoError):
+            sa.wav_info(bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,is_float", [(8, False), (16, False), (24, False), (32, False), (32, True)])
+def test_decode_wav_channel(bits, is_float):
+    rng = np.random.default_rng(bits)
+    n, ch = 5001, 3
+    if is_float:
+        a = rng.uniform(-1, 1, (n, ch)).astype(np.float32)
+        ref = a
+    elif bits == 8:
+        a = rng.integers(0, 256, (n, ch))
+        ref = ((a.astype(np.float32) - 128) / 128).astype(np.float32)
+    else:
+        lim = 1 << (bits - 1)
+        a = rng.integers(-lim, lim, (n, ch))
+        a[0, :] = [-lim, lim - 1, 0]
+        ref = (a.astype(np.float64) / lim).astype(np.float32)
+    w = make_wav(a, 500000, bits, channels=ch, is_float=is_float)
+    e = sa.SpectrogramEngine(256, "hann")
+    for c in range(ch):
+        got, info = sa.decode_wav(e, w, c)
+        assert info["frames"] == n and got.dtype == np.float32 and np.array_equal(got, ref[:, c])
+    with pytest.raises(sa.SonoError):
+        sa.decode_wav(e, w, ch)
+    e.free()
+
+
+@pytest.mark.gpu
+def test_wav_to_u8_frames_equals_float_input():
+    # int16 WAV -> decode -> compute_spectrogram_u8 equals feeding the same samples as floats
+    rng = np.random.default_rng(1)
+    t = np.arange(6000)
+    x16 = np.round(8000 * np.sin(0.3 * t + 2e-5 * t * t) + 20 * rng.standard_normal(t.size)).astype(np.int16)
+    w = make_wav(x16, 384000, 16)
+    e = sa.SpectrogramEngine(512, "hann")
+    x, info = sa.decode_wav(e, w)
+    assert np.array_equal(x, x16.astype(np.float32) / 32768)
+    assert np.array_equal(e.compute_spectrogram_u8(x, 256, 20.0, 80.0),
+                          e.compute_spectrogram_u8(x16.astype(np.float32) / 32768, 256, 20.0, 80.0))
+    e.free()
