@@ -19,17 +19,26 @@ inline std::vector<float2> make_twiddles(unsigned int len, unsigned int count)
     return t;
 }
 
-// Inter-pass twiddles of the tiled kernel for N = 32*R1: row k1-1 (k1 = 1..R1/2)
-// holds W_N^(n2*k1) for n2 in [0, 32).
+// Inter-pass twiddles of the tiled kernel for N = R1*R2 (R2 = 32 up to N = 1024,
+// 64 above): one row of R2 entries W_N^(n2*k1) per k1.  R1 < 64: rows k1 = 1..R1/2.
+// R1 = 64: rows k1 = 1..R1/4, then one row with k1 = R1/2 (the kernel derives the
+// rows in between from these).
 inline std::vector<float2> make_tile_twiddles(unsigned int N)
 {
-    const unsigned int half = N / 64;
-    std::vector<float2> t((size_t)half * 32);
-    for (unsigned int k1 = 1; k1 <= half; ++k1)
-        for (unsigned int n2 = 0; n2 < 32; ++n2) {
-            const double a = -2.0 * 3.14159265358979323846 * (double)(k1 * n2) / (double)N;
-            t[(size_t)(k1 - 1) * 32 + n2].x = (float)std::cos(a);
-            t[(size_t)(k1 - 1) * 32 + n2].y = (float)std::sin(a);
+    const unsigned int r2 = N <= 1024 ? 32 : 64, r1 = N / r2, half = r1 / 2;
+    std::vector<unsigned int> ks;
+    if (r1 == 64) {
+        for (unsigned int k1 = 1; k1 <= half / 2; ++k1) ks.push_back(k1);
+        ks.push_back(half);
+    } else {
+        for (unsigned int k1 = 1; k1 <= half; ++k1) ks.push_back(k1);
+    }
+    std::vector<float2> t(ks.size() * r2);
+    for (size_t r = 0; r < ks.size(); ++r)
+        for (unsigned int n2 = 0; n2 < r2; ++n2) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)(ks[r] * n2) / (double)N;
+            t[r * r2 + n2].x = (float)std::cos(a);
+            t[r * r2 + n2].y = (float)std::sin(a);
         }
     return t;
 }

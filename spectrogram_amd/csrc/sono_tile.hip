@@ -1,12 +1,14 @@
-// sono_tile.hip -- register-tiled fused STFT kernel for fft sizes 256/512/1024.
+// sono_tile.hip -- register-tiled fused STFT kernel for fft sizes 256 ... 4096.
 //
-// Persistent waves.  A workgroup is kWavesPerBlock independent waves, each owning
-// a private 8.25 KB LDS region that is first the pass-1 -> pass-2 exchange image
-// and then the bin-major power image; the only data shared inside a workgroup are
-// the read-only window and inter-pass twiddle tables, a row of zeros and the tile
-// counter.  One workgroup of twelve waves per CU, i.e. three waves per SIMD and
-// 168 VGPRs per lane: enough waves to keep the vector ALU issuing while others
-// sit in LDS or memory waits, without register spills.
+// Persistent waves.  A workgroup is a set of independent waves, each owning a
+// private LDS region that is first the pass-1 -> pass-2 exchange image and then
+// the bin-major power image; the only data shared inside a workgroup are the
+// read-only window and inter-pass twiddle tables, a row of zeros and the tile
+// counter.  One workgroup per CU.  N <= 1024 (32 values per lane and pass): twelve
+// waves, i.e. three per SIMD and 168 VGPRs per lane, 8.25 KB regions.  N >= 2048
+// (64 values per lane and pass): eight waves, two per SIMD and up to 256 VGPRs,
+// 16 KB regions.  Enough waves to keep the vector ALU issuing while others sit
+// in LDS or memory waits, without register spills.
 //
 // Tile walk: the tiles of a launch are cut into one contiguous range per XCD
 // (workgroups are dealt round-robin to the eight XCDs), and inside a range the
@@ -31,9 +33,18 @@ namespace {
 #ifndef SONO_WPS
 #define SONO_WPS 3
 #endif
-constexpr int kWavesPerBlock = SONO_WPB;
-constexpr int kWavesPerSimd = SONO_WPS;
-constexpr int kBlocksPerCU = 4 * kWavesPerSimd / kWavesPerBlock;
+#ifndef SONO_WIDE_WPB
+#define SONO_WIDE_WPB 8
+#endif
+#ifndef SONO_WIDE_WPS
+#define SONO_WIDE_WPS 2
+#endif
+template <int LOG_R2>
+struct Occupancy {
+    static constexpr int kWavesPerBlock = LOG_R2 == 5 ? SONO_WPB : SONO_WIDE_WPB;
+    static constexpr int kWavesPerSimd = LOG_R2 == 5 ? SONO_WPS : SONO_WIDE_WPS;
+    static constexpr int kBlocksPerCU = 4 * kWavesPerSimd / kWavesPerBlock;
+};
 constexpr int kXcds = 8;
 
 // Diagnostic build (-DSONO_EXP_STAMPS, tools/expbuild.sh): every wave sums the
@@ -60,8 +71,10 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_sched_barrier(0);      // and keeps one phase's arithmetic (and registers) out of the next
 }
 
-// Maximum over the 32 lanes of this lane's half of the wave, in every lane.
-__device__ __forceinline__ float half_wave_max(float v)
+// Maximum over the 32 lanes of this lane's half of the wave (R2 = 32) or over the
+// whole wave (R2 = 64), in every lane.
+template <int LOG_R2>
+__device__ __forceinline__ float column_max(float v)
 {
     v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xf, 0xf, true)));   // row_ror:8
     v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x124, 0xf, 0xf, true)));   // row_ror:4
@@ -69,33 +82,41 @@ __device__ __forceinline__ float half_wave_max(float v)
     v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x121, 0xf, 0xf, true)));   // row_ror:1
     // rows 0/1 and 2/3 trade places: every lane then holds both rows' maxima of its half
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    if constexpr (LOG_R2 == 6) {
+        // the two halves trade places
+        const auto w = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = fmaxf(__uint_as_float(w[0]), __uint_as_float(w[1]));
+    }
+    return v;
 }
 
-template <int LOG_R1, int MODE>
-__global__ __launch_bounds__(64 * kWavesPerBlock, kWavesPerSimd) void stft_tile_kernel(const StftArgs a,
-                                                                                      const tile::TileIter it,
-                                                                                      const float2 *tw_rows)
+template <int LOG_R1, int LOG_R2, int MODE>
+__global__ __launch_bounds__(64 * Occupancy<LOG_R2>::kWavesPerBlock, Occupancy<LOG_R2>::kWavesPerSimd)
+void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *tw_rows)
 {
-    using G = tile::Geo<LOG_R1>;
-    __shared__ __align__(16) float s_img[kWavesPerBlock * tile::kRegionFloats];
-    __shared__ __align__(16) float2 s_tw[G::TW_ROWS * 32];
+    using G = tile::Geo<LOG_R1, LOG_R2>;
+    constexpr int R2 = G::R2;
+    constexpr int kWavesPerBlock = Occupancy<LOG_R2>::kWavesPerBlock;
+    constexpr int kZeroFloats = G::ZERO_ROW ? G::BINS : 4;
+    __shared__ __align__(16) float s_img[kWavesPerBlock * G::REGION];
+    __shared__ __align__(16) float2 s_tw[G::TW_ROWS * R2];
     __shared__ __align__(16) float s_win[G::N];
     __shared__ unsigned long long s_peak[kWavesPerBlock * 16];
     __shared__ unsigned int s_next;
     __shared__ float s_meta[kWavesPerBlock * tile::kMetaFloats];
-    __shared__ __align__(16) float s_zero[G::BINS];
+    __shared__ __align__(16) float s_zero[kZeroFloats];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = threadIdx.x; i < G::TW_ROWS * 32; i += blockDim.x) s_tw[i] = tw_rows[i];
+    for (int i = threadIdx.x; i < G::TW_ROWS * R2; i += blockDim.x) s_tw[i] = tw_rows[i];
     for (int i = threadIdx.x; i < G::N; i += blockDim.x) s_win[i] = a.window[i];
     if (threadIdx.x < kWavesPerBlock * 16) s_peak[threadIdx.x] = peak_key(0.0f, 0u);
     if (threadIdx.x == 0) s_next = 0u;
-    for (int i = threadIdx.x; i < G::BINS; i += blockDim.x) s_zero[i] = 0.0f;
+    for (int i = threadIdx.x; i < kZeroFloats; i += blockDim.x) s_zero[i] = 0.0f;
     __syncthreads();
 
-    float *img = s_img + wave * tile::kRegionFloats;
+    float *img = s_img + wave * G::REGION;
     float *meta = s_meta + wave * tile::kMetaFloats;
     unsigned long long *peak_slot = s_peak + wave * 16 + (lane >> (LOG_R1 - 1));
 
@@ -111,7 +132,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kWavesPerSimd) void stft_tile_
     const unsigned int blocks_in_part = (gridDim.x - part + parts - 1) / parts;
     const unsigned long long t_first = it.n_tiles * part / parts;
     const unsigned long long t_count = it.n_tiles * (part + 1) / parts - t_first;
-    tile::TileLane<LOG_R1, MODE> L(a, lane);
+    tile::TileLane<LOG_R1, LOG_R2, MODE> L(a, lane);
     auto claim = [&]() -> unsigned long long {          // -> index of the claimed tile inside the range
         unsigned int c = 0;
         if (lane == 0) c = atomicAdd(&s_next, 1u);
@@ -129,14 +150,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kWavesPerSimd) void stft_tile_
     while (cur < t_count) {
         const unsigned long long t = t_first + cur;
         const unsigned long long nxt = claim();           // returns while this tile is being worked on
-        float re[32], im[32];
+        float re[R2], im[R2];
         {
-            float rr[32], ri[32];
+            float rr[R2], ri[R2];
             L.load(t, it);
             STAMP(0);
             float ma[G::JPL], mb[G::JPL];
             L.scan(ma, mb);
-            for (int jj = 0; jj < G::JPL; ++jj) { ma[jj] = half_wave_max(ma[jj]); mb[jj] = half_wave_max(mb[jj]); }
+            for (int jj = 0; jj < G::JPL; ++jj) { ma[jj] = column_max<LOG_R2>(ma[jj]); mb[jj] = column_max<LOG_R2>(mb[jj]); }
             L.pass1(s_win, s_tw, ma, mb, rr, ri, meta);
             __builtin_amdgcn_sched_barrier(0);
             STAMP(1);
@@ -183,10 +204,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, kWavesPerSimd) void stft_tile_
     }
 }
 
-template <int LOG_R1, int MODE>
+template <int LOG_R1, int LOG_R2, int MODE>
 hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, hipStream_t stream)
 {
-    using G = tile::Geo<LOG_R1>;
+    using G = tile::Geo<LOG_R1, LOG_R2>;
+    constexpr int kWavesPerBlock = Occupancy<LOG_R2>::kWavesPerBlock;
+    constexpr int kBlocksPerCU = Occupancy<LOG_R2>::kBlocksPerCU;
     tile::TileIter it;
     const unsigned long long tps = (a.frames_per_stream + G::FPW - 1) / G::FPW;
     it.tiles_per_stream = (unsigned int)tps;
@@ -200,7 +223,7 @@ hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, hipStream_t stre
     unsigned long long blocks = (it.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const unsigned long long resident = (unsigned long long)cus * kBlocksPerCU;
     if (blocks > resident) blocks = resident;
-    hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, MODE>), dim3((unsigned int)blocks), dim3(64 * kWavesPerBlock), 0,
+    hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE>), dim3((unsigned int)blocks), dim3(64 * kWavesPerBlock), 0,
                        stream, a, it, tw_rows);
     return hipGetLastError();
 }
@@ -209,9 +232,11 @@ template <int MODE>
 hipError_t launch_mode(const StftArgs &a, const float2 *tw_rows, hipStream_t stream)
 {
     switch (a.N) {
-    case 1024: return launch_one<5, MODE>(a, tw_rows, stream);
-    case 512: return launch_one<4, MODE>(a, tw_rows, stream);
-    case 256: return launch_one<3, MODE>(a, tw_rows, stream);
+    case 4096: return launch_one<6, 6, MODE>(a, tw_rows, stream);
+    case 2048: return launch_one<5, 6, MODE>(a, tw_rows, stream);
+    case 1024: return launch_one<5, 5, MODE>(a, tw_rows, stream);
+    case 512: return launch_one<4, 5, MODE>(a, tw_rows, stream);
+    case 256: return launch_one<3, 5, MODE>(a, tw_rows, stream);
     default: return hipErrorInvalidValue;
     }
 }
@@ -232,7 +257,7 @@ hipError_t tile_tables_build(unsigned int N, TileTables &t)
 {
     t.N = N;
     t.d_blob = nullptr;
-    if (N != 1024 && N != 512 && N != 256) return hipSuccess;
+    if (N != 4096 && N != 2048 && N != 1024 && N != 512 && N != 256) return hipSuccess;
     const std::vector<float2> rows = make_tile_twiddles(N);
     hipError_t e = hipMalloc(&t.d_blob, rows.size() * sizeof(float2));
     if (e != hipSuccess) { t.d_blob = nullptr; return e; }
@@ -244,9 +269,9 @@ void tile_tables_release(TileTables &t) { if (t.d_blob) (void)hipFree(t.d_blob);
 bool tile_supports(int mode, const StftArgs &a, const TileTables &t)
 {
     if (mode != MODE_MAG && mode != MODE_U8) return false;
-    if (a.N != 1024 && a.N != 512 && a.N != 256) return false;
+    if (a.N != 4096 && a.N != 2048 && a.N != 1024 && a.N != 512 && a.N != 256) return false;
     if (!t.d_blob || t.N != a.N) return false;
-    const unsigned long long tps = (a.frames_per_stream + 3) / 4;
+    const unsigned long long tps = (a.frames_per_stream + 1) / 2;
     if (tps >= 0xFFFFFFFFull) return false;
     if (mode == MODE_MAG && (reinterpret_cast<uintptr_t>(a.out_mag) & 15u)) return false;
     if (mode == MODE_U8 && (reinterpret_cast<uintptr_t>(a.out_u8) & 3u)) return false;

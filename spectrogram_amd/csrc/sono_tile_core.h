@@ -1,9 +1,10 @@
 // sono_tile_core.h -- per-lane arithmetic of the register-tiled STFT kernel.
 //
-// One wave64 transforms FPW = 128/R1 real frames of N = 32*R1 samples
-// (R1 = 32, 16, 8 for N = 1024, 512, 256), two frames ("a pair": A = 2q, B = 2q+1)
-// at a time, with a two-pass real-input FFT that never forms the redundant half
-// of the spectrum:
+// One wave64 transforms FPW = 128/R1 real frames of N = R1*R2 samples, two frames
+// ("a pair": A = 2q, B = 2q+1) at a time, with a two-pass real-input FFT that
+// never forms the redundant half of the spectrum.  R2 = 32 with R1 = 32, 16, 8
+// serves N = 1024, 512, 256; R2 = 64 with R1 = 32, 64 serves N = 2048, 4096.
+// Written out for R2 = 32:
 //
 //   X[k1 + R1*k2] = sum_{n2<32} W_32^(n2*k2) * W_N^(n2*k1) * Y[k1][n2],
 //   Y[k1][n2]     = sum_{n1<R1} xw[32*n1 + n2] * W_R1^(n1*k1)          (xw = x * window)
@@ -74,17 +75,19 @@ SONO_HD void static_for(F &&f)
     }
 }
 
-// ---- compile-time twiddles W_32^k = exp(-2*pi*i*k/32) ------------------------
-constexpr float kCos32[9] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f,
-                             0.70710678118654757f, 0.55557023301960229f, 0.38268343236508984f,
-                             0.19509032201612833f, 0.0f};
-constexpr float cos32(int k)
+// ---- compile-time twiddles W_64^k = exp(-2*pi*i*k/64) ------------------------
+constexpr float kCos64[17] = {1.0f, 0.99518472667219693f, 0.98078528040323043f, 0.95694033573220882f,
+                              0.92387953251128674f, 0.88192126434835505f, 0.83146961230254524f,
+                              0.77301045336273699f, 0.70710678118654757f, 0.63439328416364549f,
+                              0.55557023301960229f, 0.47139673682599764f, 0.38268343236508984f,
+                              0.29028467725446233f, 0.19509032201612833f, 0.098017140329560604f, 0.0f};
+constexpr float cos64(int k)
 {
-    k &= 31;
-    return k <= 8 ? kCos32[k] : k <= 16 ? -kCos32[16 - k] : k <= 24 ? -kCos32[k - 16] : kCos32[32 - k];
+    k &= 63;
+    return k <= 16 ? kCos64[k] : k <= 32 ? -kCos64[32 - k] : k <= 48 ? -kCos64[k - 32] : kCos64[64 - k];
 }
-constexpr float w32_re(int k) { return cos32(k); }
-constexpr float w32_im(int k) { return -cos32(k + 24); }   // -sin(2*pi*k/32)
+constexpr float w64_re(int k) { return cos64(k); }
+constexpr float w64_im(int k) { return -cos64(k + 48); }   // -sin(2*pi*k/64)
 
 constexpr int bitrev(int i, int bits)
 {
@@ -94,38 +97,38 @@ constexpr int bitrev(int i, int bits)
 }
 constexpr int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 
-// Decimation-in-time butterfly (a, b) -> (a + w b, a - w b), w = W_32^K32.
+// Decimation-in-time butterfly (a, b) -> (a + w b, a - w b), w = W_64^K64.
 // The second output is formed as 2a - (a + w b), which keeps a general butterfly
 // at six fused multiply-adds.
-template <int K32>
+template <int K64>
 SONO_HD void bfly(float &ar, float &ai, float &br, float &bi)
 {
-    if constexpr (K32 == 0) {
+    if constexpr (K64 == 0) {
         const float xr = ar + br, xi = ai + bi;
         br = ar - br; bi = ai - bi; ar = xr; ai = xi;
-    } else if constexpr (K32 == 8) {            // w = -i: w b = (b.im, -b.re)
+    } else if constexpr (K64 == 16) {           // w = -i: w b = (b.im, -b.re)
         const float xr = ar + bi, xi = ai - br;
         const float yr = ar - bi, yi = ai + br;
         ar = xr; ai = xi; br = yr; bi = yi;
-    } else if constexpr (K32 == 4) {            // w = (1 - i)/sqrt 2: w b = c (b.re + b.im, b.im - b.re)
+    } else if constexpr (K64 == 8) {            // w = (1 - i)/sqrt 2: w b = c (b.re + b.im, b.im - b.re)
         constexpr float c = 0.70710678118654757f;
         const float s1 = br + bi, s2 = bi - br;
         const float xr = ar + c * s1, xi = ai + c * s2;
         br = ar - c * s1; bi = ai - c * s2; ar = xr; ai = xi;
-    } else if constexpr (K32 == 12) {           // w = (-1 - i)/sqrt 2: w b = c (b.im - b.re, -(b.re + b.im))
+    } else if constexpr (K64 == 24) {           // w = (-1 - i)/sqrt 2: w b = c (b.im - b.re, -(b.re + b.im))
         constexpr float c = 0.70710678118654757f;
         const float s1 = bi - br, s2 = br + bi;
         const float xr = ar + c * s1, xi = ai - c * s2;
         br = ar - c * s1; bi = ai + c * s2; ar = xr; ai = xi;
     } else {
-        constexpr float wr = w32_re(K32), wi = w32_im(K32);
+        constexpr float wr = w64_re(K64), wi = w64_im(K64);
         const float xr = ar + (wr * br - wi * bi);
         const float xi = ai + (wr * bi + wi * br);
         br = 2.0f * ar - xr; bi = 2.0f * ai - xi; ar = xr; ai = xi;
     }
 }
 
-// In-place N-point DFT (N = 2..32).  Input in bit-reversed order
+// In-place N-point DFT (N = 2..64).  Input in bit-reversed order
 // (re[i] = x[bitrev(i)]), output in natural order.
 template <int N>
 SONO_HD void dft_bitrev_in(float (&re)[N], float (&im)[N])
@@ -137,36 +140,51 @@ SONO_HD void dft_bitrev_in(float (&re)[N], float (&im)[N])
             constexpr int base = decltype(b_)::value * len;
             static_for<0, half>([&](auto j_) {
                 constexpr int j = decltype(j_)::value;
-                bfly<j * (32 / len)>(re[base + j], im[base + j], re[base + j + half], im[base + j + half]);
+                bfly<j * (64 / len)>(re[base + j], im[base + j], re[base + j + half], im[base + j + half]);
             });
         });
     });
 }
 
 // ---- tile geometry -----------------------------------------------------------
-template <int LOG_R1>
+// N = R1 * R2: pass 1 transforms R1 register points per lane, pass 2 R2.  R2 = 32
+// serves N = 256..1024 (R1 = 8..32), R2 = 64 serves N = 2048 and 4096 (R1 = 32, 64).
+template <int LOG_R1, int LOG_R2>
 struct Geo {
     static constexpr int R1 = 1 << LOG_R1;     // pass-1 radix = image rows per frame pair
-    static constexpr int N = 32 * R1;          // real samples per frame
+    static constexpr int R2 = 1 << LOG_R2;     // pass-2 radix = image columns = values per lane in either pass
+    static constexpr int N = R1 * R2;          // real samples per frame
     static constexpr int BINS = N / 2;
     static constexpr int HALF = R1 / 2;        // the Nyquist row of pass 1; lanes per frame in the epilogue
     static constexpr int PPW = 64 / R1;        // frame pairs per wave
     static constexpr int FPW = 2 * PPW;        // frames per wave
-    static constexpr int JPL = 32 / R1;        // pass-1 jobs (pairs) per lane
-    static constexpr int PROW = BINS + HALF;   // floats per frame in the power image: the pad puts the frames
+    static constexpr int JPL = R2 / R1;        // pass-1 jobs (pairs) per lane
+    static constexpr int PAD = R1 < 64 ? HALF : 0;
+    static constexpr int PROW = BINS + PAD;    // floats per frame in the power image: the pad puts the frames
                                                // of one 32-lane store group on disjoint banks
-    static constexpr int TW_ROWS = HALF;       // twiddle rows k1 = 1..R1/2, 32 entries (n2) each
+    // Inter-pass twiddles W_N^(n2*k1), one row of R2 entries per k1.  Unfolded: rows
+    // k1 = 1..R1/2.  Folded (R1 = 64, where the full table would not fit beside
+    // eight wave regions): rows k1 = 1..R1/4, then one row of W_N^(n2*R1/2); the
+    // rows above R1/4 come from W^(n2*(R1/2-k)) = W^(n2*R1/2) * conj W^(n2*k).
+    static constexpr bool TW_FOLD = R1 == 64;
+    static constexpr int TW_ROWS = TW_FOLD ? HALF / 2 + 1 : HALF;
+    // A wave's LDS region is first the exchange image (64 rows of R2 floats), then
+    // the power image (FPW rows of PROW floats).
+    static constexpr int REGION = 64 * R2 > FPW * PROW ? 64 * R2 : FPW * PROW;
+    // An all-zero frame must give exact zeros.  R2 = 32: the epilogue reads such a
+    // frame from a row of zeros in LDS; R2 = 64: it multiplies by the frame's 0/1 flag.
+    static constexpr bool ZERO_ROW = R2 == 32;
 };
 
-// A wave's LDS region is first the exchange image, then the power image.
-//
-// Exchange image: 64 rows (one per pass-2 lane) of 32 floats, no padding.  Row L
-// keeps its eight 16-byte chunks in the order chunk ^ ((L >> 1) & 7): the
-// 16-lane groups in which ds_read_b128 is serviced then touch 16 disjoint
-// 4-bank sets when every lane reads the same chunk of its own row, and a
-// pass-1 store (32 lanes, one row, 32 columns) still covers 32 distinct banks.
-constexpr int kRegionFloats = 2112;                     // max(64*32, FPW*PROW) = 8 448 B per wave
-SONO_HD int image_index(int row, int col) { return row * 32 + (col ^ (((row >> 1) & 7) << 2)); }
+// Exchange image: row L (one per pass-2 lane) keeps its 16-byte chunks in the
+// order chunk ^ swizzle(L).  With 32-float rows swizzle = (L >> 1) & 7, with
+// 64-float rows L & 15: the 16-lane groups in which ds_read_b128 is serviced then
+// touch 16 disjoint 4-bank sets when every lane reads the same chunk of its own
+// row, and a pass-1 store (one row, consecutive columns) still covers distinct banks.
+template <int LOG_R2>
+SONO_HD constexpr int image_swizzle(int row) { return LOG_R2 == 5 ? ((row >> 1) & 7) << 2 : (row & 15) << 2; }
+template <int LOG_R2>
+SONO_HD constexpr int image_index(int row, int col) { return (row << LOG_R2) + (col ^ image_swizzle<LOG_R2>(row)); }
 
 // Per-wave, per-tile side information handed from pass 1 to the later passes
 // through LDS: [pair q] = g^2, the factor that undoes frame B's scaling in
@@ -192,15 +210,20 @@ struct TileIter {
 };
 
 // ---- one lane of one wave ------------------------------------------------------
-template <int LOG_R1, int MODE>
+template <int LOG_R1, int LOG_R2, int MODE>
 struct TileLane {
-    using G = Geo<LOG_R1>;
+    using G = Geo<LOG_R1, LOG_R2>;
+    static constexpr int R2 = G::R2;
     const StftArgs &a;
     int lane;
-    float xa[32], xb[32];              // samples of frames A / B of job jj at [jj*R1 + n1]
+    float xa[R2], xb[R2];              // samples of frames A / B of job jj at [jj*R1 + n1]
     float run_max;                     // running maximum of |2X|^2 over every frame this lane has finished (MODE_U8)
 
     SONO_HD TileLane(const StftArgs &args, int lane_) : a(args), lane(lane_), run_max(0.0f) {}
+
+    // Pass-1 lane layout: column n2 = lane % R2 of the pairs h*JPL .. h*JPL + JPL-1, h = lane / R2.
+    SONO_HD int col() const { return lane & (R2 - 1); }
+    SONO_HD int hgroup() const { return lane >> LOG_R2; }
 
     // Issues the loads of `tile` (pass-1 lane layout).  Frames past the end of a
     // stream re-read the stream's frame 0; their results are never stored.
@@ -208,7 +231,7 @@ struct TileLane {
     {
         const unsigned long long s = tile / it.tiles_per_stream;
         const unsigned int j = (unsigned int)(tile - s * it.tiles_per_stream);
-        const int h = lane >> 5, n2 = lane & 31;
+        const int h = hgroup(), n2 = col();
         const float *xs = a.x + s * a.stream_stride + n2;
         static_for<0, G::JPL>([&](auto jj_) {
             constexpr int jj = decltype(jj_)::value;
@@ -219,8 +242,8 @@ struct TileLane {
             const float *pa = xs + fa * a.hop, *pb = xs + fb * a.hop;
             static_for<0, G::R1>([&](auto n_) {
                 constexpr int n1 = decltype(n_)::value;
-                xa[jj * G::R1 + n1] = pa[32 * n1];
-                xb[jj * G::R1 + n1] = pb[32 * n1];
+                xa[jj * G::R1 + n1] = pa[R2 * n1];
+                xb[jj * G::R1 + n1] = pb[R2 * n1];
             });
         });
     }
@@ -243,14 +266,14 @@ struct TileLane {
 
     // Pass 1: scale B, window, DFT-R1 of A + iB, conjugate-symmetric separation,
     // unscale B, twiddle.  ma / mb = largest |sample| of frames A / B of each pair
-    // over all 32 columns.  Leaves the 32 row values of the lane (rows rho of its JPL
+    // over all R2 columns.  Leaves the R2 row values of the lane (rows rho of its JPL
     // pairs, column n2) in rr / ri at [jj*R1 + rho].  win = the N window values;
-    // tw = table [k1-1][n2] of W_N^(n2*k1), k1 = 1..R1/2.  The lane of column 0
+    // tw = the twiddle table described at Geo::TW_FOLD.  The lane of column 0
     // records the pair's side information in `meta`.
     SONO_HD void pass1(const float *win, const float2 *tw, const float (&ma)[G::JPL], const float (&mb)[G::JPL],
-                       float (&rr)[32], float (&ri)[32], float *meta) const
+                       float (&rr)[R2], float (&ri)[R2], float *meta) const
     {
-        const int h = lane >> 5, n2 = lane & 31;
+        const int h = hgroup(), n2 = col();
         static_for<0, G::JPL>([&](auto jj_) {
             constexpr int jj = decltype(jj_)::value;
             int d = (ma[jj] > 0.0f && mb[jj] > 0.0f) ? float_exponent(ma[jj]) - float_exponent(mb[jj]) : 0;
@@ -265,63 +288,78 @@ struct TileLane {
             float re[G::R1], im[G::R1];
             static_for<0, G::R1>([&](auto i_) {
                 constexpr int i = decltype(i_)::value, n1 = bitrev(i, LOG_R1);
-                const float w = win[32 * n1 + n2];
+                const float w = win[R2 * n1 + n2];
                 re[i] = xa[jj * G::R1 + n1] * w;
                 im[i] = (xb[jj * G::R1 + n1] * sb) * w;
             });
             dft_bitrev_in<G::R1>(re, im);
             rr[jj * G::R1] = re[0];
             ri[jj * G::R1] = im[0];
-            {
-                const float2 t = tw[(G::HALF - 1) * 32 + n2];
-                rr[jj * G::R1 + G::HALF] = re[G::HALF] * t.x - im[G::HALF] * t.y;
-                ri[jj * G::R1 + G::HALF] = re[G::HALF] * t.y + im[G::HALF] * t.x;
-            }
-            static_for<1, G::HALF>([&](auto k_) {
+            // rows k1 (frame A) and R1/2 + k1 (frame B), twiddled by t = W_N^(n2*k1)
+            auto rows = [&](auto k_, const float2 t) {
                 constexpr int k1 = decltype(k_)::value;
-                const float2 t = tw[(k1 - 1) * 32 + n2];
                 const float ar = re[k1] + re[G::R1 - k1], ai = im[k1] - im[G::R1 - k1];   // 2 Y_A[k1]
                 const float br = (im[k1] + im[G::R1 - k1]) * gb, bi = (re[G::R1 - k1] - re[k1]) * gb;   // 2 Y_B[k1]
                 rr[jj * G::R1 + k1] = ar * t.x - ai * t.y;
                 ri[jj * G::R1 + k1] = ar * t.y + ai * t.x;
                 rr[jj * G::R1 + G::HALF + k1] = br * t.x - bi * t.y;
                 ri[jj * G::R1 + G::HALF + k1] = br * t.y + bi * t.x;
-            });
+            };
+            float2 tn;                                                                       // W_N^(n2*R1/2)
+            if constexpr (G::TW_FOLD) {
+                constexpr int Q = G::HALF / 2;
+                tn = tw[Q * R2 + n2];
+                static_for<1, Q>([&](auto k_) {
+                    constexpr int k1 = decltype(k_)::value;
+                    const float2 t = tw[(k1 - 1) * R2 + n2];
+                    rows(k_, t);
+                    float2 u;
+                    u.x = tn.x * t.x + tn.y * t.y;
+                    u.y = tn.y * t.x - tn.x * t.y;
+                    rows(ic<G::HALF - k1>{}, u);
+                });
+                rows(ic<Q>{}, tw[(Q - 1) * R2 + n2]);
+            } else {
+                tn = tw[(G::HALF - 1) * R2 + n2];
+                static_for<1, G::HALF>([&](auto k_) { rows(k_, tw[(decltype(k_)::value - 1) * R2 + n2]); });
+            }
+            rr[jj * G::R1 + G::HALF] = re[G::HALF] * tn.x - im[G::HALF] * tn.y;
+            ri[jj * G::R1 + G::HALF] = re[G::HALF] * tn.y + im[G::HALF] * tn.x;
         });
     }
 
-    // One exchange round: every pass-1 lane stores one component of its 32 row
-    // values at column n2 (value i = jj*R1 + rho belongs to row 32*h + i) ...
-    SONO_HD void exchange_store(const float (&v)[32], float *img) const
+    // One exchange round: every pass-1 lane stores one component of its R2 row
+    // values at column n2 (value i = jj*R1 + rho belongs to row R2*h + i) ...
+    SONO_HD void exchange_store(const float (&v)[R2], float *img) const
     {
-        const int h = lane >> 5, n2 = lane & 31;
-        float *base = img + 1024 * h;
-        static_for<0, 32>([&](auto i_) {
+        const int h = hgroup(), n2 = col();
+        float *base = img + R2 * R2 * h;
+        static_for<0, R2>([&](auto i_) {
             constexpr int i = decltype(i_)::value;
-            base[32 * i + (n2 ^ (((i >> 1) & 7) << 2))] = v[i];       // = img[image_index(32*h + i, n2)]
+            base[R2 * i + (n2 ^ image_swizzle<LOG_R2>(i))] = v[i];    // = img[image_index(R2*h + i, n2)]
         });
     }
     // ... and every pass-2 lane reads its row, placing column n2 where the DFT wants it.
-    SONO_HD void exchange_load(const float *img, float (&v)[32]) const
+    SONO_HD void exchange_load(const float *img, float (&v)[R2]) const
     {
-        const float *row = img + 32 * lane;
-        const int f = ((lane >> 1) & 7) << 2;
-        static_for<0, 8>([&](auto j_) {
+        const float *row = img + R2 * lane;
+        const int f = image_swizzle<LOG_R2>(lane);
+        static_for<0, R2 / 4>([&](auto j_) {
             constexpr int j = decltype(j_)::value;
             const float4 q = *(const float4 *)(row + ((4 * j) ^ f));
-            v[bitrev(4 * j, 5)] = q.x; v[bitrev(4 * j + 1, 5)] = q.y;
-            v[bitrev(4 * j + 2, 5)] = q.z; v[bitrev(4 * j + 3, 5)] = q.w;
+            v[bitrev(4 * j, LOG_R2)] = q.x; v[bitrev(4 * j + 1, LOG_R2)] = q.y;
+            v[bitrev(4 * j + 2, LOG_R2)] = q.z; v[bitrev(4 * j + 3, LOG_R2)] = q.w;
         });
     }
 
-    // Pass 2 (after both exchange rounds): DFT-32 over n2, then |2X|^2 of the
-    // lane's 32 bins scattered into the bin-major power image P[frame][bin].
+    // Pass 2 (after both exchange rounds): DFT-R2 over n2, then |2X|^2 of the
+    // lane's R2 bins scattered into the bin-major power image P[frame][bin].
     //
     // A frame row (rho = k1 or R1/2 + k1) holds 2X[k1 + R1*t] in register t and
-    // conj 2X[(R1-k1) + R1*t] in register 31-t.  A shared row holds C = 2X_A' + i 2X_B'
+    // conj 2X[(R1-k1) + R1*t] in register R2-1-t.  A shared row holds C = 2X_A' + i 2X_B'
     // of both frames of the pair, where X' is conjugate-symmetric about register 0
     // (rho = 0: bins R1*t) or about register -1/2 (rho = R1/2: bins R1/2 + R1*t):
-    //   |2X_A|^2 = |C[t] + conj C[p]|^2,  |2X_B|^2 = |C[t] - conj C[p]|^2,  p = (32-t)%32 or 31-t.
+    //   |2X_A|^2 = |C[t] + conj C[p]|^2,  |2X_B|^2 = |C[t] - conj C[p]|^2,  p = (R2-t)%R2 or R2-1-t.
     // One instruction stream serves all three kinds: with b = conj C[p] and a
     // per-lane s (0 for frame rows, 1 for shared rows) the two stores are
     // |C[t] + s b|^2 and g2 |s C[t] - b|^2 (g2 undoes frame B's scaling in a shared
@@ -330,19 +368,19 @@ struct TileLane {
     {
         return (lane & (G::HALF - 1)) == 0 ? meta[lane >> LOG_R1] : 1.0f;
     }
-    SONO_HD void pass2_power(float (&re)[32], float (&im)[32], float g2, float *P) const
+    SONO_HD void pass2_power(float (&re)[R2], float (&im)[R2], float g2, float *P) const
     {
-        dft_bitrev_in<32>(re, im);
+        dft_bitrev_in<R2>(re, im);
         const int q = lane >> LOG_R1, rho = lane & (G::R1 - 1), k1 = rho & (G::HALF - 1);
         const bool shared = k1 == 0, row0 = rho == 0;
         const float s = shared ? 1.0f : 0.0f;
         const int frame = 2 * q + (rho >> (LOG_R1 - 1));
         float *row1 = P + (shared ? 2 * q * G::PROW + rho : frame * G::PROW + k1);
         float *row2 = P + (shared ? (2 * q + 1) * G::PROW + rho : frame * G::PROW + G::R1 - k1);
-        static_for<0, 16>([&](auto t_) {
+        static_for<0, R2 / 2>([&](auto t_) {
             constexpr int t = decltype(t_)::value;
-            const float br = row0 ? re[(32 - t) & 31] : re[31 - t];
-            const float bi = row0 ? im[(32 - t) & 31] : im[31 - t];
+            const float br = row0 ? re[(R2 - t) & (R2 - 1)] : re[R2 - 1 - t];
+            const float bi = row0 ? im[(R2 - t) & (R2 - 1)] : im[R2 - 1 - t];
             const float er = re[t] + s * br, ei = im[t] - s * bi;
             const float dr = s * re[t] - br, di = s * im[t] + bi;
             row1[G::R1 * t] = er * er + ei * ei;
@@ -350,9 +388,10 @@ struct TileLane {
         });
     }
 
-    // Epilogue: lane (frame, l) owns bins 4l + 2*R1*m + r (m < 8, r < 4) of its frame.
-    // zero_row = N/2 floats of 0.0, read in place of the power image for an all-zero frame.
-    // `peak_slot` is the LDS word of the lane's frame (ordering key of its largest |2X|^2).
+    // Epilogue: lane (frame, l) owns bins 4l + 2*R1*m + r (m < R2/4, r < 4) of its frame.
+    // zero_row = N/2 floats of 0.0, read in place of the power image for an all-zero
+    // frame (only where Geo::ZERO_ROW).  `peak_slot` is the LDS word of the lane's
+    // frame (ordering key of its largest |2X|^2).
     template <typename AtomicMax64>
     SONO_HD void epilogue(unsigned long long tile, const TileIter &it, const float *P, const float *meta,
                           const float *zero_row, unsigned long long *peak_slot, AtomicMax64 atomic_max64)
@@ -363,14 +402,16 @@ struct TileLane {
         const unsigned long long f = (unsigned long long)j * G::FPW + (unsigned int)frame;
         const bool valid = f < a.frames_per_stream;
         const unsigned long long g = s * a.frames_per_stream + f;
-        const float *row = (meta[kMetaNonZero + frame] != 0.0f ? P + frame * G::PROW : zero_row) + 4 * l;
+        const float nz = meta[kMetaNonZero + frame];
+        const float *row = ((!G::ZERO_ROW || nz != 0.0f) ? P + frame * G::PROW : zero_row) + 4 * l;
         float best_p = 0.0f;
         unsigned int best_k = 0;
         SONO_EPILOGUE_UNROLL
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < R2 / 4; ++m) {
             const int k0 = 4 * l + 2 * G::R1 * m;
             const float4 p4 = *(const float4 *)(row + 2 * G::R1 * m);
-            const float p[4] = {p4.x, p4.y, p4.z, p4.w};
+            float p[4] = {p4.x, p4.y, p4.z, p4.w};
+            if (!G::ZERO_ROW) { p[0] *= nz; p[1] *= nz; p[2] *= nz; p[3] *= nz; }
             if (MODE == MODE_MAG) {
                 if (valid) {
                     float4 o;

@@ -10,32 +10,33 @@
 
 using namespace sono;
 
-template <int LOG_R1, int MODE>
+template <int LOG_R1, int LOG_R2, int MODE>
 static void run_tiles(const StftArgs &a)
 {
-    using G = tile::Geo<LOG_R1>;
+    using G = tile::Geo<LOG_R1, LOG_R2>;
+    constexpr int R2 = G::R2, HW = 64 / R2;      // HW = groups of R2 lanes that share a pass-1 maximum
     tile::TileIter it;
     const unsigned long long tps = (a.frames_per_stream + G::FPW - 1) / G::FPW;
     it.tiles_per_stream = (unsigned int)tps;
     it.n_tiles = a.n_streams * tps;
     const std::vector<float2> tw = make_tile_twiddles(a.N);
-    alignas(16) static float img[tile::kRegionFloats];
+    alignas(16) static float img[G::REGION];
     unsigned long long peak[16];
     for (auto &p : peak) p = peak_key(0.0f, 0u);
     auto max64 = [](unsigned long long *p, unsigned long long v) { if (v > *p) *p = v; };
-    std::vector<tile::TileLane<LOG_R1, MODE>> lanes;
+    std::vector<tile::TileLane<LOG_R1, LOG_R2, MODE>> lanes;
     for (int l = 0; l < 64; ++l) lanes.emplace_back(a, l);
-    static float rr[64][32], ri[64][32], re[64][32], im[64][32], ma[64][G::JPL], mb[64][G::JPL], g2[64];
+    static float rr[64][R2], ri[64][R2], re[64][R2], im[64][R2], ma[64][G::JPL], mb[64][G::JPL], g2[64];
     float meta[tile::kMetaFloats];
     const std::vector<float> zero_row(G::BINS, 0.0f);
     for (unsigned long long t = 0; t < it.n_tiles; ++t) {
         for (int l = 0; l < 64; ++l) lanes[l].load(t, it);
         for (int l = 0; l < 64; ++l) lanes[l].scan(ma[l], mb[l]);
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < HW; ++h)
             for (int jj = 0; jj < G::JPL; ++jj) {
                 float va = 0.0f, vb = 0.0f;
-                for (int l = 32 * h; l < 32 * h + 32; ++l) { va = std::fmax(va, ma[l][jj]); vb = std::fmax(vb, mb[l][jj]); }
-                for (int l = 32 * h; l < 32 * h + 32; ++l) { ma[l][jj] = va; mb[l][jj] = vb; }
+                for (int l = R2 * h; l < R2 * h + R2; ++l) { va = std::fmax(va, ma[l][jj]); vb = std::fmax(vb, mb[l][jj]); }
+                for (int l = R2 * h; l < R2 * h + R2; ++l) { ma[l][jj] = va; mb[l][jj] = vb; }
             }
         for (int l = 0; l < 64; ++l) lanes[l].pass1(a.window, tw.data(), ma[l], mb[l], rr[l], ri[l], meta);
         for (int l = 0; l < 64; ++l) lanes[l].exchange_store(rr[l], img);
@@ -64,7 +65,7 @@ extern "C" int emul_tile(int mode, const float *x, unsigned long long n_streams,
                          float *peak_mag, unsigned int *gmax_bits, float *out_power)
 {
     (void)out_power;
-    if (N != 1024 && N != 512 && N != 256) return 1;
+    if (N != 4096 && N != 2048 && N != 1024 && N != 512 && N != 256) return 1;
     if (mode != MODE_MAG && mode != MODE_U8) return 1;
     StftArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -75,8 +76,8 @@ extern "C" int emul_tile(int mode, const float *x, unsigned long long n_streams,
     a.inv_n = 1.0f / (float)N;
     const Quant q = make_quant(N, gain_db, range_db);
     a.q_a = q.a; a.q_c = q.c; a.q_floor = q.floor;
-#define RUN(L) do { if (mode == MODE_MAG) run_tiles<L, MODE_MAG>(a); else run_tiles<L, MODE_U8>(a); } while (0)
-    if (N == 1024) RUN(5); else if (N == 512) RUN(4); else RUN(3);
+#define RUN(L1, L2) do { if (mode == MODE_MAG) run_tiles<L1, L2, MODE_MAG>(a); else run_tiles<L1, L2, MODE_U8>(a); } while (0)
+    if (N == 4096) RUN(6, 6); else if (N == 2048) RUN(5, 6); else if (N == 1024) RUN(5, 5); else if (N == 512) RUN(4, 5); else RUN(3, 5);
 #undef RUN
     return 0;
 }

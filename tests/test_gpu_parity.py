@@ -259,3 +259,80 @@ def test_time_chunks_of_the_sharding_layer_equal_one_call(kernel_path):
     assert np.array_equal(np.concatenate(parts), whole) and gm == gwhole
     assert np.array_equal(np.concatenate(pks), pk)
     e.free()
+
+
+TILED = [(256, 192), (512, 256), (1024, 768), (2048, 1536), (4096, 3891)]
+
+
+@pytest.mark.parametrize("N,V", TILED)
+def test_quiet_frames_next_to_loud_ones(N, V):
+    # frames are transformed two at a time: a loud frame must not leak rounding noise into its quiet partner
+    H = N - V
+    rng = np.random.default_rng(3)
+    n = N + 45 * H
+    x = (1e-5 * rng.standard_normal(n)).astype(np.float32)
+    t = np.arange(n)
+    burst = (t > 9 * H) & (t < 9 * H + N // 2)
+    x[burst] += (0.8 * np.sin(0.7 * t[burst])).astype(np.float32)
+    o = so.OracleEngine(N, "hann")
+    e = sa.SpectrogramEngine(N, "hann")
+    parity.check_mag(e.compute_spectrogram(x, V), o.compute_spectrogram(x, V), N // 2, f"quiet/loud N={N}")
+    nd, nt = parity.u8_diff(e.compute_spectrogram_u8(x, V, 20.0, 80.0), o.compute_spectrogram_u8(x, V, 20.0, 80.0))
+    assert nd <= max(2, parity.U8_MAX_FRACTION * nt)
+    assert np.array_equal(e.get_peaks(0.0), o.get_peaks(0.0))
+    e.free()
+
+
+@pytest.mark.parametrize("N,V", TILED)
+def test_all_zero_frames_stay_exactly_zero(N, V):
+    H, B = N - V, N // 2
+    x = np.zeros(N + 25 * H, np.float32)
+    x[N + 2 * H:] = signal(len(x) - (N + 2 * H), 9)          # frames 0..2 see only zeros
+    o = so.OracleEngine(N, "hann")
+    e = sa.SpectrogramEngine(N, "hann")
+    mag = e.compute_spectrogram(x, V)
+    assert not mag[: 3 * B].any()
+    parity.check_mag(mag, o.compute_spectrogram(x, V), B, "zero frames")
+    u8 = e.compute_spectrogram_u8(x, V, 20.0, 80.0)
+    assert np.array_equal(u8[: 3 * B], o.compute_spectrogram_u8(x, V, 20.0, 80.0)[: 3 * B])
+    assert np.array_equal(e.get_peaks(0.0), o.get_peaks(0.0))
+    assert not e.get_peak_magnitudes(0.0)[:3].any()
+    e.free()
+
+
+@pytest.mark.parametrize("N,V", TILED)
+def test_batch_streams_with_partial_tiles(N, V):
+    # stream lengths that leave the last tile of every stream partly empty, whatever the frames-per-wave count
+    import torch
+    H, B, S = N - V, N // 2, 3
+    F = 19                                                     # odd, and not a multiple of 4, 8 or 16
+    per = N + (F - 1) * H + 1
+    stride = per + 37
+    buf = np.zeros(S * stride, np.float32)
+    for s in range(S):
+        buf[s * stride: s * stride + per] = signal(per, 300 + s)
+    dx = torch.from_numpy(buf).cuda()
+    e = sa.SpectrogramEngine(N, "hann")
+    o = so.OracleEngine(N, "hann")
+    assert sa.frames_for(per, N, V) == F
+    out = torch.full((S * F * B + 64,), 7, dtype=torch.uint8, device="cuda")      # 64 guard bytes behind the rows
+    mag = torch.zeros(S * F * B, dtype=torch.float32, device="cuda")
+    pb = torch.zeros(S * F, dtype=torch.int16, device="cuda")
+    pm = torch.zeros(S * F, dtype=torch.float32, device="cuda")
+    gm = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    e.stft_u8_dev(dx.data_ptr(), S, stride, per, V, 20.0, 80.0, out.data_ptr(), pb.data_ptr(), pm.data_ptr(),
+                  gm.data_ptr(), 0)
+    e.stft_mag_f32_dev(dx.data_ptr(), S, stride, per, V, mag.data_ptr(), 0)
+    torch.cuda.synchronize()
+    out, mag = out.cpu().numpy(), mag.cpu().numpy().reshape(S, -1)
+    assert (out[S * F * B:] == 7).all()                        # nothing written past the last row
+    out = out[: S * F * B].reshape(S, -1)
+    pb = pb.cpu().numpy().view(np.uint16).reshape(S, F)
+    for s in range(S):
+        xs = buf[s * stride: s * stride + per]
+        parity.check_mag(mag[s], o.compute_spectrogram(xs, V), B, f"stream {s}")
+        nd, nt = parity.u8_diff(out[s], o.compute_spectrogram_u8(xs, V, 20.0, 80.0))
+        assert nd <= max(2, parity.U8_MAX_FRACTION * nt)
+        assert np.array_equal(pb[s], o.get_peaks(0.0))
+    e.free()

@@ -107,7 +107,8 @@ def test_generic_block_power_mode(emul):
     parity.check_power(db.astype(np.float32), so.compute_power_spectrum(x, 384000, N, "hann", 75.0), "emul power")
 
 
-@pytest.mark.parametrize("N,V", [(1024, 768), (1024, 512), (1024, 992), (1024, 0), (1024, 1022), (512, 256), (512, 384), (256, 128), (256, 192), (256, 64)])
+@pytest.mark.parametrize("N,V", [(1024, 768), (1024, 512), (1024, 992), (1024, 0), (1024, 1022), (512, 256), (512, 384), (256, 128), (256, 192), (256, 64),
+                                 (2048, 1536), (2048, 0), (2048, 2000), (4096, 3891), (4096, 2048), (4096, 0)])
 def test_tile_wave_matches_oracle(emul, N, V):
     H = N - V
     x = signal(N + 10 * H + (H - 1 if H > 1 else 0), N + 1)
@@ -142,7 +143,7 @@ def test_tile_wave_batch_with_partial_tiles(emul):
     parity.check_mag(mag, np.concatenate(refs), 512, "tile batch")
 
 
-@pytest.mark.parametrize("N,V", [(1024, 768), (512, 256), (256, 192)])
+@pytest.mark.parametrize("N,V", [(1024, 768), (512, 256), (256, 192), (2048, 1536), (4096, 3891)])
 def test_tile_wave_quiet_frames_next_to_loud_ones(emul, N, V):
     # frames are transformed in pairs: a loud frame must not leak rounding noise into its quiet partner
     H = N - V
@@ -161,17 +162,18 @@ def test_tile_wave_quiet_frames_next_to_loud_ones(emul, N, V):
     assert np.array_equal(r["peak_bin"], e.get_peaks(0.0))
 
 
-def test_tile_wave_all_zero_frames_stay_exactly_zero(emul):
-    N, V = 1024, 768
+@pytest.mark.parametrize("N,V", [(1024, 768), (2048, 1536), (4096, 3072)])
+def test_tile_wave_all_zero_frames_stay_exactly_zero(emul, N, V):
     H = N - V
     x = np.zeros(N + 15 * H, np.float32)
     x[N + 2 * H:] = signal(len(x) - (N + 2 * H), 9)          # frames 0..2 see only zeros
     e = so.OracleEngine(N, "hann")
     r = run_emul(emul, "emul_tile", 0, x, N, V, e.window)
     ref = e.compute_spectrogram(x, V)
-    assert not r["mag"][: 3 * 512].any() and not ref[: 3 * 512].any()
-    parity.check_mag(r["mag"], ref, 512, "zero frames")
+    B = N // 2
+    assert not r["mag"][: 3 * B].any() and not ref[: 3 * B].any()
+    parity.check_mag(r["mag"], ref, B, "zero frames")
     r = run_emul(emul, "emul_tile", 1, x, N, V, e.window)
-    assert np.array_equal(r["u8"][: 3 * 512], e.compute_spectrogram_u8(x, V, 20.0, 80.0)[: 3 * 512])
+    assert np.array_equal(r["u8"][: 3 * B], e.compute_spectrogram_u8(x, V, 20.0, 80.0)[: 3 * B])
     assert np.array_equal(r["peak_bin"], e.get_peaks(0.0))
     assert not r["peak_mag"][:3].any()
