@@ -94,11 +94,33 @@ SONO_HD float fast_log2(float p) { return std::log2(p); }
 SONO_HD float fast_sqrt(float p) { return std::sqrt(p); }
 #endif
 
+// Larger of two values that are +0, positive or NaN (p = |2X|^2 and the floor
+// are): their bit patterns order like the values, and an integer maximum needs
+// no NaN-quieting instruction in front of it.  A NaN wins.
+SONO_HD float max_nonneg(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned int ua = __float_as_uint(a), ub = __float_as_uint(b);
+    return __uint_as_float(ua > ub ? ua : ub);
+#else
+    unsigned int ua, ub;
+    std::memcpy(&ua, &a, 4);
+    std::memcpy(&ub, &b, 4);
+    return ua > ub ? a : b;
+#endif
+}
+
+// Largest of four such values.
+SONO_HD float max_of_4(float a, float b, float c, float d)
+{
+    return max_nonneg(max_nonneg(a, b), max_nonneg(c, d));
+}
+
 // u8 code of one bin from p = |2X|^2.  Float -> int conversion truncates toward
 // zero like Rust's `as u8`; the clamps make the saturation explicit.
 SONO_HD unsigned int quantise(float p, float q_a, float q_c, float q_floor)
 {
-    const float pf = p > q_floor ? p : q_floor;
+    const float pf = max_nonneg(p, q_floor);
     float v = q_a * fast_log2(pf) + q_c;
 #if defined(__HIP_DEVICE_COMPILE__)
     v = __builtin_amdgcn_fmed3f(v, 0.0f, 255.0f);   // one v_med3_f32; a NaN comes out as 0

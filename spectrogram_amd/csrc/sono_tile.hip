@@ -47,6 +47,12 @@ struct Occupancy {
 };
 constexpr int kXcds = 8;
 
+// Values per lane and pass (log2) of the geometry that serves fft size N.
+#ifndef SONO_WIDE_FROM
+#define SONO_WIDE_FROM 2048
+#endif
+constexpr int tile_log_r2(unsigned int N) { return N >= SONO_WIDE_FROM ? 6 : 5; }
+
 // Diagnostic build (-DSONO_EXP_STAMPS, tools/expbuild.sh): every wave sums the
 // shader-clock cycles it spends in each phase; tools/kbench prints the totals.
 #ifdef SONO_EXP_STAMPS
@@ -234,8 +240,8 @@ hipError_t launch_mode(const StftArgs &a, const float2 *tw_rows, hipStream_t str
     switch (a.N) {
     case 4096: return launch_one<6, 6, MODE>(a, tw_rows, stream);
     case 2048: return launch_one<5, 6, MODE>(a, tw_rows, stream);
-    case 1024: return launch_one<5, 5, MODE>(a, tw_rows, stream);
-    case 512: return launch_one<4, 5, MODE>(a, tw_rows, stream);
+    case 1024: return launch_one<10 - tile_log_r2(1024), tile_log_r2(1024), MODE>(a, tw_rows, stream);
+    case 512: return launch_one<9 - tile_log_r2(512), tile_log_r2(512), MODE>(a, tw_rows, stream);
     case 256: return launch_one<3, 5, MODE>(a, tw_rows, stream);
     default: return hipErrorInvalidValue;
     }
@@ -258,7 +264,7 @@ hipError_t tile_tables_build(unsigned int N, TileTables &t)
     t.N = N;
     t.d_blob = nullptr;
     if (N != 4096 && N != 2048 && N != 1024 && N != 512 && N != 256) return hipSuccess;
-    const std::vector<float2> rows = make_tile_twiddles(N);
+    const std::vector<float2> rows = make_tile_twiddles(N, 1u << (N == 256 ? 5 : tile_log_r2(N)));
     hipError_t e = hipMalloc(&t.d_blob, rows.size() * sizeof(float2));
     if (e != hipSuccess) { t.d_blob = nullptr; return e; }
     return hipMemcpy(t.d_blob, rows.data(), rows.size() * sizeof(float2), hipMemcpyHostToDevice);

@@ -51,6 +51,15 @@
 #ifndef SONO_EPI_UNROLL
 #define SONO_EPI_UNROLL 1
 #endif
+#ifndef SONO_EPI_BATCH
+#define SONO_EPI_BATCH 8          // epilogue reads in flight per lane, fft 1024
+#endif
+#ifndef SONO_EPI_BATCH_512
+#define SONO_EPI_BATCH_512 4      // the same, fft 512 and 256
+#endif
+#ifndef SONO_EPI_BATCH_WIDE
+#define SONO_EPI_BATCH_WIDE 8     // the same, 64-column geometry (fft 2048, 4096)
+#endif
 #define SONO_PRAGMA_(x) _Pragma(#x)
 #define SONO_PRAGMA(x) SONO_PRAGMA_(x)
 #if defined(__clang__)
@@ -404,32 +413,52 @@ struct TileLane {
         const unsigned long long g = s * a.frames_per_stream + f;
         const float nz = meta[kMetaNonZero + frame];
         const float *row = ((!G::ZERO_ROW || nz != 0.0f) ? P + frame * G::PROW : zero_row) + 4 * l;
+        // Peak search: per group of four bins only the group's maximum is compared
+        // with the running one (strict >, so the lowest group wins a tie); which of
+        // the four it was is settled once, after the loop.
         float best_p = 0.0f;
-        unsigned int best_k = 0;
+        int best_m = 0;
+        // The reads of a batch are issued together: the LDS serves every wave of the
+        // workgroup from one queue, and a read that is waited for on its own sits
+        // behind whatever bursts the other waves have queued.
+        constexpr int NB = R2 / 4, B = LOG_R2 == 6 ? SONO_EPI_BATCH_WIDE : LOG_R1 == 5 ? SONO_EPI_BATCH : SONO_EPI_BATCH_512;
+        static_assert(NB % B == 0, "the epilogue batch must divide the reads per lane");
+        if (!valid) return;          // lanes of frames past the end of the stream have nothing to store
         SONO_EPILOGUE_UNROLL
-        for (int m = 0; m < R2 / 4; ++m) {
-            const int k0 = 4 * l + 2 * G::R1 * m;
-            const float4 p4 = *(const float4 *)(row + 2 * G::R1 * m);
-            float p[4] = {p4.x, p4.y, p4.z, p4.w};
-            if (!G::ZERO_ROW) { p[0] *= nz; p[1] *= nz; p[2] *= nz; p[3] *= nz; }
-            if (MODE == MODE_MAG) {
-                if (valid) {
+        for (int m0 = 0; m0 < NB; m0 += B) {
+            float4 p4[B];
+            static_for<0, B>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                p4[i] = *(const float4 *)(row + 2 * G::R1 * (m0 + i));
+            });
+            static_for<0, B>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                const int k0 = 4 * l + 2 * G::R1 * (m0 + i);
+                float p[4] = {p4[i].x, p4[i].y, p4[i].z, p4[i].w};
+                if (!G::ZERO_ROW) { p[0] *= nz; p[1] *= nz; p[2] *= nz; p[3] *= nz; }
+                if (MODE == MODE_MAG) {
                     float4 o;
                     o.x = fast_sqrt(p[0]) * a.inv_n; o.y = fast_sqrt(p[1]) * a.inv_n;
                     o.z = fast_sqrt(p[2]) * a.inv_n; o.w = fast_sqrt(p[3]) * a.inv_n;
                     *(float4 *)(a.out_mag + g * (unsigned long long)G::BINS + k0) = o;
+                } else {
+                    unsigned int packed = 0;
+                    static_for<0, 4>([&](auto r_) {
+                        constexpr int r = decltype(r_)::value;
+                        packed |= quantise(p[r], a.q_a, a.q_c, a.q_floor) << (8 * r);
+                    });
+                    const float top = max_of_4(p[0], p[1], p[2], p[3]);
+                    if (top > best_p) { best_p = top; best_m = m0 + i; }        // false for a NaN
+                    *(unsigned int *)(a.out_u8 + g * (unsigned long long)G::BINS + k0) = packed;
                 }
-            } else {
-                unsigned int packed = 0;
-                static_for<0, 4>([&](auto r_) {
-                    constexpr int r = decltype(r_)::value;
-                    packed |= quantise(p[r], a.q_a, a.q_c, a.q_floor) << (8 * r);
-                    if (p[r] > best_p) { best_p = p[r]; best_k = (unsigned int)(k0 + r); }   // strict >: first wins
-                });
-                if (valid) *(unsigned int *)(a.out_u8 + g * (unsigned long long)G::BINS + k0) = packed;
-            }
+            });
         }
-        if (MODE == MODE_U8 && valid) {
+        if (MODE == MODE_U8) {
+            const float4 w4 = *(const float4 *)(row + 2 * G::R1 * best_m);
+            float w[4] = {w4.x, w4.y, w4.z, w4.w};
+            if (!G::ZERO_ROW) { w[0] *= nz; w[1] *= nz; w[2] *= nz; w[3] *= nz; }
+            const int r = w[0] == best_p ? 0 : w[1] == best_p ? 1 : w[2] == best_p ? 2 : 3;
+            const unsigned int best_k = best_p > 0.0f ? (unsigned int)(4 * l + 2 * G::R1 * best_m + r) : 0u;
             run_max = best_p > run_max ? best_p : run_max;
             atomic_max64(peak_slot, peak_key(best_p, best_k));
         }

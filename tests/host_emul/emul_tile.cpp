@@ -15,11 +15,12 @@ static void run_tiles(const StftArgs &a)
 {
     using G = tile::Geo<LOG_R1, LOG_R2>;
     constexpr int R2 = G::R2, HW = 64 / R2;      // HW = groups of R2 lanes that share a pass-1 maximum
+    if (a.N != (unsigned int)G::N) return;
     tile::TileIter it;
     const unsigned long long tps = (a.frames_per_stream + G::FPW - 1) / G::FPW;
     it.tiles_per_stream = (unsigned int)tps;
     it.n_tiles = a.n_streams * tps;
-    const std::vector<float2> tw = make_tile_twiddles(a.N);
+    const std::vector<float2> tw = make_tile_twiddles(a.N, R2);
     alignas(16) static float img[G::REGION];
     unsigned long long peak[16];
     for (auto &p : peak) p = peak_key(0.0f, 0u);
@@ -58,6 +59,9 @@ static void run_tiles(const StftArgs &a)
     }
 }
 
+static int g_log_r2 = 0;      // 0 = the geometry the kernel launcher picks for N
+extern "C" void emul_tile_set_log_r2(int v) { g_log_r2 = v; }
+
 extern "C" int emul_tile(int mode, const float *x, unsigned long long n_streams,
                          unsigned long long stream_stride, unsigned long long frames_per_stream,
                          unsigned int hop, unsigned int N, const float *window, float gain_db,
@@ -77,7 +81,9 @@ extern "C" int emul_tile(int mode, const float *x, unsigned long long n_streams,
     const Quant q = make_quant(N, gain_db, range_db);
     a.q_a = q.a; a.q_c = q.c; a.q_floor = q.floor;
 #define RUN(L1, L2) do { if (mode == MODE_MAG) run_tiles<L1, L2, MODE_MAG>(a); else run_tiles<L1, L2, MODE_U8>(a); } while (0)
-    if (N == 4096) RUN(6, 6); else if (N == 2048) RUN(5, 6); else if (N == 1024) RUN(5, 5); else if (N == 512) RUN(4, 5); else RUN(3, 5);
+    if (g_log_r2 == 6 && N == 1024) RUN(4, 6);
+    else if (g_log_r2 == 6 && N == 512) RUN(3, 6);
+    else if (N == 4096) RUN(6, 6); else if (N == 2048) RUN(5, 6); else if (N == 1024) RUN(5, 5); else if (N == 512) RUN(4, 5); else RUN(3, 5);
 #undef RUN
     return 0;
 }

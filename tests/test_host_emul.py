@@ -177,3 +177,23 @@ def test_tile_wave_all_zero_frames_stay_exactly_zero(emul, N, V):
     assert np.array_equal(r["u8"][: 3 * B], e.compute_spectrogram_u8(x, V, 20.0, 80.0)[: 3 * B])
     assert np.array_equal(r["peak_bin"], e.get_peaks(0.0))
     assert not r["peak_mag"][:3].any()
+
+
+@pytest.mark.parametrize("N,V", [(1024, 768), (1024, 1000), (512, 256)])
+def test_tile_wave_alternative_geometry(emul, N, V):
+    # N = 1024 / 512 through the 64-column geometry (R1 = 16 / 8): same results within the tolerances
+    H = N - V
+    x = signal(N + 21 * H + 3, N + 2)
+    x[: N + 2 * H] = 0.0
+    e = so.OracleEngine(N, "hann")
+    emul.emul_tile_set_log_r2(6)
+    try:
+        r = run_emul(emul, "emul_tile", 0, x, N, V, e.window)
+        parity.check_mag(r["mag"], e.compute_spectrogram(x, V), N // 2, f"wide tile mag N={N}")
+        assert not r["mag"][: 3 * (N // 2)].any()
+        r = run_emul(emul, "emul_tile", 1, x, N, V, e.window)
+        nd, nt = parity.u8_diff(r["u8"], e.compute_spectrogram_u8(x, V, 20.0, 80.0))
+        assert nd <= max(2, 1e-3 * nt)
+        assert np.array_equal(r["peak_bin"], e.get_peaks(0.0))
+    finally:
+        emul.emul_tile_set_log_r2(0)
