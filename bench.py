@@ -10,6 +10,12 @@ kernel launch), with the samples already resident in HBM.  With --gpus N every
 rank holds one such recording of its own (independent recordings, no data-path
 collective: weak scaling); only a per-rank summary row is gathered at the end.
 
+--workload selects another configuration of the same path (cfg3: a batch of 5 s
+500 kHz files spread over the ranks, strong scaling; cfg4: FFT 4096 Blackman 95 %
+overlap over 10 min; cfg5: survey pass over a long channel per rank -- per-frame
+peak features at 75 % overlap plus the detector's fast scan at 50 % overlap, no u8
+rows); those lines carry their own workload description and the same fields.
+
 Prints ONE JSON line on rank 0.  `roofline` prices the fused kernel against the
 HBM peak using the algorithmic bytes per frame (each sample read once, each
 output byte written once); `valu` prices the same launch against the fp32 vector
@@ -96,48 +102,105 @@ def measured_traffic():
     return None
 
 
+WORKLOADS = {
+    # name: fft, window, alpha, noverlap, sample rate
+    "cfg2": dict(fft=1024, window="hann", alpha=None, noverlap=768, sr=384000),
+    "cfg3": dict(fft=1024, window="hann", alpha=None, noverlap=768, sr=500000),
+    "cfg4": dict(fft=4096, window="blackman", alpha=0.16, noverlap=3891, sr=384000),
+    "cfg5": dict(fft=1024, window="hann", alpha=None, noverlap=768, sr=384000),
+}
+FILE_SAMPLES = 2500000          # cfg3: 5 s at 500 kHz
+SCAN_CHUNK_FRAMES = 1 << 19     # cfg5: frames of the fast scan whose magnitudes are in HBM at one time (1 GiB)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--seconds", type=int, default=SECONDS, help="length of the recording (default: 1 h)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
+    ap.add_argument("--seconds", type=int, default=None,
+                    help="length of the recording per GPU (default: 3600 for cfg2, 600 for cfg4, 43200 for cfg5)")
+    ap.add_argument("--files", type=int, default=10000, help="cfg3: number of files over all ranks")
     ap.add_argument("--cpu-seconds", type=float, default=600.0,
                     help="seconds of audio in the CPU baseline's sample, processed repeatedly for >= 10 s (0 disables it)")
     args = ap.parse_args()
 
     import torch
     import spectrogram_amd as sa
-    from spectrogram_amd import synth
+    from spectrogram_amd import sharding, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    # SONO_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    backend = os.environ.get("SONO_BENCH_BACKEND", "nccl")
+    device_index = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    torch.cuda.set_device(device_index if distributed else 0)
     if distributed:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
     dev = torch.cuda.current_device()
+    coll_device = "cuda" if backend == "nccl" else "cpu"
 
-    n = args.seconds * SAMPLE_RATE
-    frames = sa.frames_for(n, N_FFT, NOVERLAP)
-    bins = N_FFT // 2
-    x = synth.chirp_torch(0, n, SAMPLE_RATE, stream=rank, device="cuda")
-    out = torch.empty(frames * bins, dtype=torch.uint8, device="cuda")
+    w = WORKLOADS[args.workload]
+    n_fft, noverlap, sr = w["fft"], w["noverlap"], w["sr"]
+    hop, bins = n_fft - noverlap, n_fft // 2
+    if args.workload == "cfg3":
+        my_files = sharding.files_of_rank(args.files, rank, world)
+        n_streams, per = len(my_files), FILE_SAMPLES
+        seconds = per / sr
+    else:
+        seconds = args.seconds or {"cfg2": SECONDS, "cfg4": 600, "cfg5": 12 * 3600}[args.workload]
+        n_streams, per = 1, int(seconds * sr)
+    n = n_streams * per
+    frames_per_stream = sa.frames_for(per, n_fft, noverlap)
+    frames = n_streams * frames_per_stream
+    x = synth.chirp_torch(0, n, sr, stream=rank, device="cuda")          # cfg3: file i = samples [i*per, (i+1)*per)
+    engine = sa.SpectrogramEngine(n_fft, w["window"], w["alpha"], device=dev)
+    stream = torch.cuda.Stream()          # the stream every launch of the timed region goes to
     peak_bin = torch.empty(frames, dtype=torch.int16, device="cuda")
     peak_mag = torch.empty(frames, dtype=torch.float32, device="cuda")
     gmax = torch.zeros(1, dtype=torch.int32, device="cuda")
-    engine = sa.SpectrogramEngine(N_FFT, "hann", None, device=dev)
-    stream = torch.cuda.Stream()          # the stream every launch of the timed region goes to
+    features_only = args.workload == "cfg5"
+    bytes_per_frame = 4 * hop + (0 if features_only else bins) + 6
+    if not features_only:
+        out = torch.empty(frames * bins, dtype=torch.uint8, device="cuda")
+    else:
+        # the detector's fast scan (batCallDetector.js:878-949): 50 % overlap, band 10-120 kHz, threshold -60 dB
+        scan_v = n_fft // 2
+        scan_hop = n_fft - scan_v
+        scan_frames = sa.frames_for(per, n_fft, scan_v)
+        res = sr / n_fft
+        min_bin, max_bin = int(10000.0 // res), min(bins - 1, int(120000.0 // res))
+        target = (10.0 ** (-60.0 / 10.0)) * n_fft * 0.25
+        mags = torch.empty(min(scan_frames, SCAN_CHUNK_FRAMES) * bins, dtype=torch.float32, device="cuda")
+        active = torch.empty(scan_frames, dtype=torch.uint8, device="cuda")
+        run_first = torch.empty(scan_frames // 2 + 1, dtype=torch.int64, device="cuda")
+        run_last = torch.empty(scan_frames // 2 + 1, dtype=torch.int64, device="cuda")
+        run_count = torch.zeros(1, dtype=torch.int64, device="cuda")
 
     def step():
         with torch.cuda.stream(stream):
             gmax.zero_()
-        engine.stft_u8_dev(x.data_ptr(), 1, n, n, NOVERLAP, GAIN_DB, RANGE_DB, out.data_ptr(),
-                           peak_bin.data_ptr(), peak_mag.data_ptr(), gmax.data_ptr(), stream.cuda_stream)
+        if not features_only:
+            engine.stft_u8_dev(x.data_ptr(), n_streams, per, per, noverlap, GAIN_DB, RANGE_DB, out.data_ptr(),
+                               peak_bin.data_ptr(), peak_mag.data_ptr(), gmax.data_ptr(), stream.cuda_stream)
+            return
+        engine.stft_features_dev(x.data_ptr(), 1, per, per, noverlap, peak_bin.data_ptr(), peak_mag.data_ptr(),
+                                 gmax.data_ptr(), stream.cuda_stream)
+        for f0 in range(0, scan_frames, SCAN_CHUNK_FRAMES):
+            f1 = min(f0 + SCAN_CHUNK_FRAMES, scan_frames)
+            s0, s1 = sharding.chunk_samples((f0, f1), n_fft, scan_hop)
+            engine.stft_mag_f32_dev(x.data_ptr() + 4 * s0, 1, s1 - s0, s1 - s0, scan_v, mags.data_ptr(), stream.cuda_stream)
+            sa._check(sa.lib().sono_detect_band_active_dev(engine._handle(), mags.data_ptr(), f1 - f0, bins, min_bin, max_bin,
+                                                           target, active.data_ptr() + f0, None, stream.cuda_stream))
+        sa._check(sa.lib().sono_detect_runs_dev(engine._handle(), active.data_ptr(), scan_frames, run_first.data_ptr(),
+                                                run_last.data_ptr(), run_count.data_ptr(), stream.cuda_stream))
 
     def barrier():
         torch.cuda.synchronize()
@@ -158,26 +221,39 @@ def main():
     wall = time.perf_counter() - t0
     gpu_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream: the kernels' own time
 
-    tmax = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([wall], dtype=torch.float64, device=coll_device)
     if distributed:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall_max = float(tmax.item())
 
     # per-rank summary row, gathered with RCCL (the only collective of the path)
-    active = int((peak_mag > 0.4 * gmax.view(torch.float32)).sum().item())
-    row = torch.tensor([float(rank), float(frames), float(gmax.view(torch.float32).item()), float(active)],
-                       dtype=torch.float64, device="cuda")
+    gmax_f = float(gmax.view(torch.float32).item())
+    active_frames = int((peak_mag > 0.4 * gmax_f).sum().item())
+    extra = float(run_count.item()) if features_only else 0.0
+    row = torch.tensor([float(rank), float(frames), gmax_f, float(active_frames), extra], dtype=torch.float64,
+                       device=coll_device)
     rows = [row]
     if distributed:
         rows = [torch.empty_like(row) for _ in range(world)]
         dist.all_gather(rows, row)
 
     if rank == 0:
-        total_frames = frames * world
+        total_frames = int(sum(r[1].item() for r in rows))
         ms_per_step = wall_max * 1e3 / args.steps
         kernel_ms = gpu_ms / args.steps
-        achieved = frames * BYTES_PER_FRAME / (kernel_ms * 1e-3) / 1e9
-        tflops = frames * FLOPS_PER_FRAME / (kernel_ms * 1e-3) / 1e12
+        achieved = frames * bytes_per_frame / (kernel_ms * 1e-3) / 1e9
+        flops_per_frame = 5 * n_fft * (n_fft.bit_length() - 1) + n_fft + 16 * bins
+        tflops = frames * flops_per_frame / (kernel_ms * 1e-3) / 1e12
+        what = {
+            "cfg2": f"{seconds:g} s synthetic {sr} Hz mono FM-chirp recording per GPU, FFT {n_fft} Hann, 75% overlap (hop {hop}), "
+                    f"uint8 dB frames + per-frame peak bin/magnitude + global max, {frames} frames per GPU, samples resident in HBM",
+            "cfg3": f"{args.files} synthetic 5 s {sr} Hz files ({frames_per_stream} frames each) dealt round-robin to {world} GPU(s), "
+                    f"one launch per GPU over its files, FFT {n_fft} Hann, 75% overlap, uint8 dB frames + peaks",
+            "cfg4": f"{seconds:g} s synthetic {sr} Hz recording per GPU, FFT {n_fft} Blackman(0.16), 95% overlap (hop {hop}), "
+                    f"uint8 dB frames + peaks, {frames} frames per GPU",
+            "cfg5": f"{seconds / 3600:g} h synthetic {sr} Hz channel per GPU: per-frame peak features at FFT {n_fft} 75% overlap "
+                    f"({frames} frames, no u8 rows) + fast scan at 50% overlap (band energy, run extraction)",
+        }[args.workload]
         result = {
             "metric": "STFT frames/sec (audio-sec/sec) at FFT 1024, 75% overlap, 384 kHz; % HBM roofline",
             "value": total_frames * args.steps / wall_max,
@@ -187,35 +263,37 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.workload == "cfg3" else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "audio_s_per_s": total_frames * HOP / SAMPLE_RATE * args.steps / wall_max,
+            "audio_s_per_s": total_frames * hop / sr * args.steps / wall_max,
             "config": {
-                "workload": f"{args.seconds} s synthetic {SAMPLE_RATE} Hz mono FM-chirp recording per GPU, FFT {N_FFT} Hann, "
-                            f"75% overlap (hop {HOP}), uint8 dB frames + per-frame peak bin/magnitude + global max, "
-                            f"{frames} frames per GPU, samples resident in HBM",
-                "fft_size": N_FFT, "noverlap": NOVERLAP, "sample_rate": SAMPLE_RATE,
-                "frames_per_gpu": frames, "parallelism": f"{world} independent recording(s), one per GPU",
+                "workload": what, "name": args.workload,
+                "fft_size": n_fft, "noverlap": noverlap, "sample_rate": sr, "window": w["window"],
+                "frames_per_gpu": frames, "parallelism": f"{world} rank(s), independent units, no data-path collective",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel_ms": kernel_ms, "bytes_per_frame": BYTES_PER_FRAME,
-                "algorithmic_bytes": frames * BYTES_PER_FRAME,
+                "kernel_ms": kernel_ms, "bytes_per_frame": bytes_per_frame,
+                "algorithmic_bytes": frames * bytes_per_frame,
             },
             "valu": {"achieved": tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / VALU_PEAK_TFLOPS,
-                     "flops_per_frame": FLOPS_PER_FRAME},
+                     "flops_per_frame": flops_per_frame},
             "summary_rows": [[float(v) for v in r.tolist()] for r in rows],
         }
-        traffic = measured_traffic() if args.seconds == SECONDS else None
+        if features_only:
+            # the step is more than the one kernel the roofline prices: say so instead of a misleading fraction
+            result["roofline"]["note"] = ("kernel_ms covers the features pass AND the fast scan; bytes_per_frame counts "
+                                          "the features pass only")
+        traffic = measured_traffic() if args.workload == "cfg2" and seconds == SECONDS else None
         if traffic:
             result["roofline"]["traffic"] = traffic["hbm_bytes"]
             result["roofline"]["traffic_source"] = traffic["source"]
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and args.cpu_seconds > 0 and args.workload == "cfg2":
             threads = min(16, os.cpu_count() or 1)
-            n_cpu = int(min(args.cpu_seconds, args.seconds) * SAMPLE_RATE)
+            n_cpu = int(min(args.cpu_seconds, seconds) * sr)
             result["cpu_baseline"] = cpu_baseline(x[:n_cpu].cpu().numpy(), threads)
         print(json.dumps(result), flush=True)
 

@@ -148,6 +148,15 @@ int sono_stft_u8_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap,
                      uint8_t *d_out, uint16_t *d_peak_bin, float *d_peak_mag,
                      uint32_t *d_gmax_bits, void *hip_stream);
 
+/* The per-frame features of sono_stft_u8_dev without the u8 rows: peak bin
+ * (lib.rs:370-378: first maximum), peak magnitude and the running global maximum
+ * (lib.rs:261-266) of every frame of a batch.  For survey-scale passes (a whole
+ * night per channel) whose rows nobody looks at: batCallDetector only needs the
+ * per-frame peaks to decide where to look closer.  At least one output non-NULL. */
+int sono_stft_features_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap,
+                           uint16_t *d_peak_bin, float *d_peak_mag, uint32_t *d_gmax_bits,
+                           void *hip_stream);
+
 /* Linear-magnitude form of the same (lib.rs:113-161 over a batch). */
 int sono_stft_mag_f32_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap,
                           float *d_out, void *hip_stream);

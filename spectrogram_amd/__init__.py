@@ -96,6 +96,8 @@ _SIGNATURES = {
     "sono_stft_u8_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_float, C.c_float,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sono_stft_mag_f32_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_void_p, C.c_void_p]),
+    "sono_stft_features_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
     "sono_fast_scan_segments": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,
                                           _segp, C.c_size_t, _szp]),
     "sono_generate_spectrogram": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_double, C.c_double, C.c_double,
@@ -330,6 +332,13 @@ class SpectrogramEngine:
         _check(lib().sono_stft_u8_dev(self._handle(), C.byref(b), int(noverlap), float(gain_db), float(range_db),
                                       d_out, d_peak_bin or None, d_peak_mag or None, d_gmax_bits or None,
                                       stream or None))
+
+    def stft_features_dev(self, d_samples, n_streams, stream_stride, samples_per_stream, noverlap,
+                          d_peak_bin=0, d_peak_mag=0, d_gmax_bits=0, stream=0):
+        """stft_u8_dev without the u8 rows: per-frame peak bin / peak magnitude and the global maximum only."""
+        b = Batch(d_samples, n_streams, stream_stride, samples_per_stream)
+        _check(lib().sono_stft_features_dev(self._handle(), C.byref(b), int(noverlap), d_peak_bin or None,
+                                            d_peak_mag or None, d_gmax_bits or None, stream or None))
 
     def stft_mag_f32_dev(self, d_samples, n_streams, stream_stride, samples_per_stream, noverlap, d_out, stream=0):
         b = Batch(d_samples, n_streams, stream_stride, samples_per_stream)

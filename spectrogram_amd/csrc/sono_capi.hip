@@ -276,6 +276,25 @@ int sono_stft_u8_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap, fl
     return SONO_OK;
 }
 
+int sono_stft_features_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap, uint16_t *d_peak_bin,
+                           float *d_peak_mag, uint32_t *d_gmax_bits, void *hip_stream)
+{
+    int rc = check_batch(e, in, noverlap, "sono_stft_features_dev");
+    if (rc) return rc;
+    sono::StftArgs a;
+    fill_args(e, *in, noverlap, a);
+    if (a.n_streams * a.frames_per_stream == 0) return SONO_OK;
+    if (!d_peak_bin && !d_peak_mag && !d_gmax_bits)
+        return fail(SONO_EINVAL, "sono_stft_features_dev: every output is NULL");
+    const sono::Quant q = sono::make_quant(e->N, 20.0f, 80.0f);      // unused without rows; keeps the arithmetic defined
+    a.out_u8 = nullptr; a.peak_bin = d_peak_bin; a.peak_mag = d_peak_mag; a.gmax_bits = d_gmax_bits;
+    a.q_a = q.a; a.q_c = q.c; a.q_floor = q.floor;
+    DeviceGuard guard(e->device);
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    HIP_TRY(dispatch_stft(sono::MODE_U8, a, e->tables, s));
+    return SONO_OK;
+}
+
 int sono_stft_mag_f32(sono_engine *e, const float *x, size_t n, uint32_t noverlap, float *out,
                       size_t cap, size_t *frames)
 {

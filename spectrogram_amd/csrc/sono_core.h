@@ -42,7 +42,7 @@ struct StftArgs {
     const float2 *tw_half;        // W_{N/2}^k = exp(-2*pi*i*k/(N/2)), k in [0, N/2)
     const float2 *tw_full;        // W_N^k     = exp(-2*pi*i*k/N),     k in [0, N/2]
     float *out_mag;               // MODE_MAG
-    uint8_t *out_u8;              // MODE_U8
+    uint8_t *out_u8;              // MODE_U8; NULL = features only (no rows are written)
     uint16_t *peak_bin;           // MODE_U8, optional
     float *peak_mag;              // MODE_U8, optional
     unsigned int *gmax_bits;      // MODE_U8, optional: f32 bits, only ever raised
@@ -306,7 +306,7 @@ struct GenericBlock {
                         best = key > best ? key : best;
                     }
                 }
-                *(unsigned int *)(a.out_u8 + g * (unsigned long long)M + k0) = packed;
+                if (a.out_u8) *(unsigned int *)(a.out_u8 + g * (unsigned long long)M + k0) = packed;
                 atomic_max64(&sh.peak[fb], best);
             } else {
                 float *o = a.out_power + g * (unsigned long long)(M + 1) + k0;

@@ -449,7 +449,7 @@ struct TileLane {
                     });
                     const float top = max_of_4(p[0], p[1], p[2], p[3]);
                     if (top > best_p) { best_p = top; best_m = m0 + i; }        // false for a NaN
-                    *(unsigned int *)(a.out_u8 + g * (unsigned long long)G::BINS + k0) = packed;
+                    if (a.out_u8) *(unsigned int *)(a.out_u8 + g * (unsigned long long)G::BINS + k0) = packed;
                 }
             });
         }

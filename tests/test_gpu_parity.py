@@ -336,3 +336,33 @@ def test_batch_streams_with_partial_tiles(N, V):
         assert nd <= max(2, parity.U8_MAX_FRACTION * nt)
         assert np.array_equal(pb[s], o.get_peaks(0.0))
     e.free()
+
+
+@pytest.mark.parametrize("N,V", [(1024, 768), (4096, 3891), (512, 0)])
+def test_features_only_equals_the_u8_call(kernel_path, N, V):
+    # sono_stft_features_dev = sono_stft_u8_dev minus the rows: same peaks, same global maximum, bit for bit
+    import torch
+    H, S = N - V, 3
+    per = N + 41 * H + 5
+    stride = per + 11
+    buf = np.zeros(S * stride, np.float32)
+    for s in range(S):
+        buf[s * stride: s * stride + per] = signal(per, 700 + s)
+    dx = torch.from_numpy(buf).cuda()
+    e = sa.SpectrogramEngine(N, "hann")
+    F = sa.frames_for(per, N, V)
+    out = torch.zeros(S * F * (N // 2), dtype=torch.uint8, device="cuda")
+    pb = [torch.zeros(S * F, dtype=torch.int16, device="cuda") for _ in range(2)]
+    pm = [torch.zeros(S * F, dtype=torch.float32, device="cuda") for _ in range(2)]
+    gm = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    e.stft_u8_dev(dx.data_ptr(), S, stride, per, V, 20.0, 80.0, out.data_ptr(), pb[0].data_ptr(), pm[0].data_ptr(),
+                  gm[0].data_ptr(), 0)
+    e.stft_features_dev(dx.data_ptr(), S, stride, per, V, pb[1].data_ptr(), pm[1].data_ptr(), gm[1].data_ptr(), 0)
+    e.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(pb[0], pb[1]) and torch.equal(pm[0], pm[1]) and torch.equal(gm[0], gm[1])
+    assert pm[0].max().item() > 0
+    with pytest.raises(sa.SonoError):
+        e.stft_features_dev(dx.data_ptr(), S, stride, per, V, 0, 0, 0, 0)
+    e.free()
