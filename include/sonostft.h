@@ -229,6 +229,72 @@ int sono_detect_frame_features_dev(sono_engine *e, const float *d_db, size_t fra
 int sono_detect_runs_dev(sono_engine *e, const uint8_t *d_active, size_t frames, uint64_t *d_first,
                          uint64_t *d_last, uint64_t *d_count, void *hip_stream);
 
+/* ---- call framing: what detectCalls (batCallDetector.js:1070-1289) does between
+ * detectCallSegments and measureFrequencyParameters -------------------------- */
+
+/* calculateZonalNoiseFloors (batCallDetector.js:1818-1924) over frames
+ * start_frame..end_frame (inclusive, clipped to the matrix) of a host dB matrix:
+ * floors[z] = noise floor of the zone [10z, 10z+10) kHz; *num_zones zones
+ * (floor(freq_bins[num_bins-1] / 10 kHz) + 1).  freq_bins: host, num_bins values.
+ * The _dev form takes the matrix in HBM; freq_bins and floors stay on the host. */
+int sono_zonal_noise_floors(sono_engine *e, const float *power_db, size_t frames, uint32_t num_bins,
+                            const float *freq_bins, size_t start_frame, size_t end_frame, double *floors,
+                            size_t cap, size_t *num_zones);
+int sono_zonal_noise_floors_dev(sono_engine *e, const float *d_power_db, size_t frames, uint32_t num_bins,
+                                const float *freq_bins, size_t start_frame, size_t end_frame, double *floors,
+                                size_t cap, size_t *num_zones, void *hip_stream);
+
+/* The order statistic detectCalls takes as noise floor (batCallDetector.js:1223-1233):
+ * the value at index floor(count * fraction) of the ascending sort of all `count`
+ * dB values (fraction 0.25 in the reference; its -80 dB floor is the caller's). */
+int sono_db_percentile(sono_engine *e, const float *power_db, size_t count, double fraction, float *value);
+int sono_db_percentile_dev(sono_engine *e, const float *d_power_db, size_t count, double fraction, float *value,
+                           void *hip_stream);
+
+/* refineEndUsingOscillogram (batCallDetector.js:1646-1803).  Host only. */
+int sono_refine_end_oscillogram(const float *audio, size_t n, double sample_rate, int64_t start_sample,
+                                int64_t end_sample, int64_t *refined_end_sample);
+
+/* One framed call: frames start_frame..end_frame of the region's dB matrix
+ * (padded by 3 ms, end refined on the oscillogram), its times and duration
+ * (batCallDetector.js:1196-1204). */
+typedef struct sono_call_frame {
+    uint64_t start_frame, end_frame;
+    double start_time_s, end_time_s, duration_ms;
+} sono_call_frame;
+
+/* The per-segment part of detectCalls (batCallDetector.js:1128-1208): duration
+ * filter on the frame count, padding (3 ms there), oscillogram refinement of
+ * the end, time stamps, second duration filter (<= 1 ms or < min).  With
+ * full_file_rules != 0 the per-segment part of processFullFile
+ * (batCallDetector.js:739-810; padding 5 ms there): no filter on the frame
+ * count, only calls of <= 1 ms are dropped.  segs: runs from
+ * sono_detect_call_segments; time_frames: the `frames` centre times of
+ * sono_generate_spectrogram's rule ((f*hop + fft/2) / sample_rate); audio: the
+ * region's samples.  Host only. */
+int sono_frame_calls(const sono_segment *segs, size_t count, const double *time_frames, size_t frames,
+                     const float *audio, size_t n, double sample_rate, uint32_t fft_size, double padding_ms,
+                     double min_call_duration_ms, int full_file_rules, sono_call_frame *out, size_t cap,
+                     size_t *out_count);
+
+/* _scanSpectrumForFrequency (batCallDetector.js:2936-2987): first bin above the
+ * threshold from the top (high_to_low != 0) or from the bottom, with the
+ * reference's linear interpolation towards the neighbour below the threshold.
+ * *bin = -1 and *freq_hz = -1 if no bin qualifies.  Host only. */
+int sono_scan_spectrum_for_frequency(const float *row_db, const float *freq_bins, size_t num_bins,
+                                     double threshold_db, int high_to_low, double *freq_hz, int64_t *bin);
+
+/* calculateAutoHighpassFilterFreq (batCallDetector.js:4028-4035): corner in kHz. */
+double sono_auto_highpass_khz(double peak_freq_khz);
+
+/* applyHighpassFilter (batCallDetector.js:4045-4140): cascaded Butterworth
+ * sections, order rounded and clamped to 1..8; filter_hz <= 0 or >= Nyquist
+ * copies.  out: n floats (may be `in`).  Host only. */
+int sono_highpass_filter(const float *in, size_t n, double filter_hz, double sample_rate, double order, float *out);
+
+/* savitzkyGolay (batCallDetector.js:1610-1640), window 5, order 2.  Host only. */
+int sono_savitzky_golay(const double *in, size_t n, double *out);
+
 /* mergeAndPadSegments (batCallDetector.js:1028-1056).  Host only; sorts `segs` in place. */
 int sono_merge_and_pad_segments(sono_segment *segs, size_t count, uint64_t total_samples, double sample_rate,
                                 double padding_ms, sono_segment *out, size_t cap, size_t *out_count);

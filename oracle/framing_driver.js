@@ -1,0 +1,153 @@
+// Test infrastructure only: captures golden vectors of the detector's call-framing
+// stage from the reference's own JavaScript.  The methods live in
+// /root/reference/modules/batCallDetector.js, a module that cannot be loaded as a
+// whole under the Node 12 of the build container; this script reads the file as
+// text at run time, cuts the needed method bodies out by name, wraps each in a
+// Function and runs them against the reference wasm engine (wasm_ref.js).
+// detectCalls itself is run with stand-ins for the three things it calls that are
+// outside this stage (the BatCall record, measureFrequencyParameters, the call
+// classifier), so its own control flow -- duration filter, padding, oscillogram
+// refinement, slicing, noise-floor percentile -- is the reference's, executed.
+// Nothing of the reference is stored in this repository: only inputs and outputs.
+// usage: node --experimental-wasm-mv --experimental-wasm-anyref framing_driver.js <wasm> <detector.js> <workdir>
+'use strict';
+const fs = require('fs');
+const path = require('path');
+const { load } = require('./wasm_ref.js');
+
+const wasmPath = process.argv[2], jsPath = process.argv[3], work = process.argv[4];
+const ref = load(wasmPath);
+const src = fs.readFileSync(jsPath, 'utf8');
+const AsyncFunction = Object.getPrototypeOf(async function () {}).constructor;
+
+// "  [async ]name(args) {" at class-member indentation -> Function(argNames..., body)
+function method(name, argNames) {
+  const re = new RegExp('\\n  (async )?' + name + '\\(([^)]*)\\) \\{');
+  const m = re.exec(src);
+  if (!m) throw new Error('method not found: ' + name);
+  let i = m.index + m[0].length, depth = 1;
+  const start = i;
+  for (; i < src.length && depth > 0; i++) {
+    if (src[i] === '{') depth++;
+    else if (src[i] === '}') depth--;
+  }
+  const names = argNames || m[2].split(',').map((s) => s.trim());     // defaults stay ("order = 4")
+  const Ctor = m[1] ? AsyncFunction : Function;
+  return new Ctor(...names, src.slice(start, i - 1));
+}
+const names = ['fastScanSegmentsWasm', 'mergeAndPadSegments', 'generateSpectrogramWasm', 'detectCallSegments', 'savitzkyGolay', 'refineEndUsingOscillogram',
+  'calculateZonalNoiseFloors', '_scanSpectrumForFrequency', 'calculateAutoHighpassFilterFreq', 'applyHighpassFilter',
+  '_applyButterworthStage', 'getQualityRating', 'calculateDuration'];
+const fns = {};
+for (const n of names) fns[n] = method(n);
+fns.detectCalls = method('detectCalls', ['audioData', 'sampleRate', 'flowKHz', 'fhighKHz', 'options']);
+
+const cases = JSON.parse(fs.readFileSync(path.join(work, 'cases.json'), 'utf8'));
+const inBuf = fs.readFileSync(path.join(work, 'inputs.bin'));
+const inputs = new Float32Array(inBuf.buffer, inBuf.byteOffset, inBuf.length / 4);
+const outFd = fs.openSync(path.join(work, 'outputs.bin'), 'w');
+let outPos = 0;
+const manifest = [];
+function emit(caseName, key, typed) {
+  const b = Buffer.from(typed.buffer, typed.byteOffset, typed.byteLength);
+  fs.writeSync(outFd, b);
+  const dtype = typed instanceof Float32Array ? 'f32' : typed instanceof Float64Array ? 'f64' : 'u8';
+  manifest.push({ case: caseName, key, dtype, offset: outPos, count: typed.length });
+  outPos += b.length;
+}
+const f64 = (a) => Float64Array.from(a);
+const zoneArray = (map) => {                       // {"0": dB, "10": dB, ...} -> dB by zone index
+  const keys = Object.keys(map).map(Number).sort((a, b) => a - b);
+  return f64(keys.map((k) => map[String(k)]));
+};
+console.log = () => {}; console.warn = () => {}; console.groupCollapsed = () => {}; console.table = () => {}; console.groupEnd = () => {};
+
+async function run() {
+  for (const c of cases) {
+    const x = inputs.subarray(c.x_off, c.x_off + c.x_len);
+    const e = new ref.Engine(c.fft, c.window, null);
+    const captured = [];
+    const self = {
+      debugMode: false,
+      wasmEngine: { get_fft_size: () => c.fft, get_freq_bins: () => c.fft / 2, compute_spectrogram: (a, v) => e.mag(a, v) },
+      config: { hopPercent: c.hop_percent, callThreshold_dB: c.call_threshold_db, fftSize: c.fft,
+        minCallDuration_ms: c.min_call_duration_ms },
+    };
+    for (const n of names) self[n] = fns[n];
+    self.generateSpectrogram = fns.generateSpectrogramWasm;
+    self.fastScanSegments = fns.fastScanSegmentsWasm;
+    // stand-in for the measurement stage: records what it is handed and leaves a peak power behind
+    self.measureFrequencyParameters = function (call, flowKHz, fhighKHz, freqBins, freqResolution, zonalNoiseMap) {
+      let peak = -Infinity;
+      for (const row of call.spectrogram) for (let b = 0; b < row.length; b++) if (row[b] > peak) peak = row[b];
+      call.peakPower_dB = peak;
+      call.lowFreq_kHz = 0; call.highFreq_kHz = 0;
+      captured.push({ frames: call.spectrogram.length, zonal: zoneArray(zonalNoiseMap) });
+    };
+
+    function BatCall() {
+      this.startTime_s = null; this.endTime_s = null; this.startFreqTime_s = null; this.endFreqTime_s = null;
+      this.duration_ms = null; this.peakPower_dB = null;
+    }
+    BatCall.prototype.calculateDuration = fns.calculateDuration;
+    const CallTypeClassifier = { classify: () => 'NA' };
+    // a method whose text refers to BatCall and CallTypeClassifier as free identifiers gets them as leading parameters
+    const scoped = (name, argNames) => {
+      const m = new RegExp('\\n  async ' + name + '\\(([^)]*)\\) \\{').exec(src);
+      let i = m.index + m[0].length, depth = 1; const start = i;
+      for (; i < src.length && depth > 0; i++) { if (src[i] === '{') depth++; else if (src[i] === '}') depth--; }
+      return new AsyncFunction('BatCall', 'CallTypeClassifier', ...argNames, src.slice(start, i - 1));
+    };
+    if (c.kind === 'fullfile') {
+      const processFullFile = scoped('processFullFile', ['fullAudioData', 'sampleRate', 'flowKHz', 'fhighKHz', 'options']);
+      const calls = await processFullFile.call(self, BatCall, CallTypeClassifier, x, c.sr, c.flow_khz, c.fhigh_khz,
+        { threshold_dB: c.scan_threshold_db, padding_ms: c.padding_ms });
+      emit(c.name, 'calls', f64([].concat(...calls.map((k) => [k.startTime_s, k.endTime_s, k.duration_ms, k.snr_dB, k.spectrogram.length]))));
+      emit(c.name, 'zonal_first', captured.length ? captured[0].zonal : new Float64Array(0));
+      emit(c.name, 'measured_frames', f64(captured.map((k) => k.frames)));
+    } else if (c.kind === 'calls') {
+      const detectCalls = scoped('detectCalls', ['audioData', 'sampleRate', 'flowKHz', 'fhighKHz', 'options']);
+      let noise = null;
+      if (c.noise_len > 0) noise = fns.generateSpectrogramWasm.call(self, inputs.subarray(c.noise_off, c.noise_off + c.noise_len), c.sr, c.flow_khz, c.fhigh_khz);
+      const calls = await detectCalls.call(self, BatCall, CallTypeClassifier, x, c.sr, c.flow_khz, c.fhigh_khz, { skipSNR: true, noiseSpectrogram: noise });
+      emit(c.name, 'calls', f64([].concat(...calls.map((k) => [k.startTime_s, k.endTime_s, k.duration_ms, k.noiseFloor_dB, k.snr_dB, k.spectrogram.length]))));
+      emit(c.name, 'measured_frames', f64(captured.map((k) => k.frames)));
+      emit(c.name, 'zonal', captured.length ? captured[0].zonal : new Float64Array(0));
+    } else if (c.kind === 'refine') {
+      const out = [];
+      for (const [s0, s1] of c.ranges) out.push(fns.refineEndUsingOscillogram.call(self, x, c.sr, s0, s1));
+      emit(c.name, 'refined', f64(out));
+    } else if (c.kind === 'zonal') {
+      const sp = fns.generateSpectrogramWasm.call(self, x, c.sr, c.flow_khz, c.fhigh_khz);
+      const nb = sp.freqBins.length, F = sp.powerMatrix.length;
+      const db = new Float32Array(F * nb);
+      sp.powerMatrix.forEach((row, f) => db.set(row, f * nb));
+      emit(c.name, 'db', db);
+      emit(c.name, 'freq', sp.freqBins);
+      emit(c.name, 'shape', f64([F, nb]));
+      for (const [f0, f1] of c.ranges) emit(c.name, 'zonal_' + f0 + '_' + f1, zoneArray(fns.calculateZonalNoiseFloors.call(self, sp.powerMatrix, sp.freqBins, f0, f1)));
+      // the noise floor of detectCalls (batCallDetector.js:1223-1235): 25th percentile of every value, floored at -80
+      const all = Array.from(db); all.sort((a, b) => a - b);
+      emit(c.name, 'p25', f64([all[Math.max(0, Math.floor(all.length * 0.25))]]));
+      // per-frame threshold crossings with interpolation
+      const scans = [];
+      for (const thr of c.thresholds) for (let f = 0; f < F; f += c.scan_stride) for (const dir of ['HighToLow', 'LowToHigh']) {
+        const r = fns._scanSpectrumForFrequency.call(self, sp.powerMatrix[f], sp.freqBins, thr, dir);
+        scans.push(r ? r.freq_Hz : -1, r ? r.binIdx : -1);
+      }
+      emit(c.name, 'scans', f64(scans));
+    } else if (c.kind === 'filter') {
+      for (const [hz, order] of c.filters) emit(c.name, 'hp_' + hz + '_' + order, fns.applyHighpassFilter.call(self, x, hz, c.sr, order));
+      emit(c.name, 'auto', f64(c.peaks_khz.map((p) => fns.calculateAutoHighpassFilterFreq.call(self, p))));
+      const sg = fns.savitzkyGolay.call(self, Array.from(x.subarray(0, c.sg_len)).map((v) => v * 1000));
+      emit(c.name, 'sg', f64(sg));
+      emit(c.name, 'sg_short', f64(fns.savitzkyGolay.call(self, [1, 2, 4])));
+    }
+    e.free();
+  }
+}
+run().then(() => {
+  fs.closeSync(outFd);
+  fs.writeFileSync(path.join(work, 'outputs.json'), JSON.stringify(manifest));
+  process.stdout.write('framing_driver: ' + cases.length + ' cases, ' + outPos + ' bytes\n');
+}).catch((err) => { process.stderr.write(String(err && err.stack || err) + '\n'); process.exit(1); });

@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Capture golden vectors of the detector's call-framing stage from the
+reference's own JavaScript (detectCalls up to the measurement stage,
+refineEndUsingOscillogram, calculateZonalNoiseFloors, _scanSpectrumForFrequency,
+applyHighpassFilter, savitzkyGolay of modules/batCallDetector.js) driving the
+reference wasm.
+
+TEST INFRASTRUCTURE ONLY.  Runs in the build container, where /root/reference
+and Node are present; the GPU box only ever sees the committed output,
+tests/golden/golden_framing.npz (inputs + the reference's outputs, no code).
+
+  python oracle/make_golden_framing.py
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+from make_golden import chirp, tone, white  # noqa: E402
+
+WASM = os.environ.get("SONO_REF_WASM", "/root/reference/modules/spectrogram_wasm_bg.wasm")
+DETECTOR_JS = os.environ.get("SONO_REF_DETECTOR", "/root/reference/modules/batCallDetector.js")
+OUT = os.path.join(ROOT, "tests", "golden", "golden_framing.npz")
+
+
+def pulse(n, sr, seed, at, dur_ms, f0, f1, amp, tail_db=None, noise=0.02):
+    """Noise with one downward FM pulse starting at sample `at`; tail_db adds a weaker echo right after it."""
+    x = noise * white(n, seed, 1.0)
+    m = int(sr * dur_ms / 1000)
+    t = np.arange(m) / sr
+    ph = 2 * np.pi * (f0 * t + 0.5 * (f1 - f0) / (m / sr) * t * t)
+    env = np.hanning(m)
+    x[at:at + m] += (amp * env * np.sin(ph)).astype(np.float32)
+    if tail_db is not None:
+        k = at + m + int(0.0006 * sr)
+        e = amp * 10 ** (tail_db / 20)
+        x[k:k + m] += (e * env * np.sin(ph)).astype(np.float32)
+    return x.astype(np.float32)
+
+
+def build_cases():
+    cases, bufs, pos = [], [], [0]
+
+    def put(x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        off = pos[0]
+        bufs.append(x)
+        pos[0] += x.size
+        return off, int(x.size)
+
+    def add(name, kind, x, sr, fft=1024, window="hann", flow=10.0, fhigh=128.0, hop_percent=3.125, call_thr=-24.0,
+            min_ms=1.0, noise=None, **extra):
+        off, ln = put(x)
+        noff, nlen = put(noise) if noise is not None else (0, 0)
+        cases.append(dict(name=name, kind=kind, fft=fft, window=window, sr=sr, flow_khz=flow, fhigh_khz=fhigh,
+                          hop_percent=hop_percent, call_threshold_db=call_thr, min_call_duration_ms=min_ms,
+                          x_off=off, x_len=ln, noise_off=noff, noise_len=nlen, **extra))
+
+    sr = 384000
+    # --- detectCalls framing: pulses of different lengths, an echo that the oscillogram refinement cuts, a pulse that
+    #     is too short, a pulse at the very start, external noise spectrogram vs. the first-frames fallback
+    a = pulse(12000, sr, 61, 3000, 4.0, 80000, 35000, 0.5)
+    add("one_pulse", "calls", a, sr, flow=20.0, fhigh=100.0)
+    b = pulse(16000, sr, 62, 2500, 3.0, 70000, 40000, 0.6, tail_db=-30.0)
+    add("pulse_with_echo", "calls", b, sr, flow=20.0, fhigh=100.0)
+    c = pulse(20000, sr, 63, 2000, 5.0, 90000, 30000, 0.4)
+    c += pulse(20000, sr, 64, 11000, 0.4, 60000, 55000, 0.3, noise=0.0)        # 0.4 ms: dropped by the duration filter
+    c += pulse(20000, sr, 65, 15000, 2.5, 50000, 45000, 0.5, noise=0.0)
+    add("three_pulses_min2ms", "calls", c, sr, flow=20.0, fhigh=100.0, min_ms=2.0, hop_percent=6.25)
+    d = pulse(9000, sr, 66, 0, 3.0, 60000, 30000, 0.5, noise=0.1)
+    add("pulse_at_start_ext_noise", "calls", d, sr, flow=15.0, fhigh=110.0, noise=0.1 * white(6000, 67, 1.0), hop_percent=6.25)
+    add("loud_noise_only", "calls", 0.3 * white(6000, 68, 1.0), sr, call_thr=-3.0)
+    add("pulses500k_512", "calls", pulse(15000, 500000, 69, 4000, 3.5, 110000, 50000, 0.5, tail_db=-26.0), 500000, fft=512,
+        flow=20.0, fhigh=150.0, hop_percent=6.25)
+    # --- processFullFile: fast scan -> ROIs -> auto high-pass -> segments -> strongest-first 30 ms echo filter -> framing
+    n = 120000
+    ff = 0.01 * white(n, 80, 1.0)
+    for k, (at, dur, f0, f1, amp) in enumerate([(8000, 4.0, 80000, 45000, 0.5),       # peak >= 40 kHz: 30 kHz high-pass
+                                                 (13000, 3.0, 80000, 45000, 0.05),     # echo 13 ms later: dropped (< 30 ms)
+                                                 (40000, 5.0, 38000, 33000, 0.4),      # 35-40 kHz: 25 kHz high-pass
+                                                 (70000, 6.0, 33000, 30500, 0.4),      # 30-35 kHz: 20 kHz
+                                                 (95000, 4.0, 27000, 21000, 0.5),      # below 30 kHz: no high-pass
+                                                 (110000, 0.6, 60000, 58000, 0.4)]):   # very short
+        ff = ff + pulse(n, sr, 81 + k, at, dur, f0, f1, amp, noise=0.0)
+    add("full_file", "fullfile", ff, sr, flow=15.0, fhigh=110.0, hop_percent=6.25, scan_threshold_db=-45.0, padding_ms=5.0)
+    add("full_file_512_quiet", "fullfile", 0.001 * white(30000, 90, 1.0), 500000, fft=512, flow=20.0, fhigh=120.0,
+        hop_percent=12.5, scan_threshold_db=-30.0, padding_ms=5.0)
+    g2 = 0.02 * white(60000, 91, 1.0) + pulse(60000, 500000, 92, 20000, 3.0, 90000, 50000, 0.6, tail_db=-25.0, noise=0.0)
+    add("full_file_512", "fullfile", g2, 500000, fft=512, flow=20.0, fhigh=120.0, hop_percent=12.5, scan_threshold_db=-50.0,
+        padding_ms=8.0)
+    # --- oscillogram refinement on its own: ranges that end in noise, in the signal body, out of bounds, too short
+    e = pulse(14000, sr, 70, 2000, 6.0, 60000, 40000, 0.7, tail_db=-28.0)
+    add("refine", "refine", e, sr, ranges=[[1500, 9000], [1500, 5000], [0, 14000], [-200, 20000], [3000, 3100], [2000, 4300],
+                                           [6000, 14000], [4000, 4191], [4000, 4193]])
+    q = pulse(8000, sr, 71, 1000, 4.0, 60000, 40000, 0.9, noise=1e-6)
+    add("refine_quiet_floor", "refine", q, sr, ranges=[[500, 7500], [1000, 4000], [2536, 7000]])
+    # --- zonal noise floors, percentile, threshold crossings
+    f = pulse(9000, sr, 72, 3000, 4.0, 100000, 25000, 0.5, noise=0.05)
+    add("zonal", "zonal", f, sr, flow=0.0, fhigh=192.0, hop_percent=12.5, ranges=[[0, 5], [0, 0], [10, 40], [50, 1000], [3, 2]],
+        thresholds=[-60.0, -40.0, -27.5], scan_stride=3)
+    add("zonal_band", "zonal", f, sr, flow=18.0, fhigh=97.0, hop_percent=25.0, ranges=[[0, 5], [2, 30]], thresholds=[-55.0],
+        scan_stride=2)
+    add("zonal_digital_silence", "zonal", np.zeros(5000, np.float32), sr, flow=5.0, fhigh=60.0, hop_percent=25.0,
+        ranges=[[0, 5]], thresholds=[-100.0, -170.0], scan_stride=1)
+    # --- Butterworth high-pass, automatic corner frequency, Savitzky-Golay
+    g = chirp(6000, sr, 73, period=0.01, t0=0.002) + 0.2 * tone(6000, sr, 8000.0, amp=1.0)
+    add("filter", "filter", g, sr, filters=[[30000, 4], [25000, 2], [20000, 1], [20000, 3], [15000, 8], [10000, 12], [0, 4],
+                                            [192000, 4], [250000, 2]],
+        peaks_khz=[45.0, 40.0, 39.999, 35.0, 34.0, 30.0, 29.9, 0.0], sg_len=64)
+    return cases, np.concatenate(bufs)
+
+
+def main():
+    cases, inputs = build_cases()
+    with tempfile.TemporaryDirectory() as work:
+        json.dump(cases, open(os.path.join(work, "cases.json"), "w"))
+        inputs.tofile(os.path.join(work, "inputs.bin"))
+        node = ["node"]
+        ver = subprocess.check_output(["node", "--version"]).decode().strip()
+        if int(ver.lstrip("v").split(".")[0]) < 16:
+            node += ["--experimental-wasm-mv", "--experimental-wasm-anyref"]
+        subprocess.check_call(node + [os.path.join(HERE, "framing_driver.js"), WASM, DETECTOR_JS, work])
+        man = json.load(open(os.path.join(work, "outputs.json")))
+        blob = open(os.path.join(work, "outputs.bin"), "rb").read()
+    dt = {"f32": np.float32, "f64": np.float64, "u8": np.uint8}
+    arrays = {}
+    for m in man:
+        arrays[f"{m['case']}/{m['key']}"] = np.frombuffer(blob, np.dtype(dt[m["dtype"]]), m["count"], m["offset"]).copy()
+    meta = []
+    for c in cases:
+        c = dict(c)
+        arrays[f"{c['name']}/x"] = inputs[c["x_off"]:c["x_off"] + c["x_len"]].copy()
+        if c["noise_len"]:
+            arrays[f"{c['name']}/noise"] = inputs[c["noise_off"]:c["noise_off"] + c["noise_len"]].copy()
+        for k in ("x_off", "x_len", "noise_off", "noise_len"):
+            c.pop(k)
+        meta.append(c)
+    arrays["__meta__"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(OUT, **arrays)
+    print(f"wrote {OUT}: {len(cases)} cases, {os.path.getsize(OUT)} bytes")
+    for c in meta:
+        n = c["name"]
+        if c["kind"] == "fullfile":
+            print(f"  {n}: calls {arrays[n + '/calls'].reshape(-1, 5).round(5).tolist()}")
+        elif c["kind"] == "calls":
+            print(f"  {n}: calls {arrays[n + '/calls'].reshape(-1, 6).round(5).tolist()} zonal {arrays[n + '/zonal'].tolist()}")
+        elif c["kind"] == "refine":
+            print(f"  {n}: refined {arrays[n + '/refined'].tolist()}")
+        elif c["kind"] == "zonal":
+            print(f"  {n}: p25 {arrays[n + '/p25'].tolist()} " + " ".join(f"{k.split('/')[1]}={arrays[k].tolist()}" for k in arrays if k.startswith(n + "/zonal_")))
+        else:
+            print(f"  {n}: auto {arrays[n + '/auto'].tolist()} sg_short {arrays[n + '/sg_short'].tolist()}")
+
+
+if __name__ == "__main__":
+    sys.exit(main())

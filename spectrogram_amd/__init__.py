@@ -50,6 +50,12 @@ class Segment(C.Structure):
     _fields_ = [("start", C.c_uint64), ("end", C.c_uint64)]
 
 
+class CallFrame(C.Structure):
+    """struct sono_call_frame."""
+    _fields_ = [("start_frame", C.c_uint64), ("end_frame", C.c_uint64), ("start_time_s", C.c_double),
+                ("end_time_s", C.c_double), ("duration_ms", C.c_double)]
+
+
 class FrameFeatures(C.Structure):
     """struct sono_frame_features."""
     _fields_ = [("peak_bin", C.c_int32), ("peak_db", C.c_float), ("low_bin", C.c_int32), ("high_bin", C.c_int32)]
@@ -119,6 +125,20 @@ _SIGNATURES = {
                                                  C.c_uint32, C.c_double, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p]),
     "sono_detect_runs_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
+    "sono_zonal_noise_floors": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_uint32, _f32p, C.c_size_t, C.c_size_t,
+                                          C.POINTER(C.c_double), C.c_size_t, _szp]),
+    "sono_zonal_noise_floors_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, _f32p, C.c_size_t, C.c_size_t,
+                                              C.POINTER(C.c_double), C.c_size_t, _szp, C.c_void_p]),
+    "sono_db_percentile": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_double, C.POINTER(C.c_float)]),
+    "sono_db_percentile_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.POINTER(C.c_float), C.c_void_p]),
+    "sono_refine_end_oscillogram": (C.c_int, [_f32p, C.c_size_t, C.c_double, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
+    "sono_frame_calls": (C.c_int, [_segp, C.c_size_t, C.POINTER(C.c_double), C.c_size_t, _f32p, C.c_size_t, C.c_double,
+                                   C.c_uint32, C.c_double, C.c_double, C.c_int, C.POINTER(CallFrame), C.c_size_t, _szp]),
+    "sono_scan_spectrum_for_frequency": (C.c_int, [_f32p, _f32p, C.c_size_t, C.c_double, C.c_int, C.POINTER(C.c_double),
+                                                   C.POINTER(C.c_int64)]),
+    "sono_auto_highpass_khz": (C.c_double, [C.c_double]),
+    "sono_highpass_filter": (C.c_int, [_f32p, C.c_size_t, C.c_double, C.c_double, C.c_double, _f32p]),
+    "sono_savitzky_golay": (C.c_int, [C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double)]),
     "sono_wav_parse": (C.c_int, [_u8p, C.c_size_t, C.POINTER(WavInfo)]),
     "sono_pcm_to_f32_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                       C.c_void_p, C.c_void_p]),

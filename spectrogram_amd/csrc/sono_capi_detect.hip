@@ -10,6 +10,7 @@
 #include "../../include/sonostft.h"
 #include "sono_detect.h"
 #include "sono_engine.h"
+#include "sono_framing.h"
 
 using sono::DeviceGuard;
 using sono::fail;
@@ -258,6 +259,142 @@ int sono_frame_features_db(sono_engine *e, const float *power_db, size_t frames,
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, e->d_out.p, frames * sizeof(sono_frame_features), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    return SONO_OK;
+}
+
+// ---- call framing -------------------------------------------------------------
+
+int sono_zonal_noise_floors_dev(sono_engine *e, const float *d_db, size_t frames, uint32_t num_bins, const float *freq_bins,
+                                size_t start_frame, size_t end_frame, double *floors, size_t cap, size_t *num_zones,
+                                void *hip_stream)
+{
+    if (num_zones) *num_zones = 0;
+    if (!e || !freq_bins || num_bins == 0 || (frames && !d_db))
+        return fail(SONO_EINVAL, "sono_zonal_noise_floors: NULL argument or empty bin list");
+    std::vector<uint8_t> zone_of_bin;
+    const size_t zones = sono::host_zone_map(freq_bins, num_bins, zone_of_bin);
+    if (zones == 0) return fail(SONO_EINVAL, "sono_zonal_noise_floors: frequency axis out of range");
+    if (!floors || cap < zones) return fail(SONO_ECAPACITY, "sono_zonal_noise_floors: output buffer too small");
+    std::vector<unsigned int> hist(zones * sono::kZoneHistBins, 0u);
+    const size_t last = frames ? (end_frame < frames - 1 ? end_frame : frames - 1) : 0;      // js:1850: stop at the matrix end
+    if (frames && start_frame <= last) {
+        DeviceGuard guard(e->device);
+        hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+        const size_t hist_bytes = hist.size() * sizeof(unsigned int);
+        HIP_TRY(e->d_edges.reserve(hist_bytes + num_bins));
+        unsigned int *d_hist = (unsigned int *)e->d_edges.p;
+        uint8_t *d_zone = (uint8_t *)e->d_edges.p + hist_bytes;
+        HIP_TRY(hipMemsetAsync(d_hist, 0, hist_bytes, s));
+        HIP_TRY(hipMemcpyAsync(d_zone, zone_of_bin.data(), num_bins, hipMemcpyHostToDevice, s));
+        HIP_TRY(sono::launch_zone_hist(d_db + start_frame * (size_t)num_bins, (last - start_frame + 1) * (size_t)num_bins,
+                                       num_bins, d_zone, (uint32_t)zones, d_hist, s));
+        HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, hist_bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    sono::host_zone_modes(hist.data(), zones, floors);
+    if (num_zones) *num_zones = zones;
+    return SONO_OK;
+}
+
+int sono_zonal_noise_floors(sono_engine *e, const float *power_db, size_t frames, uint32_t num_bins, const float *freq_bins,
+                            size_t start_frame, size_t end_frame, double *floors, size_t cap, size_t *num_zones)
+{
+    if (num_zones) *num_zones = 0;
+    if (!e || (frames && num_bins && !power_db)) return fail(SONO_EINVAL, "sono_zonal_noise_floors: NULL argument");
+    DeviceGuard guard(e->device);
+    const size_t total = frames * (size_t)num_bins;
+    HIP_TRY(e->d_db.reserve((total ? total : 1) * sizeof(float)));
+    if (total) HIP_TRY(hipMemcpyAsync(e->d_db.p, power_db, total * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    return sono_zonal_noise_floors_dev(e, (const float *)e->d_db.p, frames, num_bins, freq_bins, start_frame, end_frame,
+                                       floors, cap, num_zones, nullptr);
+}
+
+int sono_db_percentile_dev(sono_engine *e, const float *d_db, size_t count, double fraction, float *value, void *hip_stream)
+{
+    if (!e || !value || (count && !d_db)) return fail(SONO_EINVAL, "sono_db_percentile: NULL argument");
+    if (count == 0 || !(fraction >= 0.0) || fraction > 1.0) return fail(SONO_EINVAL, "sono_db_percentile: empty input or fraction outside [0, 1]");
+    if (count > 0x7FFFFFFFull) return fail(SONO_EINVAL, "sono_db_percentile: more than 2^31 - 1 values");
+    DeviceGuard guard(e->device);
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    size_t tmp = 0;
+    HIP_TRY(sono::sort_floats(nullptr, tmp, d_db, nullptr, count, s));
+    HIP_TRY(e->d_select_tmp.reserve(tmp ? tmp : 1));
+    HIP_TRY(e->d_runs.reserve(count * sizeof(float)));
+    HIP_TRY(sono::sort_floats(e->d_select_tmp.p, tmp, d_db, (float *)e->d_runs.p, count, s));
+    size_t k = (size_t)std::floor((double)count * fraction);                     // js:1232
+    if (k >= count) k = count - 1;
+    HIP_TRY(hipMemcpyAsync(value, (const float *)e->d_runs.p + k, sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SONO_OK;
+}
+
+int sono_db_percentile(sono_engine *e, const float *power_db, size_t count, double fraction, float *value)
+{
+    if (!e || !value || (count && !power_db)) return fail(SONO_EINVAL, "sono_db_percentile: NULL argument");
+    if (count == 0) return fail(SONO_EINVAL, "sono_db_percentile: empty input");
+    DeviceGuard guard(e->device);
+    HIP_TRY(e->d_db.reserve(count * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(e->d_db.p, power_db, count * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    return sono_db_percentile_dev(e, (const float *)e->d_db.p, count, fraction, value, nullptr);
+}
+
+int sono_refine_end_oscillogram(const float *audio, size_t n, double sample_rate, int64_t start_sample, int64_t end_sample,
+                                int64_t *refined)
+{
+    if (!refined || (n && !audio)) return fail(SONO_EINVAL, "sono_refine_end_oscillogram: NULL argument");
+    if (!sono::host_refine_end(audio, n, sample_rate, start_sample, end_sample, refined))
+        return fail(SONO_EINVAL, "sono_refine_end_oscillogram: sample rate below 20 kHz (the 0.1 ms window has no hop)");
+    return SONO_OK;
+}
+
+int sono_frame_calls(const sono_segment *segs, size_t count, const double *time_frames, size_t frames, const float *audio,
+                     size_t n, double sample_rate, uint32_t fft_size, double padding_ms, double min_call_duration_ms,
+                     int full_file_rules, sono_call_frame *out, size_t cap, size_t *out_count)
+{
+    if (out_count) *out_count = 0;
+    if ((count && !segs) || (frames && !time_frames) || (n && !audio) || !(sample_rate > 0) || fft_size == 0)
+        return fail(SONO_EINVAL, "sono_frame_calls: NULL or non-positive argument");
+    std::vector<sono::FrameRun> runs(count);
+    for (size_t i = 0; i < count; ++i) { runs[i].start = segs[i].start; runs[i].end = segs[i].end; }
+    std::vector<sono::CallFrame> calls;
+    if (!(padding_ms >= 0)) return fail(SONO_EINVAL, "sono_frame_calls: padding_ms must be >= 0");
+    if (!sono::host_frame_calls(runs.data(), count, time_frames, frames, audio, n, sample_rate, fft_size, padding_ms,
+                                min_call_duration_ms, full_file_rules != 0, calls))
+        return fail(SONO_EINVAL, "sono_frame_calls: sample rate below 20 kHz (the 0.1 ms window has no hop)");
+    if (calls.size() > cap || (calls.size() && !out)) return fail(SONO_ECAPACITY, "sono_frame_calls: output buffer too small");
+    for (size_t i = 0; i < calls.size(); ++i) {
+        out[i].start_frame = calls[i].start_frame; out[i].end_frame = calls[i].end_frame;
+        out[i].start_time_s = calls[i].start_time_s; out[i].end_time_s = calls[i].end_time_s;
+        out[i].duration_ms = calls[i].duration_ms;
+    }
+    if (out_count) *out_count = calls.size();
+    return SONO_OK;
+}
+
+int sono_scan_spectrum_for_frequency(const float *row_db, const float *freq_bins, size_t num_bins, double threshold_db,
+                                     int high_to_low, double *freq_hz, int64_t *bin)
+{
+    if (!freq_hz || !bin || (num_bins && (!row_db || !freq_bins)))
+        return fail(SONO_EINVAL, "sono_scan_spectrum_for_frequency: NULL argument");
+    sono::host_scan_spectrum(row_db, freq_bins, num_bins, threshold_db, high_to_low != 0, freq_hz, bin);
+    return SONO_OK;
+}
+
+double sono_auto_highpass_khz(double peak_freq_khz) { return sono::host_auto_highpass_khz(peak_freq_khz); }
+
+int sono_highpass_filter(const float *in, size_t n, double filter_hz, double sample_rate, double order, float *out)
+{
+    if (n && (!in || !out)) return fail(SONO_EINVAL, "sono_highpass_filter: NULL argument");
+    if (!(sample_rate > 0)) return fail(SONO_EINVAL, "sono_highpass_filter: sample_rate must be positive");
+    sono::host_highpass(in, n, filter_hz, sample_rate, order, out);
+    return SONO_OK;
+}
+
+int sono_savitzky_golay(const double *in, size_t n, double *out)
+{
+    if (n && (!in || !out)) return fail(SONO_EINVAL, "sono_savitzky_golay: NULL argument");
+    if (in == out && n >= 5) return fail(SONO_EINVAL, "sono_savitzky_golay: in and out must not alias");
+    sono::host_savitzky_golay(in, n, out);
     return SONO_OK;
 }
 

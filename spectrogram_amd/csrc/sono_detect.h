@@ -42,6 +42,16 @@ hipError_t launch_run_edges(const uint8_t *d_active, size_t frames, uint8_t *d_i
 hipError_t select_flagged(void *d_temp, size_t &temp_bytes, const uint8_t *d_flags, uint64_t *d_out,
                           uint64_t *d_count, size_t frames, hipStream_t s);
 
+// calculateZonalNoiseFloors' histogram pass (batCallDetector.js:1849-1879) over count = rows*nb values that
+// start at d_db: value i belongs to bin i % nb, d_zone_of_bin[bin] is its 10 kHz zone (255 = not counted),
+// d_hist[zone*141 + (floor(max(dB, -100)) clamped to -120..20) + 120] counts it.  The caller zeroes d_hist.
+constexpr int kZoneHistBins = 141;
+hipError_t launch_zone_hist(const float *d_db, size_t count, uint32_t nb, const uint8_t *d_zone_of_bin,
+                            uint32_t num_zones, unsigned int *d_hist, hipStream_t s);
+
+// Ascending sort of `count` finite floats (d_in -> d_out).  d_temp == nullptr: size query.
+hipError_t sort_floats(void *d_temp, size_t &temp_bytes, const float *d_in, float *d_out, size_t count, hipStream_t s);
+
 // Interleaved PCM -> one f32 channel.  Integer samples are divided by 2^(bits-1); 8-bit WAV is unsigned.
 hipError_t launch_pcm_to_f32(const void *d_pcm, size_t frames, uint32_t channels, uint32_t channel, uint32_t bits,
                              int is_float, float *d_out, hipStream_t s);

@@ -163,7 +163,47 @@ __global__ __launch_bounds__(kThreads) void pcm_to_f32_kernel(const uint8_t *pcm
 
 unsigned int rows_grid(size_t frames) { return (unsigned int)((frames + kRowsPerBlock - 1) / kRowsPerBlock); }
 
+// One LDS histogram per workgroup, merged into the global one at the end.
+__global__ __launch_bounds__(kThreads) void zone_hist_kernel(const float *db, size_t count, uint32_t nb,
+                                                             const uint8_t *zone_of_bin, uint32_t num_zones,
+                                                             unsigned int *hist)
+{
+    extern __shared__ unsigned int s_hist[];
+    const uint32_t cells = num_zones * (uint32_t)kZoneHistBins;
+    for (uint32_t i = threadIdx.x; i < cells; i += kThreads) s_hist[i] = 0u;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (size_t)gridDim.x * kThreads) {
+        const uint32_t zone = zone_of_bin[i % nb];
+        float v = db[i];
+        if (zone >= num_zones || v != v) continue;                  // a NaN lands in no bin of the reference's array either
+        v = v < -100.0f ? -100.0f : v;                              // js:1857
+        float fl = floorf(v);                                       // js:1867
+        fl = fl < -120.0f ? -120.0f : fl > 20.0f ? 20.0f : fl;      // js:1870-1871
+        atomicAdd(&s_hist[zone * kZoneHistBins + (uint32_t)((int)fl + 120)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < cells; i += kThreads)
+        if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
+}
+
 }  // namespace
+
+hipError_t launch_zone_hist(const float *d_db, size_t count, uint32_t nb, const uint8_t *d_zone_of_bin,
+                            uint32_t num_zones, unsigned int *d_hist, hipStream_t s)
+{
+    if (count == 0 || num_zones == 0) return hipSuccess;
+    size_t blocks = (count + (size_t)kThreads * 16 - 1) / ((size_t)kThreads * 16);
+    blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
+    const size_t lds = (size_t)num_zones * kZoneHistBins * sizeof(unsigned int);
+    hipLaunchKernelGGL(zone_hist_kernel, dim3((unsigned int)blocks), dim3(kThreads), lds, s, d_db, count, nb,
+                       d_zone_of_bin, num_zones, d_hist);
+    return hipGetLastError();
+}
+
+hipError_t sort_floats(void *d_temp, size_t &temp_bytes, const float *d_in, float *d_out, size_t count, hipStream_t s)
+{
+    return hipcub::DeviceRadixSort::SortKeys(d_temp, temp_bytes, d_in, d_out, (int)count, 0, 32, s);
+}
 
 hipError_t launch_band_active(const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin, uint32_t max_bin,
                               double target, uint8_t *d_active, double *d_band_energy, hipStream_t s)

@@ -1,0 +1,196 @@
+"""Call framing: what the reference's BatCallDetector.detectCalls
+(modules/batCallDetector.js:1070-1289) does between detectCallSegments and the
+measurement stage, under the reference's method names (snake_case).  The matrix
+passes (zonal histograms, the noise-floor order statistic, call segments) run on
+the GPU; the per-call serial steps (oscillogram refinement, Butterworth
+high-pass) are host C++ in libsonostft.  Nothing numeric is computed here.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import CallFrame as _CallFrame, Segment as _Segment, _check, _f32, _p, lib
+from . import detector as _det
+
+__all__ = ["calculate_zonal_noise_floors", "db_percentile", "refine_end_using_oscillogram", "frame_calls",
+           "scan_spectrum_for_frequency", "calculate_auto_highpass_filter_freq", "apply_highpass_filter",
+           "savitzky_golay", "detect_calls_framing", "process_full_file", "DEFAULT_FRAMING_CONFIG"]
+
+# the members of DEFAULT_DETECTION_CONFIG (batCallDetector.js:3-45) this stage reads
+DEFAULT_FRAMING_CONFIG = {"minCallDuration_ms": 1, "callThreshold_dB": -24, "hopPercent": 3.125}
+
+
+def calculate_zonal_noise_floors(engine, spectrogram, freq_bins, start_frame, end_frame):
+    """calculateZonalNoiseFloors (batCallDetector.js:1818-1924) -> {zone start in kHz (int): floor dB}."""
+    p = np.ascontiguousarray(spectrogram, dtype=np.float32)
+    fb = _f32(freq_bins)
+    F, B = (p.shape if p.ndim == 2 else (0, fb.size))
+    floors = (C.c_double * 256)()
+    zones = C.c_size_t(0)
+    if end_frame < start_frame:                      # empty range: every zone gets the default (the loop never runs)
+        start_frame, end_frame = 1, 0
+    _check(lib().sono_zonal_noise_floors(engine._handle(), _p(p) if p.size else None, F, B, _p(fb), max(0, int(start_frame)),
+                                         max(0, int(end_frame)), floors, 256, C.byref(zones)))
+    return {10 * z: floors[z] for z in range(zones.value)}
+
+
+def db_percentile(engine, spectrogram, fraction=0.25):
+    """The order statistic detectCalls uses as noise floor (batCallDetector.js:1223-1233)."""
+    p = np.ascontiguousarray(spectrogram, dtype=np.float32).ravel()
+    v = C.c_float(0)
+    _check(lib().sono_db_percentile(engine._handle(), _p(p), p.size, float(fraction), C.byref(v)))
+    return float(v.value)
+
+
+def refine_end_using_oscillogram(audio_data, sample_rate, start_sample, end_sample):
+    """refineEndUsingOscillogram (batCallDetector.js:1646-1803) -> end sample."""
+    x = _f32(audio_data)
+    r = C.c_int64(0)
+    _check(lib().sono_refine_end_oscillogram(_p(x), x.size, float(sample_rate), int(start_sample), int(end_sample), C.byref(r)))
+    return int(r.value)
+
+
+def frame_calls(segments, time_frames, audio_data, sample_rate, fft_size, min_call_duration_ms=None, padding_ms=3.0,
+                full_file_rules=False):
+    """The per-segment part of detectCalls (batCallDetector.js:1128-1208) or, with full_file_rules and
+    padding_ms=5, of processFullFile (batCallDetector.js:739-810) ->
+    [{'startFrame', 'endFrame', 'startTime_s', 'endTime_s', 'duration_ms'}, ...] in the order of `segments`."""
+    if min_call_duration_ms is None:
+        min_call_duration_ms = DEFAULT_FRAMING_CONFIG["minCallDuration_ms"]
+    n = len(segments)
+    if n == 0:
+        return []
+    x = _f32(audio_data)
+    tf = np.ascontiguousarray(time_frames, dtype=np.float64)
+    segs = (_Segment * n)(*[_Segment(int(s["startFrame"]), int(s["endFrame"])) for s in segments])
+    out = (_CallFrame * n)()
+    got = C.c_size_t(0)
+    _check(lib().sono_frame_calls(segs, n, tf.ctypes.data_as(C.POINTER(C.c_double)), tf.size, _p(x), x.size, float(sample_rate),
+                                  int(fft_size), float(padding_ms), float(min_call_duration_ms), 1 if full_file_rules else 0,
+                                  out, n, C.byref(got)))
+    return [{"startFrame": int(out[i].start_frame), "endFrame": int(out[i].end_frame), "startTime_s": out[i].start_time_s,
+             "endTime_s": out[i].end_time_s, "duration_ms": out[i].duration_ms} for i in range(got.value)]
+
+
+def scan_spectrum_for_frequency(spectrum_data, freq_bins, threshold_db, direction):
+    """_scanSpectrumForFrequency (batCallDetector.js:2936-2987) -> {'freq_Hz', 'binIdx'} or None."""
+    row, fb = _f32(spectrum_data), _f32(freq_bins)
+    f, b = C.c_double(0), C.c_int64(0)
+    _check(lib().sono_scan_spectrum_for_frequency(_p(row), _p(fb), row.size, float(threshold_db),
+                                                  1 if direction == "HighToLow" else 0, C.byref(f), C.byref(b)))
+    return None if b.value < 0 else {"freq_Hz": f.value, "binIdx": int(b.value)}
+
+
+def calculate_auto_highpass_filter_freq(peak_freq_khz):
+    """calculateAutoHighpassFilterFreq (batCallDetector.js:4028-4035) -> kHz."""
+    return lib().sono_auto_highpass_khz(float(peak_freq_khz))
+
+
+def apply_highpass_filter(audio_data, filter_freq_hz, sample_rate, order=4):
+    """applyHighpassFilter (batCallDetector.js:4045-4140) -> float32 array."""
+    x = _f32(audio_data)
+    out = np.empty_like(x)
+    _check(lib().sono_highpass_filter(_p(x), x.size, float(filter_freq_hz), float(sample_rate), float(order), _p(out)))
+    return out
+
+
+def savitzky_golay(data):
+    """savitzkyGolay (batCallDetector.js:1610-1640) -> list of floats."""
+    d = np.ascontiguousarray(data, dtype=np.float64)
+    out = np.empty_like(d)
+    dp = C.POINTER(C.c_double)
+    _check(lib().sono_savitzky_golay(d.ctypes.data_as(dp), d.size, out.ctypes.data_as(dp)))
+    return out.tolist()
+
+
+def detect_calls_framing(engine, audio_data, sample_rate, flow_khz, fhigh_khz, config=None, noise_spectrogram=None):
+    """detectCalls (batCallDetector.js:1070-1289) up to the measurement stage ->
+    (calls, zonal_noise_map, noise_floor_dB, spectrogram): calls as frame_calls returns them, each with
+    'noiseFloor_dB'; zonal_noise_map = the map the reference hands to measureFrequencyParameters;
+    noise_floor_dB = max(25th percentile, -80); spectrogram = generate_spectrogram's dict (None if there is none)."""
+    cfg = dict(DEFAULT_FRAMING_CONFIG, **(config or {}))
+    x = _f32(audio_data)
+    sp = _det.generate_spectrogram(engine, x, sample_rate, flow_khz, fhigh_khz, cfg["hopPercent"])
+    if sp is None:
+        return [], {}, None, None
+    p, tf, fb = sp["powerMatrix"], sp["timeFrames"], sp["freqBins"]
+    ns = noise_spectrogram
+    if ns is not None and len(ns["powerMatrix"]) > 0:                                             # js:1086
+        total, first = len(ns["powerMatrix"]), 0
+        if len(ns["timeFrames"]) > 1:
+            per = float(ns["timeFrames"][1] - ns["timeFrames"][0])
+            first = max(0, total - math.ceil(0.005 / per))                                        # js:1093-1098
+        zonal = calculate_zonal_noise_floors(engine, ns["powerMatrix"], ns["freqBins"], first, total - 1)
+    else:
+        zonal = calculate_zonal_noise_floors(engine, p, fb, 0, min(5, len(p) - 1))               # js:1115-1120
+    segments = _det.detect_call_segments(engine, p, cfg["callThreshold_dB"])                       # js:1124
+    if not segments:
+        return [], zonal, None, sp
+    calls = frame_calls(segments, tf, x, sample_rate, engine.get_fft_size(), cfg["minCallDuration_ms"])
+    floor = max(db_percentile(engine, p, 0.25), -80.0)                                             # js:1232-1235
+    for c in calls:
+        c["noiseFloor_dB"] = floor
+    return calls, zonal, floor, sp
+
+
+def process_full_file(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options=None, config=None):
+    """processFullFile (batCallDetector.js:584-840) without the measurement stage: fast scan -> merge & pad ->
+    per region: analysis spectrogram, automatic high-pass, call segments, strongest-first 30 ms echo filter,
+    5 ms padding + oscillogram refinement -> calls in the reference's order (per region, strongest first):
+    {'startTime_s', 'endTime_s', 'duration_ms' (file time), 'peakPower_dB', 'peakTime_s', 'peakFreq_kHz', 'snr_dB'
+    (peak + 80, js:818), 'roi', 'startFrame', 'endFrame', 'highpass_kHz', 'zonalNoiseMap'}.
+    options: {'threshold_dB': -60, 'padding_ms': 5} as in the reference."""
+    opt = dict({"threshold_dB": -60, "padding_ms": 5}, **(options or {}))
+    cfg = dict(DEFAULT_FRAMING_CONFIG, **(config or {}))
+    x = _f32(full_audio_data)
+    raw = _det.fast_scan_segments(engine, x, sample_rate, flow_khz, fhigh_khz, opt["threshold_dB"])          # js:594
+    if not raw:
+        return []
+    merged = _det.merge_and_pad_segments(raw, x.size, sample_rate, opt["padding_ms"])                        # js:601
+    calls = []
+    for roi, seg in enumerate(merged):
+        audio = x[seg["startSample"]:seg["endSample"]]                                                      # js:611
+        spec = _det.generate_spectrogram(engine, audio, sample_rate, flow_khz, fhigh_khz, cfg["hopPercent"])
+        if spec is None:
+            continue
+        power, tf, fb = spec["powerMatrix"], spec["timeFrames"], spec["freqBins"]
+        nb = power.shape[1]
+        zonal = calculate_zonal_noise_floors(engine, power, fb, 0, min(5, len(power) - 1))                  # js:622-627
+        peak_bin, peak_db, _, _ = _det.frame_features(engine, power, 0, nb - 1, 0, np.inf, nb, np.inf)
+        pf = int(np.argmax(peak_db))                                       # first frame holding the region's maximum, js:635-644
+        cutoff = calculate_auto_highpass_filter_freq(float(fb[peak_bin[pf]]) / 1000)                         # js:646-647
+        if cutoff > 0:                                                                                      # js:651-671
+            audio = apply_highpass_filter(audio, cutoff * 1000, sample_rate)
+            again = _det.generate_spectrogram(engine, audio, sample_rate, flow_khz, fhigh_khz, cfg["hopPercent"])
+            if again is not None:
+                power, tf, fb = again["powerMatrix"], again["timeFrames"], again["freqBins"]
+                peak_bin, peak_db, _, _ = _det.frame_features(engine, power, 0, nb - 1, 0, np.inf, nb, np.inf)
+        segments = _det.detect_call_segments(engine, power, cfg["callThreshold_dB"])                         # js:677
+        candidates = []
+        for s in segments:
+            f0, f1 = s["startFrame"], s["endFrame"]
+            if tf[f1] - tf[f0] < cfg["minCallDuration_ms"] / 1000:                                           # js:688-689
+                continue
+            k = f0 + int(np.argmax(peak_db[f0:f1 + 1]))                                                      # js:695-703
+            candidates.append({"seg": s, "peakPower": float(peak_db[k]), "peakTime": float(tf[k]), "peakFrame": k})
+        candidates.sort(key=lambda c: -c["peakPower"])                                                      # stable, js:714
+        kept = []
+        for c in candidates:                                                                                # js:720-734
+            if all(abs(c["peakTime"] - k["peakTime"]) >= 0.030 for k in kept):
+                kept.append(c)
+        offset = seg["startSample"] / sample_rate                                                           # js:737
+        for c in kept:
+            framed = frame_calls([c["seg"]], tf, audio, sample_rate, engine.get_fft_size(), cfg["minCallDuration_ms"],
+                                 padding_ms=5.0, full_file_rules=True)                                      # js:743-810
+            for k in framed:
+                f0, f1 = k["startFrame"], k["endFrame"]
+                kk = f0 + int(np.argmax(peak_db[f0:f1 + 1]))
+                calls.append({
+                    "roi": roi, "startFrame": f0, "endFrame": f1, "startTime_s": k["startTime_s"] + offset,
+                    "endTime_s": k["endTime_s"] + offset, "duration_ms": k["duration_ms"],
+                    "peakPower_dB": float(peak_db[kk]), "peakTime_s": float(tf[kk]) + offset,
+                    "peakFreq_kHz": float(fb[peak_bin[kk]]) / 1000, "snr_dB": float(peak_db[kk]) + 80.0,       # js:818
+                    "highpass_kHz": cutoff, "zonalNoiseMap": zonal,
+                })
+    return calls

@@ -54,14 +54,15 @@ def chunk_samples(frame_range, fft_size, hop):
 
 
 def calls_to_rows(calls, file_id, channel=0):
-    """Candidate calls of detector.process_full_file_front_end -> float64 rows in COLUMNS order."""
+    """Calls of framing.process_full_file (or detector.process_full_file_front_end) -> float64 rows in COLUMNS order."""
     rows = np.full((len(calls), len(COLUMNS)), np.nan, np.float64)
     col = {k: i for i, k in enumerate(COLUMNS)}
     for r, c in enumerate(calls):
         rows[r, col["file"]] = file_id
         rows[r, col["channel"]] = channel
-        for k in ("startTime_s", "endTime_s", "duration_ms", "peakFreq_kHz", "peakPower_dB"):
-            rows[r, col[k]] = c[k]
+        for k in ("startTime_s", "endTime_s", "duration_ms", "peakFreq_kHz", "peakPower_dB", "snr_dB"):
+            if k in c:
+                rows[r, col[k]] = c[k]
         rows[r, col["peakFreq_ms"]] = (c["peakTime_s"] - c["startTime_s"]) * 1000
     return rows
 

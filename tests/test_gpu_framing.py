@@ -1,0 +1,115 @@
+"""The call-framing stage with its matrix passes on the GPU, against the golden
+vectors captured from the reference's JavaScript.  Needs an MI355X: -m gpu."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import spectrogram_amd as sa
+from oracle import framing_oracle as fo
+from spectrogram_amd import detector as det
+from spectrogram_amd import framing as fr
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def golden():
+    g = np.load(os.path.join(HERE, "golden", "golden_framing.npz"))
+    return g, json.loads(bytes(g["__meta__"]).decode())
+
+
+def cases(meta, kind):
+    return [c for c in meta if c["kind"] == kind]
+
+
+def test_zonal_floors_and_percentile_on_the_reference_matrix(golden):
+    # the reference's own dB matrix in, so every count and the order statistic must match exactly
+    g, meta = golden
+    e = sa.SpectrogramEngine(1024, "hann")
+    for c in cases(meta, "zonal"):
+        n = c["name"]
+        F, nb = (int(v) for v in g[n + "/shape"])
+        db, fb = g[n + "/db"].reshape(F, nb), g[n + "/freq"]
+        for f0, f1 in c["ranges"]:
+            got = fr.calculate_zonal_noise_floors(e, db, fb, f0, f1)
+            assert [got[k] for k in sorted(got)] == g[f"{n}/zonal_{f0}_{f1}"].tolist(), (n, f0, f1)
+        assert fr.db_percentile(e, db, 0.25) == float(g[n + "/p25"][0])
+        assert fr.db_percentile(e, db, 0.0) == float(db.min()) and fr.db_percentile(e, db, 1.0) == float(db.max())
+    with pytest.raises(sa.SonoError):
+        fr.db_percentile(e, np.zeros(0, np.float32))
+    e.free()
+
+
+def test_zonal_histogram_at_scale_matches_numpy():
+    rng = np.random.default_rng(5)
+    F, nb = 3000, 400
+    db = (rng.normal(-85, 6, (F, nb)) + np.linspace(0, 25, nb)[None, :]).astype(np.float32)
+    db[5, 7], db[6, 8], db[7, 9] = -np.inf, np.inf, np.nan
+    fb = (np.arange(nb) * 375.0 + 10000).astype(np.float32)
+    e = sa.SpectrogramEngine(1024, "hann")
+    got = fr.calculate_zonal_noise_floors(e, db, fb, 10, 2900)
+    want = fo.zonal_noise_floors(np.nan_to_num(db, nan=-1e9)[:, :], fb, 10, 2900)      # the NaN sits outside the frame range
+    assert [got[k] for k in sorted(got)] == want
+    assert fr.db_percentile(e, db[:5], 0.25) == float(np.sort(db[:5].ravel())[int(5 * nb * 0.25)])
+    e.free()
+
+
+def test_detect_calls_framing_end_to_end(golden):
+    g, meta = golden
+    seen = 0
+    for c in cases(meta, "calls"):
+        n = c["name"]
+        e = sa.SpectrogramEngine(c["fft"], c["window"])
+        cfg = {"hopPercent": c["hop_percent"], "callThreshold_dB": c["call_threshold_db"],
+               "minCallDuration_ms": c["min_call_duration_ms"]}
+        ns = None
+        if n + "/noise" in g.files:
+            ns = det.generate_spectrogram(e, g[n + "/noise"], c["sr"], c["flow_khz"], c["fhigh_khz"], c["hop_percent"])
+        calls, zonal, floor, sp = fr.detect_calls_framing(e, g[n + "/x"], c["sr"], c["flow_khz"], c["fhigh_khz"], cfg, ns)
+        want = g[n + "/calls"].reshape(-1, 6)
+        assert len(calls) == len(want), n
+        for k, w in zip(calls, want):
+            assert (k["startTime_s"], k["endTime_s"], k["duration_ms"]) == (w[0], w[1], w[2]), (n, k, w)     # call boundaries: exact
+            assert abs(k["noiseFloor_dB"] - w[3]) < 1e-3
+            peak = float(sp["powerMatrix"][k["startFrame"]:k["endFrame"] + 1].max())
+            assert abs((peak - floor) - w[4]) < 2e-3
+            seen += 1
+        if len(want):
+            # a dB value within 1e-4 of an integer may fall into the neighbouring 1 dB cell: allow one cell per zone
+            ref = g[n + "/zonal"]
+            got = np.asarray([zonal[k] for k in sorted(zonal)])
+            assert got.shape == ref.shape and np.all(np.abs(got - ref) <= 1.0), (n, got, ref)
+            assert np.mean(got == ref) >= 0.8
+        e.free()
+    assert seen >= 8
+
+
+def test_process_full_file_end_to_end(golden):
+    from spectrogram_amd import sharding as sh
+    g, meta = golden
+    seen = 0
+    for c in cases(meta, "fullfile"):
+        n = c["name"]
+        e = sa.SpectrogramEngine(c["fft"], c["window"])
+        calls = fr.process_full_file(e, g[n + "/x"], c["sr"], c["flow_khz"], c["fhigh_khz"],
+                                     {"threshold_dB": c["scan_threshold_db"], "padding_ms": c["padding_ms"]},
+                                     {"hopPercent": c["hop_percent"], "callThreshold_dB": c["call_threshold_db"],
+                                      "minCallDuration_ms": c["min_call_duration_ms"]})
+        want = g[n + "/calls"].reshape(-1, 5)
+        assert len(calls) == len(want), (n, calls, want)
+        for k, w in zip(calls, want):
+            assert (k["startTime_s"], k["endTime_s"], k["duration_ms"]) == (w[0], w[1], w[2]), (n, k, w)     # exact
+            assert abs(k["snr_dB"] - w[3]) < 2e-3 and k["endFrame"] - k["startFrame"] + 1 == int(w[4])
+            seen += 1
+        if n == "full_file":
+            assert [k["highpass_kHz"] for k in calls] == [30, 25, 20, 0, 30] or sorted(k["highpass_kHz"] for k in calls) == [0, 20, 25, 30, 30]
+            rows = sh.calls_to_rows(calls, file_id=3)
+            col = {k: i for i, k in enumerate(sh.COLUMNS)}
+            assert rows.shape == (len(calls), len(sh.COLUMNS)) and (rows[:, col["file"]] == 3).all()
+            assert np.array_equal(rows[:, col["startTime_s"]], want[:, 0]) and np.array_equal(rows[:, col["snr_dB"]],
+                                                                                             [k["snr_dB"] for k in calls])
+        e.free()
+    assert seen >= 6
