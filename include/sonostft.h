@@ -210,6 +210,17 @@ int sono_frame_features_db(sono_engine *e, const float *power_db, size_t frames,
 
 /* Device-resident building blocks of the four calls above (device pointers,
  * asynchronous on hip_stream or the engine's stream). */
+/* The fast scan's two passes in one launch (batCallDetector.js:894-927): STFT at
+ * `noverlap`, then per frame the sum over bins min_bin..max_bin of the squared
+ * f32 magnitude (accumulated in double), compared with target_energy_sum --
+ * without ever writing the magnitudes.  d_active: one flag per frame (stream s,
+ * frame f at s*frames_per_stream + f); d_band_energy may be NULL.  Requires
+ * max_bin < fft_size/2 (a band that reaches past the last bin makes the
+ * reference read into the next frame's row: use sono_stft_mag_f32_dev +
+ * sono_detect_band_active_dev for that case). */
+int sono_stft_band_active_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap, uint32_t min_bin,
+                              uint32_t max_bin, double target_energy_sum, uint8_t *d_active,
+                              double *d_band_energy /* may be NULL */, void *hip_stream);
 int sono_detect_band_active_dev(sono_engine *e, const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin,
                                 uint32_t max_bin, double target_energy_sum, uint8_t *d_active,
                                 double *d_band_energy /* may be NULL */, void *hip_stream);

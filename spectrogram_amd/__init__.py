@@ -114,6 +114,8 @@ _SIGNATURES = {
                                          C.c_double, C.c_uint32, C.c_double, _ffp, C.c_size_t]),
     "sono_merge_and_pad_segments": (C.c_int, [_segp, C.c_size_t, C.c_uint64, C.c_double, C.c_double, _segp, C.c_size_t,
                                               _szp]),
+    "sono_stft_band_active_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]),
     "sono_detect_band_active_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                               C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sono_detect_power_db_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -359,6 +361,13 @@ class SpectrogramEngine:
         b = Batch(d_samples, n_streams, stream_stride, samples_per_stream)
         _check(lib().sono_stft_features_dev(self._handle(), C.byref(b), int(noverlap), d_peak_bin or None,
                                             d_peak_mag or None, d_gmax_bits or None, stream or None))
+
+    def stft_band_active_dev(self, d_samples, n_streams, stream_stride, samples_per_stream, noverlap, min_bin, max_bin,
+                             target_energy_sum, d_active, d_band_energy=0, stream=0):
+        """The fast scan's STFT + band-energy test in one launch (no magnitude matrix)."""
+        b = Batch(d_samples, n_streams, stream_stride, samples_per_stream)
+        _check(lib().sono_stft_band_active_dev(self._handle(), C.byref(b), int(noverlap), int(min_bin), int(max_bin),
+                                               float(target_energy_sum), d_active, d_band_energy or None, stream or None))
 
     def stft_mag_f32_dev(self, d_samples, n_streams, stream_stride, samples_per_stream, noverlap, d_out, stream=0):
         b = Batch(d_samples, n_streams, stream_stride, samples_per_stream)

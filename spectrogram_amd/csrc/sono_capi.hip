@@ -295,6 +295,34 @@ int sono_stft_features_dev(sono_engine *e, const sono_batch *in, uint32_t noverl
     return SONO_OK;
 }
 
+int sono_stft_band_active_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap, uint32_t min_bin, uint32_t max_bin,
+                              double target_energy_sum, uint8_t *d_active, double *d_band_energy, void *hip_stream)
+{
+    int rc = check_batch(e, in, noverlap, "sono_stft_band_active_dev");
+    if (rc) return rc;
+    sono::StftArgs a;
+    fill_args(e, *in, noverlap, a);
+    if (a.n_streams * a.frames_per_stream == 0) return SONO_OK;
+    if (!d_active) return fail(SONO_EINVAL, "sono_stft_band_active_dev: d_active is NULL");
+    if (max_bin >= e->N / 2 || min_bin > max_bin)
+        return fail(SONO_EINVAL, "sono_stft_band_active_dev: need min_bin <= max_bin < fft_size/2");
+    a.band_lo = min_bin; a.band_hi = max_bin; a.band_target = target_energy_sum;
+    a.band_active = d_active; a.band_energy = d_band_energy;
+    DeviceGuard guard(e->device);
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    if (force_generic() || !sono::tile_supports(sono::MODE_BAND, a, e->tables.tile)) {
+        // the generic kernel has no fused form: magnitudes to a scratch matrix, then the band pass
+        const size_t F = (size_t)(a.n_streams * a.frames_per_stream), B = e->N / 2;
+        HIP_TRY(e->d_mags.reserve(F * B * sizeof(float)));
+        rc = sono_stft_mag_f32_dev(e, in, noverlap, (float *)e->d_mags.p, hip_stream);
+        if (rc) return rc;
+        return sono_detect_band_active_dev(e, (const float *)e->d_mags.p, F, (uint32_t)B, min_bin, max_bin,
+                                           target_energy_sum, d_active, d_band_energy, hip_stream);
+    }
+    HIP_TRY(sono::launch_stft_tile(sono::MODE_BAND, a, e->tables.tile, s));
+    return SONO_OK;
+}
+
 int sono_stft_mag_f32(sono_engine *e, const float *x, size_t n, uint32_t noverlap, float *out,
                       size_t cap, size_t *frames)
 {

@@ -151,14 +151,21 @@ int sono_fast_scan_segments(sono_engine *e, const float *x, size_t n, double sam
     const size_t used = (F - 1) * (size_t)hop + N;
     HIP_TRY(e->d_in.reserve(used * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(e->d_in.p, x, used * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(e->d_mags.reserve(F * bins * sizeof(float)));
     HIP_TRY(e->d_flags.reserve(F));
     sono_batch b{(const float *)e->d_in.p, 1, used, used};
-    int rc = sono_stft_mag_f32_dev(e, &b, noverlap, (float *)e->d_mags.p, nullptr);
-    if (rc) return rc;
-    // a band whose first flat index lies past the frame row still indexes the flat array (js:918-921)
-    rc = sono_detect_band_active_dev(e, (const float *)e->d_mags.p, F, bins, min_bin, max_bin, target,
-                                     (uint8_t *)e->d_flags.p, nullptr, nullptr);
+    int rc;
+    if (max_bin < bins) {
+        // the usual case: one fused launch, the magnitudes never leave the chip
+        rc = sono_stft_band_active_dev(e, &b, noverlap, min_bin, max_bin, target, (uint8_t *)e->d_flags.p, nullptr, nullptr);
+    } else {
+        // a band that reaches the last bin: the reference's flat index runs into the next frame's row (js:918-921),
+        // which needs the whole magnitude matrix
+        HIP_TRY(e->d_mags.reserve(F * bins * sizeof(float)));
+        rc = sono_stft_mag_f32_dev(e, &b, noverlap, (float *)e->d_mags.p, nullptr);
+        if (rc) return rc;
+        rc = sono_detect_band_active_dev(e, (const float *)e->d_mags.p, F, bins, min_bin, max_bin, target,
+                                         (uint8_t *)e->d_flags.p, nullptr, nullptr);
+    }
     if (rc) return rc;
     std::vector<uint64_t> first, last;
     rc = runs_to_host(e, (const uint8_t *)e->d_flags.p, F, first, last);

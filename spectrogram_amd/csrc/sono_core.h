@@ -26,6 +26,8 @@ enum Mode : int {
     MODE_MAG = 0,    // frames x N/2 linear magnitudes           (lib.rs:113-161)
     MODE_U8 = 1,     // frames x N/2 u8 dB codes + peak features (lib.rs:199-304,349-443)
     MODE_POWER = 2,  // frames x (N/2+1) |X|^2 of mean-removed frames (lib.rs:1058-1094)
+    MODE_BAND = 3,   // per frame: sum of mag^2 over a band of bins, compared with a target (batCallDetector.js:913-927);
+                     // tiled kernel only
 };
 
 // Arguments common to the STFT kernels.  Frames are numbered globally:
@@ -50,6 +52,10 @@ struct StftArgs {
     float inv_n;                  // 1/N: |2X| * inv_n = |X| * 2/N (lib.rs:150)
     float q_a, q_c;               // code = trunc(q_a * log2(max(|2X|^2, q_floor)) + q_c), saturated to [0,255]
     float q_floor;
+    unsigned int band_lo, band_hi;   // MODE_BAND: bins band_lo..band_hi (inclusive, band_hi < N/2)
+    double band_target;              // MODE_BAND: a frame is active iff its band energy > band_target
+    uint8_t *band_active;            // MODE_BAND: one flag per frame
+    double *band_energy;             // MODE_BAND, optional: the sums themselves
 };
 
 SONO_HD float2 cadd(float2 a, float2 b) { return float2{a.x + b.x, a.y + b.y}; }

@@ -180,7 +180,13 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
         L.pass2_power(re, im, L.pass2_scale(meta), img);
         wave_lds_fence();
         STAMP(3);
-        L.epilogue(t, it, img, meta, s_zero, peak_slot, LdsMax64());
+        if constexpr (MODE == MODE_BAND) {
+            double e = L.band_sum(img, meta, s_zero);
+            for (int o = G::HALF / 2; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+            L.band_emit(t, it, e);
+        } else {
+            L.epilogue(t, it, img, meta, s_zero, peak_slot, LdsMax64());
+        }
         if (MODE == MODE_U8) {
             wave_lds_fence();
             L.features(t, it, peak_slot);
@@ -274,7 +280,8 @@ void tile_tables_release(TileTables &t) { if (t.d_blob) (void)hipFree(t.d_blob);
 
 bool tile_supports(int mode, const StftArgs &a, const TileTables &t)
 {
-    if (mode != MODE_MAG && mode != MODE_U8) return false;
+    if (mode != MODE_MAG && mode != MODE_U8 && mode != MODE_BAND) return false;
+    if (mode == MODE_BAND && (!a.band_active || a.band_hi >= a.N / 2 || a.band_lo > a.band_hi)) return false;
     if (a.N != 4096 && a.N != 2048 && a.N != 1024 && a.N != 512 && a.N != 256) return false;
     if (!t.d_blob || t.N != a.N) return false;
     const unsigned long long tps = (a.frames_per_stream + 1) / 2;
@@ -287,7 +294,9 @@ bool tile_supports(int mode, const StftArgs &a, const TileTables &t)
 hipError_t launch_stft_tile(int mode, const StftArgs &a, const TileTables &t, hipStream_t stream)
 {
     const float2 *tw_rows = (const float2 *)t.d_blob;
-    return mode == MODE_MAG ? launch_mode<MODE_MAG>(a, tw_rows, stream) : launch_mode<MODE_U8>(a, tw_rows, stream);
+    return mode == MODE_MAG ? launch_mode<MODE_MAG>(a, tw_rows, stream)
+         : mode == MODE_BAND ? launch_mode<MODE_BAND>(a, tw_rows, stream)
+                             : launch_mode<MODE_U8>(a, tw_rows, stream);
 }
 
 }  // namespace sono

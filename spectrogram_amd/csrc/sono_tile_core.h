@@ -464,6 +464,53 @@ struct TileLane {
         }
     }
 
+    // MODE_BAND epilogue, step 1: this lane's share of its frame's band energy --
+    // the sum over its bins k in [band_lo, band_hi] of (double)mag * mag, where mag is
+    // the f32 magnitude MODE_MAG would store, in increasing k.  Step 2 (the caller's):
+    // add up the R1/2 lanes of the frame, pairing lanes l and l ^ o for o = R1/4 ... 1.
+    SONO_HD double band_sum(const float *P, const float *meta, const float *zero_row) const
+    {
+        const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
+        const float nz = meta[kMetaNonZero + frame];
+        const float *row = ((!G::ZERO_ROW || nz != 0.0f) ? P + frame * G::PROW : zero_row) + 4 * l;
+        constexpr int NB = R2 / 4, B = LOG_R2 == 6 ? SONO_EPI_BATCH_WIDE : LOG_R1 == 5 ? SONO_EPI_BATCH : SONO_EPI_BATCH_512;
+        double acc = 0.0;
+        SONO_EPILOGUE_UNROLL
+        for (int m0 = 0; m0 < NB; m0 += B) {
+            float4 p4[B];
+            static_for<0, B>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                p4[i] = *(const float4 *)(row + 2 * G::R1 * (m0 + i));
+            });
+            static_for<0, B>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                const unsigned int k0 = (unsigned int)(4 * l + 2 * G::R1 * (m0 + i));
+                float p[4] = {p4[i].x, p4[i].y, p4[i].z, p4[i].w};
+                if (!G::ZERO_ROW) { p[0] *= nz; p[1] *= nz; p[2] *= nz; p[3] *= nz; }
+                static_for<0, 4>([&](auto r_) {
+                    constexpr int r = decltype(r_)::value;
+                    const double m = (double)(fast_sqrt(p[r]) * a.inv_n);
+                    const double t = m * m;
+                    acc += (k0 + r >= a.band_lo && k0 + r <= a.band_hi) ? t : 0.0;
+                });
+            });
+        }
+        return acc;
+    }
+    // Step 3: the frame's first lane writes the flag (and the sum).
+    SONO_HD void band_emit(unsigned long long tile, const TileIter &it, double total) const
+    {
+        const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
+        if (l != 0) return;
+        const unsigned long long s = tile / it.tiles_per_stream;
+        const unsigned int j = (unsigned int)(tile - s * it.tiles_per_stream);
+        const unsigned long long f = (unsigned long long)j * G::FPW + (unsigned int)frame;
+        if (f >= a.frames_per_stream) return;
+        const unsigned long long g = s * a.frames_per_stream + f;
+        a.band_active[g] = total > a.band_target ? 1 : 0;
+        if (a.band_energy) a.band_energy[g] = total;
+    }
+
     // After every lane of the frame has contributed: the frame's first lane emits
     // the features and clears the slot for the next tile.
     SONO_HD void features(unsigned long long tile, const TileIter &it, unsigned long long *peak_slot) const

@@ -46,6 +46,16 @@ static void run_tiles(const StftArgs &a)
         for (int l = 0; l < 64; ++l) lanes[l].exchange_load(img, im[l]);
         for (int l = 0; l < 64; ++l) g2[l] = lanes[l].pass2_scale(meta);
         for (int l = 0; l < 64; ++l) lanes[l].pass2_power(re[l], im[l], g2[l], img);
+        if (MODE == MODE_BAND) {
+            double e[64], e2[64];
+            for (int l = 0; l < 64; ++l) e[l] = lanes[l].band_sum(img, meta, zero_row.data());
+            for (int o = G::HALF / 2; o > 0; o >>= 1) {
+                for (int l = 0; l < 64; ++l) e2[l] = e[l] + e[l ^ o];
+                std::memcpy(e, e2, sizeof(e));
+            }
+            for (int l = 0; l < 64; ++l) lanes[l].band_emit(t, it, e[l]);
+            continue;
+        }
         for (int l = 0; l < 64; ++l) lanes[l].epilogue(t, it, img, meta, zero_row.data(), &peak[l >> (LOG_R1 - 1)], max64);
         for (int l = 0; l < 64; ++l) lanes[l].features(t, it, &peak[l >> (LOG_R1 - 1)]);
     }
@@ -62,6 +72,16 @@ static void run_tiles(const StftArgs &a)
 static int g_log_r2 = 0;      // 0 = the geometry the kernel launcher picks for N
 extern "C" void emul_tile_set_log_r2(int v) { g_log_r2 = v; }
 
+static unsigned int g_band_lo = 0, g_band_hi = 0;
+static double g_band_target = 0.0;
+static uint8_t *g_band_active = nullptr;
+static double *g_band_energy = nullptr;
+// Parameters of the next emul_tile call with mode 3 (band energy).
+extern "C" void emul_tile_set_band(unsigned int lo, unsigned int hi, double target, uint8_t *active, double *energy)
+{
+    g_band_lo = lo; g_band_hi = hi; g_band_target = target; g_band_active = active; g_band_energy = energy;
+}
+
 extern "C" int emul_tile(int mode, const float *x, unsigned long long n_streams,
                          unsigned long long stream_stride, unsigned long long frames_per_stream,
                          unsigned int hop, unsigned int N, const float *window, float gain_db,
@@ -70,7 +90,7 @@ extern "C" int emul_tile(int mode, const float *x, unsigned long long n_streams,
 {
     (void)out_power;
     if (N != 4096 && N != 2048 && N != 1024 && N != 512 && N != 256) return 1;
-    if (mode != MODE_MAG && mode != MODE_U8) return 1;
+    if (mode != MODE_MAG && mode != MODE_U8 && mode != MODE_BAND) return 1;
     StftArgs a;
     std::memset(&a, 0, sizeof(a));
     a.x = x; a.n_streams = n_streams; a.stream_stride = stream_stride;
@@ -78,9 +98,11 @@ extern "C" int emul_tile(int mode, const float *x, unsigned long long n_streams,
     a.out_mag = out_mag; a.out_u8 = out_u8; a.peak_bin = peak_bin; a.peak_mag = peak_mag;
     a.gmax_bits = gmax_bits;
     a.inv_n = 1.0f / (float)N;
+    a.band_lo = g_band_lo; a.band_hi = g_band_hi; a.band_target = g_band_target;
+    a.band_active = g_band_active; a.band_energy = g_band_energy;
     const Quant q = make_quant(N, gain_db, range_db);
     a.q_a = q.a; a.q_c = q.c; a.q_floor = q.floor;
-#define RUN(L1, L2) do { if (mode == MODE_MAG) run_tiles<L1, L2, MODE_MAG>(a); else run_tiles<L1, L2, MODE_U8>(a); } while (0)
+#define RUN(L1, L2) do { if (mode == MODE_MAG) run_tiles<L1, L2, MODE_MAG>(a); else if (mode == MODE_BAND) run_tiles<L1, L2, MODE_BAND>(a); else run_tiles<L1, L2, MODE_U8>(a); } while (0)
     if (g_log_r2 == 6 && N == 1024) RUN(4, 6);
     else if (g_log_r2 == 6 && N == 512) RUN(3, 6);
     else if (N == 4096) RUN(6, 6); else if (N == 2048) RUN(5, 6); else if (N == 1024) RUN(5, 5); else if (N == 512) RUN(4, 5); else RUN(3, 5);

@@ -108,3 +108,45 @@ def test_front_end_pipeline_matches_oracle_composition():
         assert g["peakFreq_kHz"] == w[5]
         assert abs(g["duration_ms"] - (g["endFrame"] - g["startFrame"]) * 32 / sr * 1000) < 1e-9
     e.free()
+
+
+@pytest.mark.parametrize("N,lo,hi", [(1024, 27, 341), (512, 0, 255), (2048, 100, 900), (4096, 10, 2047), (256, 3, 3)])
+def test_fused_band_energy_equals_the_two_pass_form(N, lo, hi):
+    # sono_stft_band_active_dev (no magnitude matrix) against sono_stft_mag_f32_dev + sono_detect_band_active_dev
+    import ctypes as C
+    import torch
+    V, S = N // 2, 3
+    per = N + 57 * (N - V) + 9
+    stride = per + 5
+    rng = np.random.default_rng(N)
+    buf = np.zeros(S * stride, np.float32)
+    for s in range(S):
+        t = np.arange(per)
+        buf[s * stride: s * stride + per] = (0.2 * np.sin(0.3 * t + 2e-5 * t * t) * (rng.random(per) > 0.3)
+                                             + 0.01 * rng.standard_normal(per)).astype(np.float32)
+    buf[: N + 3 * (N - V)] = 0.0
+    dx = torch.from_numpy(buf).cuda()
+    e = sa.SpectrogramEngine(N, "hann")
+    F = sa.frames_for(per, N, V)
+    T, B = S * F, N // 2
+    mags = torch.zeros(T * B, dtype=torch.float32, device="cuda")
+    act = [torch.full((T,), 9, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    en = [torch.zeros(T, dtype=torch.float64, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    e.stft_mag_f32_dev(dx.data_ptr(), S, stride, per, V, mags.data_ptr(), 0)
+    e.synchronize()
+    m = mags.cpu().numpy().reshape(T, B).astype(np.float64)
+    want = (m[:, lo:hi + 1] ** 2).sum(axis=1)
+    target = float(np.median(want))
+    sa._check(sa.lib().sono_detect_band_active_dev(e._handle(), mags.data_ptr(), T, B, lo, hi, target, act[0].data_ptr(),
+                                                   en[0].data_ptr(), None))
+    e.stft_band_active_dev(dx.data_ptr(), S, stride, per, V, lo, hi, target, act[1].data_ptr(), en[1].data_ptr(), 0)
+    e.synchronize()
+    torch.cuda.synchronize()
+    e0, e1 = en[0].cpu().numpy(), en[1].cpu().numpy()
+    assert np.allclose(e1, want, rtol=1e-12, atol=0) and np.allclose(e0, e1, rtol=1e-12, atol=0)    # same terms, other order
+    assert e1[0] == 0.0 and e1[2] == 0.0
+    assert torch.equal(act[0], act[1]) and 0 < int(act[1].sum()) < T
+    with pytest.raises(sa.SonoError):
+        e.stft_band_active_dev(dx.data_ptr(), S, stride, per, V, lo, B, target, act[1].data_ptr(), 0, 0)
+    e.free()

@@ -197,3 +197,24 @@ def test_tile_wave_alternative_geometry(emul, N, V):
         assert np.array_equal(r["peak_bin"], e.get_peaks(0.0))
     finally:
         emul.emul_tile_set_log_r2(0)
+
+
+@pytest.mark.parametrize("N,V,lo,hi", [(1024, 512, 27, 341), (512, 256, 0, 255), (256, 128, 100, 100), (2048, 1024, 5, 1000),
+                                       (4096, 2048, 300, 2047)])
+def test_tile_wave_band_energy(emul, N, V, lo, hi):
+    # the fused fast-scan mode: per-frame sum of (double)mag^2 over a band, against the oracle's magnitudes
+    H = N - V
+    x = signal(N + 12 * H + 3, N + 5)
+    x[: N + H] = 0.0                                       # the first two frames see only zeros
+    e = so.OracleEngine(N, "hann")
+    F = so.num_frames(len(x), N, V)
+    mags = e.compute_spectrogram(x, V).reshape(F, N // 2).astype(np.float64)
+    want = (mags[:, lo:hi + 1] ** 2).sum(axis=1)
+    target = float(np.median(want))
+    active = np.full(F, 7, np.uint8)
+    energy = np.zeros(F, np.float64)
+    emul.emul_tile_set_band(C.c_uint(lo), C.c_uint(hi), C.c_double(target), _p(active), _p(energy))
+    run_emul(emul, "emul_tile", 3, x, N, V, e.window)
+    assert energy[0] == 0.0 and energy[1] == 0.0
+    assert np.allclose(energy, want, rtol=3e-4, atol=0)    # f32 magnitudes agree to 1e-4
+    assert np.array_equal(active, (energy > target).astype(np.uint8))
