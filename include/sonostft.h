@@ -210,6 +210,28 @@ int sono_frame_features_db(sono_engine *e, const float *power_db, size_t frames,
 
 /* Device-resident building blocks of the four calls above (device pointers,
  * asynchronous on hip_stream or the engine's stream). */
+/* ---- ragged batches: recordings of different lengths in one launch ------------ */
+
+typedef struct sono_ragged_batch {
+    const float *d_samples;     /* device: stream s starts at d_samples + offsets[s] */
+    size_t n_streams;
+    const uint64_t *offsets;    /* host, n_streams entries (samples) */
+    const uint64_t *lengths;    /* host, n_streams entries (samples); shorter than fft_size = no frames */
+} sono_ragged_batch;
+
+/* Row layout of a ragged batch: row0[s] = first output row of stream s (rows of
+ * all streams are contiguous, in stream order), row0[n_streams] = total frames.
+ * row0: n_streams + 1 entries.  Host only. */
+int sono_ragged_rows(const uint64_t *lengths, size_t n_streams, uint32_t fft_size, uint32_t noverlap, uint64_t *row0);
+
+/* sono_stft_u8_dev / sono_stft_mag_f32_dev over a ragged batch.  Output rows as
+ * sono_ragged_rows lays them out; everything else as in the uniform forms. */
+int sono_stft_u8_ragged_dev(sono_engine *e, const sono_ragged_batch *in, uint32_t noverlap, float gain_db,
+                            float range_db, uint8_t *d_out /* may be NULL: features only */, uint16_t *d_peak_bin,
+                            float *d_peak_mag, uint32_t *d_gmax_bits, void *hip_stream);
+int sono_stft_mag_f32_ragged_dev(sono_engine *e, const sono_ragged_batch *in, uint32_t noverlap, float *d_out,
+                                 void *hip_stream);
+
 /* The fast scan's two passes in one launch (batCallDetector.js:894-927): STFT at
  * `noverlap`, then per frame the sum over bins min_bin..max_bin of the squared
  * f32 magnitude (accumulated in double), compared with target_energy_sum --

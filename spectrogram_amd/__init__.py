@@ -45,6 +45,12 @@ class Batch(C.Structure):
                 ("stream_stride", C.c_size_t), ("samples_per_stream", C.c_size_t)]
 
 
+class RaggedBatch(C.Structure):
+    """struct sono_ragged_batch."""
+    _fields_ = [("d_samples", C.c_void_p), ("n_streams", C.c_size_t), ("offsets", C.POINTER(C.c_uint64)),
+                ("lengths", C.POINTER(C.c_uint64))]
+
+
 class Segment(C.Structure):
     """struct sono_segment."""
     _fields_ = [("start", C.c_uint64), ("end", C.c_uint64)]
@@ -114,6 +120,10 @@ _SIGNATURES = {
                                          C.c_double, C.c_uint32, C.c_double, _ffp, C.c_size_t]),
     "sono_merge_and_pad_segments": (C.c_int, [_segp, C.c_size_t, C.c_uint64, C.c_double, C.c_double, _segp, C.c_size_t,
                                               _szp]),
+    "sono_ragged_rows": (C.c_int, [C.POINTER(C.c_uint64), C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "sono_stft_u8_ragged_dev": (C.c_int, [C.c_void_p, C.POINTER(RaggedBatch), C.c_uint32, C.c_float, C.c_float, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sono_stft_mag_f32_ragged_dev": (C.c_int, [C.c_void_p, C.POINTER(RaggedBatch), C.c_uint32, C.c_void_p, C.c_void_p]),
     "sono_stft_band_active_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_uint32, C.c_uint32, C.c_double,
                                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "sono_detect_band_active_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -362,6 +372,19 @@ class SpectrogramEngine:
         _check(lib().sono_stft_features_dev(self._handle(), C.byref(b), int(noverlap), d_peak_bin or None,
                                             d_peak_mag or None, d_gmax_bits or None, stream or None))
 
+    def stft_u8_ragged_dev(self, d_samples, offsets, lengths, noverlap, gain_db, range_db, d_out=0, d_peak_bin=0,
+                           d_peak_mag=0, d_gmax_bits=0, stream=0):
+        """stft_u8_dev over streams of different lengths: stream s = samples [offsets[s], offsets[s] + lengths[s]) of
+        d_samples.  Rows are laid out as ragged_rows() says.  d_out = 0: features only."""
+        off, ln, b = _ragged(d_samples, offsets, lengths)
+        _check(lib().sono_stft_u8_ragged_dev(self._handle(), C.byref(b), int(noverlap), float(gain_db), float(range_db),
+                                             d_out or None, d_peak_bin or None, d_peak_mag or None, d_gmax_bits or None,
+                                             stream or None))
+
+    def stft_mag_f32_ragged_dev(self, d_samples, offsets, lengths, noverlap, d_out, stream=0):
+        off, ln, b = _ragged(d_samples, offsets, lengths)
+        _check(lib().sono_stft_mag_f32_ragged_dev(self._handle(), C.byref(b), int(noverlap), d_out, stream or None))
+
     def stft_band_active_dev(self, d_samples, n_streams, stream_stride, samples_per_stream, noverlap, min_bin, max_bin,
                              target_energy_sum, d_active, d_band_energy=0, stream=0):
         """The fast scan's STFT + band-energy test in one launch (no magnitude matrix)."""
@@ -375,6 +398,24 @@ class SpectrogramEngine:
 
     def synchronize(self):
         _check(lib().sono_engine_synchronize(self._handle()))
+
+
+def _ragged(d_samples, offsets, lengths):
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+    if off.shape != ln.shape or off.ndim != 1:
+        raise ValueError("offsets and lengths must be 1-D arrays of the same length")
+    u64p = C.POINTER(C.c_uint64)
+    return off, ln, RaggedBatch(d_samples, off.size, off.ctypes.data_as(u64p), ln.ctypes.data_as(u64p))
+
+
+def ragged_rows(lengths, fft_size, noverlap):
+    """First output row of every stream of a ragged batch, and the total: n + 1 values (sono_ragged_rows)."""
+    ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+    out = np.zeros(ln.size + 1, np.uint64)
+    u64p = C.POINTER(C.c_uint64)
+    _check(lib().sono_ragged_rows(ln.ctypes.data_as(u64p), ln.size, int(fft_size), int(noverlap), out.ctypes.data_as(u64p)))
+    return out
 
 
 class WaveformEngine:

@@ -295,6 +295,116 @@ int sono_stft_features_dev(sono_engine *e, const sono_batch *in, uint32_t noverl
     return SONO_OK;
 }
 
+int sono_ragged_rows(const uint64_t *lengths, size_t n_streams, uint32_t fft_size, uint32_t noverlap, uint64_t *row0)
+{
+    if (!row0 || (n_streams && !lengths)) return fail(SONO_EINVAL, "sono_ragged_rows: NULL argument");
+    if (fft_size == 0 || noverlap >= fft_size) return fail(SONO_EINVAL, "sono_ragged_rows: noverlap must be < fft_size");
+    uint64_t rows = 0;
+    for (size_t s = 0; s < n_streams; ++s) {
+        row0[s] = rows;
+        rows += sono_frames_for((size_t)lengths[s], fft_size, noverlap);
+    }
+    row0[n_streams] = rows;
+    return SONO_OK;
+}
+
+namespace {
+
+// Builds and uploads the per-stream / per-tile tables of a ragged launch and runs it.  Where the tiled
+// kernel cannot take the launch (forced generic kernel, unaligned output), every stream gets a launch
+// of its own through the usual dispatch.
+int run_ragged(sono_engine *e, const sono_ragged_batch *in, uint32_t noverlap, int mode, sono::StftArgs &a, void *hip_stream,
+               const char *who)
+{
+    if (!e || !in) return fail(SONO_EINVAL, std::string(who) + ": NULL argument");
+    if (noverlap >= e->N) return fail(SONO_EINVAL, std::string(who) + ": noverlap must be < fft_size");
+    if (in->n_streams && (!in->offsets || !in->lengths || !in->d_samples))
+        return fail(SONO_EINVAL, std::string(who) + ": NULL stream table or samples");
+    const uint32_t N = e->N, B = N / 2;
+    const unsigned int fpw = sono::tile_frames_per_wave(N);
+    DeviceGuard guard(e->device);
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    a.x = in->d_samples;
+    a.n_streams = 0; a.stream_stride = 0; a.frames_per_stream = 0;
+    const bool tiled = fpw && !force_generic() &&
+                       [&] { sono::StftArgs p = a; p.frames_per_stream = 2; return sono::tile_supports(mode, p, e->tables.tile); }();
+    e->ragged_streams.clear();
+    e->ragged_tile_stream.clear();
+    unsigned long long rows = 0, tiles = 0;
+    for (size_t i = 0; i < in->n_streams; ++i) {
+        const unsigned long long F = sono_frames_for((size_t)in->lengths[i], N, noverlap);
+        if (tiled) {
+            const unsigned long long t = (F + fpw - 1) / fpw;
+            if (tiles + t >= 0xFFFFFFFFull || in->n_streams >= 0xFFFFFFFFull)
+                return fail(SONO_EINVAL, std::string(who) + ": more than 2^32 - 1 tiles or streams in one launch");
+            e->ragged_streams.push_back({in->offsets[i], F, rows, tiles});
+            e->ragged_tile_stream.insert(e->ragged_tile_stream.end(), (size_t)t, (unsigned int)i);
+            tiles += t;
+        } else if (F) {
+            sono::StftArgs one = a;
+            one.x = in->d_samples + in->offsets[i];
+            one.n_streams = 1; one.stream_stride = in->lengths[i]; one.frames_per_stream = F;
+            if (one.out_mag) one.out_mag += rows * B;
+            if (one.out_u8) one.out_u8 += rows * B;
+            if (one.peak_bin) one.peak_bin += rows;
+            if (one.peak_mag) one.peak_mag += rows;
+            HIP_TRY(dispatch_stft(mode, one, e->tables, s));
+        }
+        rows += F;
+    }
+    if (!tiled || tiles == 0) return SONO_OK;
+    const size_t sb = e->ragged_streams.size() * sizeof(sono::RaggedStreamEntry);
+    const size_t tb = e->ragged_tile_stream.size() * sizeof(unsigned int);
+    HIP_TRY(e->d_ragged.reserve(sb + tb));
+    HIP_TRY(hipMemcpyAsync(e->d_ragged.p, e->ragged_streams.data(), sb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync((char *)e->d_ragged.p + sb, e->ragged_tile_stream.data(), tb, hipMemcpyHostToDevice, s));
+    sono::RaggedPlan plan;
+    plan.n_tiles = tiles;
+    plan.d_streams = (const sono::RaggedStreamEntry *)e->d_ragged.p;
+    plan.d_tile_stream = (const unsigned int *)((const char *)e->d_ragged.p + sb);
+    HIP_TRY(sono::launch_stft_tile_ragged(mode, a, e->tables.tile, plan, s));
+    return SONO_OK;
+}
+
+void fill_common(const sono_engine *e, uint32_t noverlap, sono::StftArgs &a)
+{
+    std::memset(&a, 0, sizeof(a));
+    a.hop = e->N - noverlap;
+    a.N = e->N;
+    a.window = e->tables.d_window;
+    a.tw_half = e->tables.d_tw_half;
+    a.tw_full = e->tables.d_tw_full;
+    a.inv_n = 1.0f / (float)e->N;
+}
+
+}  // namespace
+
+int sono_stft_u8_ragged_dev(sono_engine *e, const sono_ragged_batch *in, uint32_t noverlap, float gain_db, float range_db,
+                            uint8_t *d_out, uint16_t *d_peak_bin, float *d_peak_mag, uint32_t *d_gmax_bits, void *hip_stream)
+{
+    if (!e) return fail(SONO_EINVAL, "sono_stft_u8_ragged_dev: NULL engine");
+    if (noverlap >= e->N) return fail(SONO_EINVAL, "sono_stft_u8_ragged_dev: noverlap must be < fft_size");
+    if (!d_out && !d_peak_bin && !d_peak_mag && !d_gmax_bits)
+        return fail(SONO_EINVAL, "sono_stft_u8_ragged_dev: every output is NULL");
+    sono::StftArgs a;
+    fill_common(e, noverlap, a);
+    const sono::Quant q = sono::make_quant(e->N, gain_db, range_db);
+    a.out_u8 = d_out; a.peak_bin = d_peak_bin; a.peak_mag = d_peak_mag; a.gmax_bits = d_gmax_bits;
+    a.q_a = q.a; a.q_c = q.c; a.q_floor = q.floor;
+    return run_ragged(e, in, noverlap, sono::MODE_U8, a, hip_stream, "sono_stft_u8_ragged_dev");
+}
+
+int sono_stft_mag_f32_ragged_dev(sono_engine *e, const sono_ragged_batch *in, uint32_t noverlap, float *d_out, void *hip_stream)
+{
+    if (!e) return fail(SONO_EINVAL, "sono_stft_mag_f32_ragged_dev: NULL engine");
+    if (noverlap >= e->N) return fail(SONO_EINVAL, "sono_stft_mag_f32_ragged_dev: noverlap must be < fft_size");
+    if (!d_out) return fail(SONO_EINVAL, "sono_stft_mag_f32_ragged_dev: d_out is NULL");
+    sono::StftArgs a;
+    fill_common(e, noverlap, a);
+    a.out_mag = d_out;
+    return run_ragged(e, in, noverlap, sono::MODE_MAG, a, hip_stream, "sono_stft_mag_f32_ragged_dev");
+}
+
 int sono_stft_band_active_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap, uint32_t min_bin, uint32_t max_bin,
                               double target_energy_sum, uint8_t *d_active, double *d_band_energy, void *hip_stream)
 {

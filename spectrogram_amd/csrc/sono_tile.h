@@ -16,11 +16,33 @@ struct TileTables {
 hipError_t tile_tables_build(unsigned int N, TileTables &t);
 void tile_tables_release(TileTables &t);
 
-// True when the tiled kernel can run this launch: fft size 256/512/1024, mode
-// MAG or U8, output rows aligned for its 16-byte (MAG) / 4-byte (U8) stores.
+// True when the tiled kernel can run this launch: fft size 256 ... 4096, mode MAG, U8
+// or BAND, output rows aligned for its 16-byte (MAG) / 4-byte (U8) stores.
 // Samples are read one float per lane, so any hop and sample alignment works.
 bool tile_supports(int mode, const StftArgs &a, const TileTables &t);
 
 hipError_t launch_stft_tile(int mode, const StftArgs &a, const TileTables &t, hipStream_t stream);
+
+// ---- ragged batches: streams of different lengths in one launch -----------------
+// Frames one wave of the tiled kernel handles at fft size N (0 = size not covered): the unit in
+// which a stream's tiles are counted (tiles never straddle streams).
+unsigned int tile_frames_per_wave(unsigned int N);
+
+// One entry per stream, in device memory (same layout as the kernel's own view).
+struct RaggedStreamEntry {
+    unsigned long long sample_offset;  // first sample of the stream, relative to StftArgs::x
+    unsigned long long frames;         // frames of the stream
+    unsigned long long row0;           // output row of its frame 0
+    unsigned long long tile0;          // index of its first tile = sum of ceil(frames / frames_per_wave) of the streams before
+};
+struct RaggedPlan {
+    unsigned long long n_tiles;
+    const RaggedStreamEntry *d_streams;     // device, one per stream
+    const unsigned int *d_tile_stream;      // device, n_tiles entries: the stream of every tile
+};
+// StftArgs::n_streams / stream_stride / frames_per_stream are not used; the alignment rules of
+// tile_supports apply to the output base pointers.
+hipError_t launch_stft_tile_ragged(int mode, const StftArgs &a, const TileTables &t, const RaggedPlan &plan,
+                                   hipStream_t stream);
 
 }  // namespace sono

@@ -97,7 +97,8 @@ __device__ __forceinline__ float column_max(float v)
     return v;
 }
 
-template <int LOG_R1, int LOG_R2, int MODE>
+// RAGGED: streams of different lengths, located through TileIter's tables.
+template <int LOG_R1, int LOG_R2, int MODE, bool RAGGED>
 __global__ __launch_bounds__(64 * Occupancy<LOG_R2>::kWavesPerBlock, Occupancy<LOG_R2>::kWavesPerSimd)
 void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *tw_rows)
 {
@@ -156,10 +157,11 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
     while (cur < t_count) {
         const unsigned long long t = t_first + cur;
         const unsigned long long nxt = claim();           // returns while this tile is being worked on
+        const tile::TileRef tr = tile::locate<RAGGED>(a, it, t);
         float re[R2], im[R2];
         {
             float rr[R2], ri[R2];
-            L.load(t, it);
+            L.load(tr);
             STAMP(0);
             float ma[G::JPL], mb[G::JPL];
             L.scan(ma, mb);
@@ -183,13 +185,13 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
         if constexpr (MODE == MODE_BAND) {
             double e = L.band_sum(img, meta, s_zero);
             for (int o = G::HALF / 2; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
-            L.band_emit(t, it, e);
+            L.band_emit(tr, e);
         } else {
-            L.epilogue(t, it, img, meta, s_zero, peak_slot, LdsMax64());
+            L.epilogue(tr, img, meta, s_zero, peak_slot, LdsMax64());
         }
         if (MODE == MODE_U8) {
             wave_lds_fence();
-            L.features(t, it, peak_slot);
+            L.features(tr, peak_slot);
         }
         wave_lds_fence();
         STAMP(4);
@@ -217,15 +219,24 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
 }
 
 template <int LOG_R1, int LOG_R2, int MODE>
-hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, hipStream_t stream)
+hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, hipStream_t stream)
 {
     using G = tile::Geo<LOG_R1, LOG_R2>;
     constexpr int kWavesPerBlock = Occupancy<LOG_R2>::kWavesPerBlock;
     constexpr int kBlocksPerCU = Occupancy<LOG_R2>::kBlocksPerCU;
     tile::TileIter it;
-    const unsigned long long tps = (a.frames_per_stream + G::FPW - 1) / G::FPW;
-    it.tiles_per_stream = (unsigned int)tps;
-    it.n_tiles = a.n_streams * tps;
+    if (plan) {
+        it.tiles_per_stream = 0;
+        it.n_tiles = plan->n_tiles;
+        it.streams = (const tile::RaggedStream *)plan->d_streams;
+        it.tile_stream = plan->d_tile_stream;
+    } else {
+        const unsigned long long tps = (a.frames_per_stream + G::FPW - 1) / G::FPW;
+        it.tiles_per_stream = (unsigned int)tps;
+        it.n_tiles = a.n_streams * tps;
+        it.streams = nullptr;
+        it.tile_stream = nullptr;
+    }
     if (it.n_tiles == 0) return hipSuccess;
     int dev = 0, cus = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -235,22 +246,33 @@ hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, hipStream_t stre
     unsigned long long blocks = (it.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const unsigned long long resident = (unsigned long long)cus * kBlocksPerCU;
     if (blocks > resident) blocks = resident;
-    hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE>), dim3((unsigned int)blocks), dim3(64 * kWavesPerBlock), 0,
-                       stream, a, it, tw_rows);
+    const dim3 grid((unsigned int)blocks), block(64 * kWavesPerBlock);
+    if (plan)
+        hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, true>), grid, block, 0, stream, a, it, tw_rows);
+    else
+        hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false>), grid, block, 0, stream, a, it, tw_rows);
     return hipGetLastError();
 }
 
 template <int MODE>
-hipError_t launch_mode(const StftArgs &a, const float2 *tw_rows, hipStream_t stream)
+hipError_t launch_mode(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, hipStream_t stream)
 {
     switch (a.N) {
-    case 4096: return launch_one<6, 6, MODE>(a, tw_rows, stream);
-    case 2048: return launch_one<5, 6, MODE>(a, tw_rows, stream);
-    case 1024: return launch_one<10 - tile_log_r2(1024), tile_log_r2(1024), MODE>(a, tw_rows, stream);
-    case 512: return launch_one<9 - tile_log_r2(512), tile_log_r2(512), MODE>(a, tw_rows, stream);
-    case 256: return launch_one<3, 5, MODE>(a, tw_rows, stream);
+    case 4096: return launch_one<6, 6, MODE>(a, tw_rows, plan, stream);
+    case 2048: return launch_one<5, 6, MODE>(a, tw_rows, plan, stream);
+    case 1024: return launch_one<10 - tile_log_r2(1024), tile_log_r2(1024), MODE>(a, tw_rows, plan, stream);
+    case 512: return launch_one<9 - tile_log_r2(512), tile_log_r2(512), MODE>(a, tw_rows, plan, stream);
+    case 256: return launch_one<3, 5, MODE>(a, tw_rows, plan, stream);
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_any(int mode, const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream)
+{
+    const float2 *tw_rows = (const float2 *)t.d_blob;
+    return mode == MODE_MAG ? launch_mode<MODE_MAG>(a, tw_rows, plan, stream)
+         : mode == MODE_BAND ? launch_mode<MODE_BAND>(a, tw_rows, plan, stream)
+                             : launch_mode<MODE_U8>(a, tw_rows, plan, stream);
 }
 
 }  // namespace
@@ -293,10 +315,27 @@ bool tile_supports(int mode, const StftArgs &a, const TileTables &t)
 
 hipError_t launch_stft_tile(int mode, const StftArgs &a, const TileTables &t, hipStream_t stream)
 {
-    const float2 *tw_rows = (const float2 *)t.d_blob;
-    return mode == MODE_MAG ? launch_mode<MODE_MAG>(a, tw_rows, stream)
-         : mode == MODE_BAND ? launch_mode<MODE_BAND>(a, tw_rows, stream)
-                             : launch_mode<MODE_U8>(a, tw_rows, stream);
+    return launch_any(mode, a, t, nullptr, stream);
+}
+
+unsigned int tile_frames_per_wave(unsigned int N)
+{
+    switch (N) {
+    case 4096: return tile::Geo<6, 6>::FPW;
+    case 2048: return tile::Geo<5, 6>::FPW;
+    case 1024: return tile::Geo<10 - tile_log_r2(1024), tile_log_r2(1024)>::FPW;
+    case 512: return tile::Geo<9 - tile_log_r2(512), tile_log_r2(512)>::FPW;
+    case 256: return tile::Geo<3, 5>::FPW;
+    default: return 0;
+    }
+}
+
+static_assert(sizeof(RaggedStreamEntry) == sizeof(tile::RaggedStream), "host and kernel views of a stream entry differ");
+
+hipError_t launch_stft_tile_ragged(int mode, const StftArgs &a, const TileTables &t, const RaggedPlan &plan,
+                                   hipStream_t stream)
+{
+    return launch_any(mode, a, t, &plan, stream);
 }
 
 }  // namespace sono

@@ -210,13 +210,50 @@ SONO_HD int float_exponent(float v) { int e = 0; (void)std::frexp(v, &e); return
 SONO_HD float pow2(int e) { return std::ldexp(1.0f, e); }
 #endif
 
-// Per-launch tile walk.  Tiles never straddle streams: stream s owns tiles
-// [s*tps, (s+1)*tps); tile j of a stream covers its frames j*FPW .. j*FPW+FPW-1
-// (the last tile of a stream may be partial).
-struct TileIter {
-    unsigned int tiles_per_stream;     // ceil(frames_per_stream / FPW)
-    unsigned long long n_tiles;        // n_streams * tiles_per_stream
+// Per-launch tile walk.  Tiles never straddle streams; tile j of a stream covers
+// its frames j*FPW .. j*FPW+FPW-1 (the last tile of a stream may be partial).
+// Uniform batch: every stream has frames_per_stream frames and stream_stride
+// samples between starts; stream s owns tiles [s*tps, (s+1)*tps).  Ragged batch:
+// every stream has its own start, frame count and first output row; a per-tile
+// table names the stream of each tile.
+struct RaggedStream {
+    unsigned long long sample_offset;  // first sample of the stream, relative to StftArgs::x
+    unsigned long long frames;         // frames of the stream (0 if it is shorter than a frame)
+    unsigned long long row0;           // output row of its frame 0 (rows of all streams are contiguous, in stream order)
+    unsigned long long tile0;          // index of its first tile
 };
+struct TileIter {
+    unsigned int tiles_per_stream;     // uniform: ceil(frames_per_stream / FPW)
+    unsigned long long n_tiles;        // tiles of the launch
+    const RaggedStream *streams;       // ragged: one per stream (device memory); nullptr for a uniform batch
+    const unsigned int *tile_stream;   // ragged: stream of every tile (device memory)
+};
+// Where one tile reads and writes.
+struct TileRef {
+    const float *xs;                   // sample 0 of the tile's stream
+    unsigned long long frames;         // frames of that stream
+    unsigned long long row0;           // output row of the stream's frame 0
+    unsigned int j;                    // the tile's index inside the stream
+};
+template <bool RAGGED>
+SONO_HD TileRef locate(const StftArgs &a, const TileIter &it, unsigned long long tile)
+{
+    TileRef r;
+    if (RAGGED) {
+        const RaggedStream st = it.streams[it.tile_stream[tile]];
+        r.xs = a.x + st.sample_offset;
+        r.frames = st.frames;
+        r.row0 = st.row0;
+        r.j = (unsigned int)(tile - st.tile0);
+    } else {
+        const unsigned long long s = tile / it.tiles_per_stream;
+        r.xs = a.x + s * a.stream_stride;
+        r.frames = a.frames_per_stream;
+        r.row0 = s * a.frames_per_stream;
+        r.j = (unsigned int)(tile - s * it.tiles_per_stream);
+    }
+    return r;
+}
 
 // ---- one lane of one wave ------------------------------------------------------
 template <int LOG_R1, int LOG_R2, int MODE>
@@ -236,18 +273,17 @@ struct TileLane {
 
     // Issues the loads of `tile` (pass-1 lane layout).  Frames past the end of a
     // stream re-read the stream's frame 0; their results are never stored.
-    SONO_HD void load(unsigned long long tile, const TileIter &it)
+    SONO_HD void load(const TileRef &tr)
     {
-        const unsigned long long s = tile / it.tiles_per_stream;
-        const unsigned int j = (unsigned int)(tile - s * it.tiles_per_stream);
+        const unsigned int j = tr.j;
         const int h = hgroup(), n2 = col();
-        const float *xs = a.x + s * a.stream_stride + n2;
+        const float *xs = tr.xs + n2;
         static_for<0, G::JPL>([&](auto jj_) {
             constexpr int jj = decltype(jj_)::value;
             unsigned long long fa = (unsigned long long)j * G::FPW + (unsigned int)(2 * (h * G::JPL + jj));
             unsigned long long fb = fa + 1;
-            if (fa >= a.frames_per_stream) fa = 0;
-            if (fb >= a.frames_per_stream) fb = 0;
+            if (fa >= tr.frames) fa = 0;
+            if (fb >= tr.frames) fb = 0;
             const float *pa = xs + fa * a.hop, *pb = xs + fb * a.hop;
             static_for<0, G::R1>([&](auto n_) {
                 constexpr int n1 = decltype(n_)::value;
@@ -402,15 +438,13 @@ struct TileLane {
     // frame (only where Geo::ZERO_ROW).  `peak_slot` is the LDS word of the lane's
     // frame (ordering key of its largest |2X|^2).
     template <typename AtomicMax64>
-    SONO_HD void epilogue(unsigned long long tile, const TileIter &it, const float *P, const float *meta,
+    SONO_HD void epilogue(const TileRef &tr, const float *P, const float *meta,
                           const float *zero_row, unsigned long long *peak_slot, AtomicMax64 atomic_max64)
     {
-        const unsigned long long s = tile / it.tiles_per_stream;
-        const unsigned int j = (unsigned int)(tile - s * it.tiles_per_stream);
         const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
-        const unsigned long long f = (unsigned long long)j * G::FPW + (unsigned int)frame;
-        const bool valid = f < a.frames_per_stream;
-        const unsigned long long g = s * a.frames_per_stream + f;
+        const unsigned long long f = (unsigned long long)tr.j * G::FPW + (unsigned int)frame;
+        const bool valid = f < tr.frames;
+        const unsigned long long g = tr.row0 + f;
         const float nz = meta[kMetaNonZero + frame];
         const float *row = ((!G::ZERO_ROW || nz != 0.0f) ? P + frame * G::PROW : zero_row) + 4 * l;
         // Peak search: per group of four bins only the group's maximum is compared
@@ -498,32 +532,28 @@ struct TileLane {
         return acc;
     }
     // Step 3: the frame's first lane writes the flag (and the sum).
-    SONO_HD void band_emit(unsigned long long tile, const TileIter &it, double total) const
+    SONO_HD void band_emit(const TileRef &tr, double total) const
     {
         const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
         if (l != 0) return;
-        const unsigned long long s = tile / it.tiles_per_stream;
-        const unsigned int j = (unsigned int)(tile - s * it.tiles_per_stream);
-        const unsigned long long f = (unsigned long long)j * G::FPW + (unsigned int)frame;
-        if (f >= a.frames_per_stream) return;
-        const unsigned long long g = s * a.frames_per_stream + f;
+        const unsigned long long f = (unsigned long long)tr.j * G::FPW + (unsigned int)frame;
+        if (f >= tr.frames) return;
+        const unsigned long long g = tr.row0 + f;
         a.band_active[g] = total > a.band_target ? 1 : 0;
         if (a.band_energy) a.band_energy[g] = total;
     }
 
     // After every lane of the frame has contributed: the frame's first lane emits
     // the features and clears the slot for the next tile.
-    SONO_HD void features(unsigned long long tile, const TileIter &it, unsigned long long *peak_slot) const
+    SONO_HD void features(const TileRef &tr, unsigned long long *peak_slot) const
     {
         const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
         if (MODE != MODE_U8 || l != 0) return;
-        const unsigned long long s = tile / it.tiles_per_stream;
-        const unsigned int j = (unsigned int)(tile - s * it.tiles_per_stream);
-        const unsigned long long f = (unsigned long long)j * G::FPW + (unsigned int)frame;
+        const unsigned long long f = (unsigned long long)tr.j * G::FPW + (unsigned int)frame;
         const unsigned long long key = *peak_slot;
         *peak_slot = peak_key(0.0f, 0u);
-        if (f >= a.frames_per_stream) return;
-        const unsigned long long g = s * a.frames_per_stream + f;
+        if (f >= tr.frames) return;
+        const unsigned long long g = tr.row0 + f;
         unsigned int bits = (unsigned int)(key >> 32);
         float pmax;
 #if defined(__HIP_DEVICE_COMPILE__)

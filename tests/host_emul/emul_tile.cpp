@@ -10,6 +10,9 @@
 
 using namespace sono;
 
+static int g_ragged = 0;      // 1 = walk the tiles through the ragged-batch tables
+extern "C" void emul_tile_set_ragged(int v) { g_ragged = v; }
+
 template <int LOG_R1, int LOG_R2, int MODE>
 static void run_tiles(const StftArgs &a)
 {
@@ -20,6 +23,19 @@ static void run_tiles(const StftArgs &a)
     const unsigned long long tps = (a.frames_per_stream + G::FPW - 1) / G::FPW;
     it.tiles_per_stream = (unsigned int)tps;
     it.n_tiles = a.n_streams * tps;
+    it.streams = nullptr;
+    it.tile_stream = nullptr;
+    // ragged form of the same batch (every stream gets its own table entry): must give identical results
+    std::vector<tile::RaggedStream> rs;
+    std::vector<unsigned int> ts;
+    if (g_ragged) {
+        for (unsigned long long s = 0; s < a.n_streams; ++s) {
+            rs.push_back({s * a.stream_stride, a.frames_per_stream, s * a.frames_per_stream, s * tps});
+            for (unsigned long long j = 0; j < tps; ++j) ts.push_back((unsigned int)s);
+        }
+        it.streams = rs.data();
+        it.tile_stream = ts.data();
+    }
     const std::vector<float2> tw = make_tile_twiddles(a.N, R2);
     alignas(16) static float img[G::REGION];
     unsigned long long peak[16];
@@ -31,7 +47,8 @@ static void run_tiles(const StftArgs &a)
     float meta[tile::kMetaFloats];
     const std::vector<float> zero_row(G::BINS, 0.0f);
     for (unsigned long long t = 0; t < it.n_tiles; ++t) {
-        for (int l = 0; l < 64; ++l) lanes[l].load(t, it);
+        const tile::TileRef tr = g_ragged ? tile::locate<true>(a, it, t) : tile::locate<false>(a, it, t);
+        for (int l = 0; l < 64; ++l) lanes[l].load(tr);
         for (int l = 0; l < 64; ++l) lanes[l].scan(ma[l], mb[l]);
         for (int h = 0; h < HW; ++h)
             for (int jj = 0; jj < G::JPL; ++jj) {
@@ -53,11 +70,11 @@ static void run_tiles(const StftArgs &a)
                 for (int l = 0; l < 64; ++l) e2[l] = e[l] + e[l ^ o];
                 std::memcpy(e, e2, sizeof(e));
             }
-            for (int l = 0; l < 64; ++l) lanes[l].band_emit(t, it, e[l]);
+            for (int l = 0; l < 64; ++l) lanes[l].band_emit(tr, e[l]);
             continue;
         }
-        for (int l = 0; l < 64; ++l) lanes[l].epilogue(t, it, img, meta, zero_row.data(), &peak[l >> (LOG_R1 - 1)], max64);
-        for (int l = 0; l < 64; ++l) lanes[l].features(t, it, &peak[l >> (LOG_R1 - 1)]);
+        for (int l = 0; l < 64; ++l) lanes[l].epilogue(tr, img, meta, zero_row.data(), &peak[l >> (LOG_R1 - 1)], max64);
+        for (int l = 0; l < 64; ++l) lanes[l].features(tr, &peak[l >> (LOG_R1 - 1)]);
     }
     if (MODE == MODE_U8 && a.gmax_bits) {
         float m = 0.0f;

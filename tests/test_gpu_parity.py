@@ -366,3 +366,55 @@ def test_features_only_equals_the_u8_call(kernel_path, N, V):
     with pytest.raises(sa.SonoError):
         e.stft_features_dev(dx.data_ptr(), S, stride, per, V, 0, 0, 0, 0)
     e.free()
+
+
+@pytest.mark.parametrize("N,V", [(1024, 768), (512, 256), (4096, 3891), (256, 0)])
+def test_ragged_batch_equals_one_call_per_stream(kernel_path, N, V):
+    # streams of different lengths (one empty, one shorter than a frame, one of exactly one frame) in ONE launch
+    import torch
+    H, B = N - V, N // 2
+    lengths = [N + 17 * H + 3, 0, N - 1, N, N + 40 * H, N + 5 * H + H - 1, N + 2 * H]
+    gaps = [5, 0, 3, 1, 0, 8, 2]
+    offsets, pos = [], 7
+    for ln, g in zip(lengths, gaps):
+        offsets.append(pos)
+        pos += ln + g
+    buf = np.zeros(pos + 16, np.float32)
+    for i, (o, ln) in enumerate(zip(offsets, lengths)):
+        buf[o:o + ln] = signal(ln, 900 + i) if ln else 0
+    dx = torch.from_numpy(buf).cuda()
+    e = sa.SpectrogramEngine(N, "hann")
+    row0 = sa.ragged_rows(lengths, N, V)
+    assert row0.tolist() == np.concatenate([[0], np.cumsum([sa.frames_for(ln, N, V) for ln in lengths])]).tolist()
+    T = int(row0[-1])
+    out = torch.full((T * B + 64,), 7, dtype=torch.uint8, device="cuda")
+    mag = torch.zeros(T * B, dtype=torch.float32, device="cuda")
+    pb = torch.zeros(T, dtype=torch.int16, device="cuda")
+    pm = torch.zeros(T, dtype=torch.float32, device="cuda")
+    gm = torch.zeros(1, dtype=torch.int32, device="cuda")
+    pb2, pm2, gm2 = torch.zeros_like(pb), torch.zeros_like(pm), torch.zeros_like(gm)
+    torch.cuda.synchronize()
+    e.stft_u8_ragged_dev(dx.data_ptr(), offsets, lengths, V, 20.0, 80.0, out.data_ptr(), pb.data_ptr(), pm.data_ptr(),
+                         gm.data_ptr(), 0)
+    e.stft_mag_f32_ragged_dev(dx.data_ptr(), offsets, lengths, V, mag.data_ptr(), 0)
+    e.stft_u8_ragged_dev(dx.data_ptr(), offsets, lengths, V, 20.0, 80.0, 0, pb2.data_ptr(), pm2.data_ptr(), gm2.data_ptr(), 0)
+    e.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(pb, pb2) and torch.equal(pm, pm2) and torch.equal(gm, gm2)           # features only = same features
+    out_h, mag_h = out.cpu().numpy(), mag.cpu().numpy()
+    assert (out_h[T * B:] == 7).all()
+    pbh, pmh = pb.cpu().numpy().view(np.uint16), pm.cpu().numpy()
+    best = 0.0
+    for i, (o, ln) in enumerate(zip(offsets, lengths)):
+        r0, r1 = int(row0[i]), int(row0[i + 1])
+        xs = buf[o:o + ln]
+        u8 = e.compute_spectrogram_u8(xs, V, 20.0, 80.0)                                     # same kernel: bit-exact
+        assert np.array_equal(out_h[r0 * B:r1 * B], u8), i
+        assert np.array_equal(mag_h[r0 * B:r1 * B], e.compute_spectrogram(xs, V)), i
+        if r1 > r0:
+            assert np.array_equal(pbh[r0:r1], e.get_peaks(0.0)) and np.array_equal(pmh[r0:r1], e.get_peak_magnitudes(0.0))
+            best = max(best, e.get_global_max())
+    assert gm.cpu().numpy().view(np.float32)[0] == np.float32(best)
+    # an empty batch is not an error
+    e.stft_u8_ragged_dev(dx.data_ptr(), [], [], V, 20.0, 80.0, out.data_ptr(), 0, 0, 0, 0)
+    e.free()

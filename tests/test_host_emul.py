@@ -218,3 +218,32 @@ def test_tile_wave_band_energy(emul, N, V, lo, hi):
     assert energy[0] == 0.0 and energy[1] == 0.0
     assert np.allclose(energy, want, rtol=3e-4, atol=0)    # f32 magnitudes agree to 1e-4
     assert np.array_equal(active, (energy > target).astype(np.uint8))
+
+
+@pytest.mark.parametrize("N,V", [(1024, 768), (256, 128), (4096, 3891)])
+def test_tile_wave_ragged_tables_give_the_same_rows(emul, N, V):
+    # the same batch walked through the ragged-batch tables (per-tile stream ids, per-stream offsets): identical output
+    H, B = N - V, N // 2
+    per, stride = N + 10 * H + 1, N + 12 * H
+    buf = np.zeros(3 * stride, np.float32)
+    for s in range(3):
+        buf[s * stride: s * stride + per] = signal(per, 400 + s)
+    e = so.OracleEngine(N, "hann")
+    res = []
+    for ragged in (0, 1):
+        emul.emul_tile_set_ragged(ragged)
+        try:
+            res.append(_run_batch(emul, buf, N, V, e.window, per, stride))
+        finally:
+            emul.emul_tile_set_ragged(0)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][0].any()
+
+
+def _run_batch(emul, buf, N, V, window, per, stride):
+    F, B = so.num_frames(per, N, V), N // 2
+    u8 = np.zeros(3 * F * B, np.uint8)
+    pb = np.zeros(3 * F, np.uint16)
+    rc = emul.emul_tile(C.c_int(1), _p(buf), C.c_ulonglong(3), C.c_ulonglong(stride), C.c_ulonglong(F), C.c_uint(N - V),
+                        C.c_uint(N), _p(window), C.c_float(20), C.c_float(80), None, _p(u8), _p(pb), None, None, None)
+    assert rc == 0
+    return u8, pb
