@@ -143,6 +143,11 @@ void sono_engine_destroy(sono_engine *e)
     e->d_gmax.release(); e->d_mags.release(); e->d_bank.release();
     e->d_db.release(); e->d_flags.release(); e->d_edges.release(); e->d_runs.release();
     e->d_count.release(); e->d_select_tmp.release();
+    for (auto &slot : e->ragged) {
+        if (slot.done) { (void)hipEventSynchronize(slot.done); (void)hipEventDestroy(slot.done); }
+        slot.buf.release();
+    }
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     delete e;
 }
 
@@ -328,8 +333,8 @@ int run_ragged(sono_engine *e, const sono_ragged_batch *in, uint32_t noverlap, i
     a.n_streams = 0; a.stream_stride = 0; a.frames_per_stream = 0;
     const bool tiled = fpw && !force_generic() &&
                        [&] { sono::StftArgs p = a; p.frames_per_stream = 2; return sono::tile_supports(mode, p, e->tables.tile); }();
-    e->ragged_streams.clear();
-    e->ragged_tile_stream.clear();
+    std::vector<sono::RaggedStreamEntry> streams;
+    std::vector<unsigned int> tile_stream;
     unsigned long long rows = 0, tiles = 0;
     for (size_t i = 0; i < in->n_streams; ++i) {
         const unsigned long long F = sono_frames_for((size_t)in->lengths[i], N, noverlap);
@@ -337,8 +342,8 @@ int run_ragged(sono_engine *e, const sono_ragged_batch *in, uint32_t noverlap, i
             const unsigned long long t = (F + fpw - 1) / fpw;
             if (tiles + t >= 0xFFFFFFFFull || in->n_streams >= 0xFFFFFFFFull)
                 return fail(SONO_EINVAL, std::string(who) + ": more than 2^32 - 1 tiles or streams in one launch");
-            e->ragged_streams.push_back({in->offsets[i], F, rows, tiles});
-            e->ragged_tile_stream.insert(e->ragged_tile_stream.end(), (size_t)t, (unsigned int)i);
+            streams.push_back({in->offsets[i], F, rows, tiles});
+            tile_stream.insert(tile_stream.end(), (size_t)t, (unsigned int)i);
             tiles += t;
         } else if (F) {
             sono::StftArgs one = a;
@@ -353,16 +358,23 @@ int run_ragged(sono_engine *e, const sono_ragged_batch *in, uint32_t noverlap, i
         rows += F;
     }
     if (!tiled || tiles == 0) return SONO_OK;
-    const size_t sb = e->ragged_streams.size() * sizeof(sono::RaggedStreamEntry);
-    const size_t tb = e->ragged_tile_stream.size() * sizeof(unsigned int);
-    HIP_TRY(e->d_ragged.reserve(sb + tb));
-    HIP_TRY(hipMemcpyAsync(e->d_ragged.p, e->ragged_streams.data(), sb, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync((char *)e->d_ragged.p + sb, e->ragged_tile_stream.data(), tb, hipMemcpyHostToDevice, s));
+    sono_engine::RaggedSlot &slot = e->ragged[e->ragged_next++ & 1u];
+    if (slot.used) HIP_TRY(hipEventSynchronize(slot.done));          // the launch that last read this slot has finished
+    if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    const size_t sb = streams.size() * sizeof(sono::RaggedStreamEntry);
+    const size_t tb = tile_stream.size() * sizeof(unsigned int);
+    HIP_TRY(slot.buf.reserve(sb + tb));
+    HIP_TRY(hipMemcpyAsync(slot.buf.p, streams.data(), sb, hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(hipMemcpyAsync((char *)slot.buf.p + sb, tile_stream.data(), tb, hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(hipStreamSynchronize(e->copy_stream));                   // the tables are in HBM before the kernel is queued
     sono::RaggedPlan plan;
     plan.n_tiles = tiles;
-    plan.d_streams = (const sono::RaggedStreamEntry *)e->d_ragged.p;
-    plan.d_tile_stream = (const unsigned int *)((const char *)e->d_ragged.p + sb);
+    plan.d_streams = (const sono::RaggedStreamEntry *)slot.buf.p;
+    plan.d_tile_stream = (const unsigned int *)((const char *)slot.buf.p + sb);
     HIP_TRY(sono::launch_stft_tile_ragged(mode, a, e->tables.tile, plan, s));
+    HIP_TRY(hipEventRecord(slot.done, s));
+    slot.used = true;
     return SONO_OK;
 }
 

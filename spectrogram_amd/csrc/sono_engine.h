@@ -88,10 +88,16 @@ struct sono_engine {
     sono::DevBuf d_in, d_out, d_peak_bin, d_peak_mag, d_gmax, d_mags, d_bank;
     // device scratch of the detector front end (sono_capi_detect.hip)
     sono::DevBuf d_db, d_flags, d_edges, d_runs, d_count, d_select_tmp;
-    // tables of the last ragged-batch launch: host copies stay alive until the next one replaces them
-    sono::DevBuf d_ragged;
-    std::vector<sono::RaggedStreamEntry> ragged_streams;
-    std::vector<unsigned int> ragged_tile_stream;
+    // Tables of ragged-batch launches.  A launch returns before its kernel has run, so its tables must stay
+    // untouched until then: two slots are used in turn, each guarded by an event recorded behind its kernel.
+    struct RaggedSlot {
+        sono::DevBuf buf;
+        hipEvent_t done = nullptr;
+        bool used = false;
+    };
+    RaggedSlot ragged[2];
+    unsigned int ragged_next = 0;
+    hipStream_t copy_stream = nullptr;      // uploads the tables without waiting for the caller's stream
     // filter bank (lib.rs:20-22)
     std::vector<float> bank;
     unsigned int num_filters = 0;

@@ -418,3 +418,30 @@ def test_ragged_batch_equals_one_call_per_stream(kernel_path, N, V):
     # an empty batch is not an error
     e.stft_u8_ragged_dev(dx.data_ptr(), [], [], V, 20.0, 80.0, out.data_ptr(), 0, 0, 0, 0)
     e.free()
+
+
+def test_ragged_launches_back_to_back_keep_their_own_tables():
+    # four ragged launches queued without a host synchronisation in between, each with another stream order
+    import torch
+    N, V = 1024, 768
+    H, B = N - V, N // 2
+    lengths = [N + (5 + 3 * i) * H for i in range(6)]
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.uint64)
+    buf = np.concatenate([signal(ln, 950 + i) for i, ln in enumerate(lengths)])
+    dx = torch.from_numpy(buf).cuda()
+    e = sa.SpectrogramEngine(N, "hann")
+    single = [e.compute_spectrogram_u8(buf[int(o):int(o) + ln], V, 20.0, 80.0) for o, ln in zip(offsets, lengths)]
+    orders = [[0, 1, 2, 3, 4, 5], [5, 4, 3, 2, 1, 0], [2, 0, 4, 1, 5, 3], [3, 3, 0, 5, 1, 1]]
+    outs = []
+    st = torch.cuda.Stream()
+    for order in orders:
+        total = int(sa.ragged_rows([lengths[i] for i in order], N, V)[-1])
+        outs.append(torch.zeros(total * B, dtype=torch.uint8, device="cuda"))
+    torch.cuda.synchronize()
+    for order, out in zip(orders, outs):
+        e.stft_u8_ragged_dev(dx.data_ptr(), [offsets[i] for i in order], [lengths[i] for i in order], V, 20.0, 80.0,
+                             out.data_ptr(), 0, 0, 0, st.cuda_stream)
+    st.synchronize()
+    for order, out in zip(orders, outs):
+        assert np.array_equal(out.cpu().numpy(), np.concatenate([single[i] for i in order]))
+    e.free()
