@@ -328,6 +328,57 @@ int sono_highpass_filter(const float *in, size_t n, double filter_hz, double sam
 /* savitzkyGolay (batCallDetector.js:1610-1640), window 5, order 2.  Host only. */
 int sono_savitzky_golay(const double *in, size_t n, double *out);
 
+/* ---- batched region analysis: processFullFile's per-region work
+ * (batCallDetector.js:609-711) for all regions of a recording at once ---------- */
+
+#define SONO_MAX_ZONES 32
+
+typedef struct sono_roi_table {
+    /* arrays the caller provides */
+    uint64_t *row0;        /* n_rois + 1: first record of every region, then the total */
+    float *peak_db;        /* one per analysis frame: largest dB value of the frame inside the band
+                              (after the automatic high-pass where it applies) */
+    int32_t *peak_bin;     /* its bin, counted from the band's first bin */
+    double *zonal;         /* n_rois * SONO_MAX_ZONES: calculateZonalNoiseFloors of the region's first six frames */
+    float *highpass_khz;   /* n_rois: corner of the automatic high-pass, 0 = none */
+    /* filled in by sono_analyze_rois */
+    uint32_t num_zones, min_bin, num_bins, hop;
+} sono_roi_table;
+
+/* Records per region at fft_size and the analysis hop floor(fft_size * hop_percent / 100)
+ * (batCallDetector.js:1306): regions are [start, end) sample ranges.  row0: n_rois + 1. */
+int sono_roi_rows(const sono_segment *rois, size_t n_rois, uint32_t fft_size, double hop_percent, uint64_t *row0);
+
+/* For every region (sorted, disjoint [start, end) sample ranges of x, as
+ * sono_merge_and_pad_segments returns them): the analysis spectrogram
+ * (generateSpectrogramWasm, js:1296-1377), the zonal noise floors of its first
+ * frames (js:622-627), the region's peak and, if auto_highpass, the automatic
+ * Butterworth high-pass and a second spectrogram of the filtered samples
+ * (js:631-671) -- thousands of regions per launch, the spectrograms never leave
+ * the GPU.  x_filtered (n floats, may be NULL, may be a copy of x): the samples
+ * of high-passed regions are overwritten with their filtered values; nothing
+ * else is touched. */
+int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segment *rois, size_t n_rois,
+                      double sample_rate, double flow_khz, double fhigh_khz, double hop_percent, int auto_highpass,
+                      sono_roi_table *out, size_t frames_cap, float *x_filtered);
+
+typedef struct sono_roi_call {
+    uint64_t roi, start_frame, end_frame, peak_frame;           /* frames inside the region */
+    double start_time_s, end_time_s, duration_ms, peak_time_s;  /* times from the start of the recording */
+    float peak_power_db;
+    int32_t peak_bin;
+} sono_roi_call;
+
+/* The rest of processFullFile's per-region work (js:677-828, without the
+ * measurement stage) from sono_analyze_rois's table: call segments, duration
+ * filter, strongest-first 30 ms echo filter, 5 ms padding, oscillogram
+ * refinement, time stamps.  x: the recording with high-passed regions filtered
+ * (sono_analyze_rois's x_filtered).  Calls come out region by region, strongest
+ * first inside a region, like the reference's.  Host only. */
+int sono_frame_roi_calls(const float *x, size_t n, const sono_segment *rois, size_t n_rois, const sono_roi_table *table,
+                         double sample_rate, uint32_t fft_size, double call_threshold_db, double min_call_duration_ms,
+                         sono_roi_call *out, size_t cap, size_t *count);
+
 /* mergeAndPadSegments (batCallDetector.js:1028-1056).  Host only; sorts `segs` in place. */
 int sono_merge_and_pad_segments(sono_segment *segs, size_t count, uint64_t total_samples, double sample_rate,
                                 double padding_ms, sono_segment *out, size_t cap, size_t *out_count);

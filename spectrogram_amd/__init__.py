@@ -56,6 +56,23 @@ class Segment(C.Structure):
     _fields_ = [("start", C.c_uint64), ("end", C.c_uint64)]
 
 
+class RoiTable(C.Structure):
+    """struct sono_roi_table."""
+    _fields_ = [("row0", C.POINTER(C.c_uint64)), ("peak_db", C.POINTER(C.c_float)), ("peak_bin", C.POINTER(C.c_int32)),
+                ("zonal", C.POINTER(C.c_double)), ("highpass_khz", C.POINTER(C.c_float)), ("num_zones", C.c_uint32),
+                ("min_bin", C.c_uint32), ("num_bins", C.c_uint32), ("hop", C.c_uint32)]
+
+
+class RoiCall(C.Structure):
+    """struct sono_roi_call."""
+    _fields_ = [("roi", C.c_uint64), ("start_frame", C.c_uint64), ("end_frame", C.c_uint64), ("peak_frame", C.c_uint64),
+                ("start_time_s", C.c_double), ("end_time_s", C.c_double), ("duration_ms", C.c_double),
+                ("peak_time_s", C.c_double), ("peak_power_db", C.c_float), ("peak_bin", C.c_int32)]
+
+
+SONO_MAX_ZONES = 32
+
+
 class CallFrame(C.Structure):
     """struct sono_call_frame."""
     _fields_ = [("start_frame", C.c_uint64), ("end_frame", C.c_uint64), ("start_time_s", C.c_double),
@@ -151,6 +168,11 @@ _SIGNATURES = {
     "sono_auto_highpass_khz": (C.c_double, [C.c_double]),
     "sono_highpass_filter": (C.c_int, [_f32p, C.c_size_t, C.c_double, C.c_double, C.c_double, _f32p]),
     "sono_savitzky_golay": (C.c_int, [C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double)]),
+    "sono_roi_rows": (C.c_int, [_segp, C.c_size_t, C.c_uint32, C.c_double, C.POINTER(C.c_uint64)]),
+    "sono_analyze_rois": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, _segp, C.c_size_t, C.c_double, C.c_double, C.c_double,
+                                    C.c_double, C.c_int, C.POINTER(RoiTable), C.c_size_t, _f32p]),
+    "sono_frame_roi_calls": (C.c_int, [_f32p, C.c_size_t, _segp, C.c_size_t, C.POINTER(RoiTable), C.c_double, C.c_uint32,
+                                       C.c_double, C.c_double, C.POINTER(RoiCall), C.c_size_t, _szp]),
     "sono_wav_parse": (C.c_int, [_u8p, C.c_size_t, C.POINTER(WavInfo)]),
     "sono_pcm_to_f32_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                       C.c_void_p, C.c_void_p]),

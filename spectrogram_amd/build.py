@@ -20,7 +20,7 @@ LIB = os.path.join(LIBDIR, "libsonostft.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
-HIP_SOURCES = ["sono_kernels.hip", "sono_tile.hip", "sono_detect.hip", "sono_capi.hip", "sono_capi_detect.hip"]
+HIP_SOURCES = ["sono_kernels.hip", "sono_tile.hip", "sono_detect.hip", "sono_capi.hip", "sono_capi_detect.hip", "sono_capi_rois.hip"]
 CXX_SOURCES = ["sono_host.cpp", "sono_framing.cpp"]
 # -fno-slp-vectorize: gfx950 executes v_pk_{add,mul,fma}_f32 at half the rate of the scalar forms
 # (measured, tools/microbench.hip), so packing buys nothing and costs the moves that build the pairs.

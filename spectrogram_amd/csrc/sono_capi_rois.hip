@@ -1,0 +1,312 @@
+// sono_capi_rois.hip -- C ABI of the batched region analysis: processFullFile's
+// per-region work (batCallDetector.js:609-711) for all regions of a recording at
+// once.  Thousands of regions share each launch (ragged STFT batch, dB crop,
+// per-frame peaks, per-region noise-floor histograms, per-region high-pass);
+// only one record per frame and a few numbers per region return to the host.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/sonostft.h"
+#include "sono_detect.h"
+#include "sono_engine.h"
+#include "sono_framing.h"
+
+using sono::DeviceGuard;
+using sono::fail;
+
+namespace {
+
+constexpr size_t kBatchFrames = (size_t)1 << 19;      // frames whose magnitudes are in HBM at one time (1 GiB at fft 1024)
+
+struct Band { uint32_t hop, noverlap, min_bin, nb; bool ok; };
+
+// Hop and band of generateSpectrogramWasm (batCallDetector.js:1306-1335); ok = false where it would return null.
+Band band_of(uint32_t N, double sample_rate, double flow_khz, double fhigh_khz, double hop_percent)
+{
+    Band b{0, 0, 0, 0, false};
+    const uint32_t bins = N / 2;
+    const double hop_d = std::floor((double)N * (hop_percent / 100.0));
+    if (!(hop_d >= 1.0)) return b;
+    b.hop = hop_d >= (double)N ? N : (uint32_t)hop_d;
+    b.noverlap = N - b.hop;
+    const double res = sample_rate / (double)N;
+    const double lo = std::max(0.0, std::floor(flow_khz * 1000.0 / res));
+    const double hi = std::min((double)(bins - 1), std::floor(fhigh_khz * 1000.0 / res));
+    if (!(hi - lo + 1.0 > 0.0)) return b;
+    b.min_bin = (uint32_t)lo;
+    b.nb = (uint32_t)(hi - lo + 1.0);
+    b.ok = true;
+    return b;
+}
+
+// One pass over a set of regions whose samples sit at d_src + off[i]: magnitudes -> dB crop -> per-frame peak.
+// feat_rows[i] = where region i's records go in the host arrays.
+int peaks_pass(sono_engine *e, const float *d_src, const std::vector<uint64_t> &off, const std::vector<uint64_t> &len,
+               const std::vector<uint64_t> &feat_rows, const Band &b, size_t frames, float *peak_db, int32_t *peak_bin,
+               std::vector<uint64_t> *first_row_out)
+{
+    const uint32_t N = e->N, bins = N / 2;
+    HIP_TRY(e->d_mags.reserve(frames * bins * sizeof(float)));
+    HIP_TRY(e->d_db.reserve(frames * b.nb * sizeof(float)));
+    HIP_TRY(e->d_out.reserve(frames * sizeof(sono_frame_features)));
+    sono_ragged_batch rb{d_src, off.size(), off.data(), len.data()};
+    int rc = sono_stft_mag_f32_ragged_dev(e, &rb, b.noverlap, (float *)e->d_mags.p, nullptr);
+    if (rc) return rc;
+    rc = sono_detect_power_db_dev(e, (const float *)e->d_mags.p, frames, bins, b.min_bin, b.nb, (float *)e->d_db.p, nullptr);
+    if (rc) return rc;
+    rc = sono_detect_frame_features_dev(e, (const float *)e->d_db.p, frames, b.nb, 0, b.nb - 1, 0, INFINITY, b.nb, INFINITY,
+                                        (sono_frame_features *)e->d_out.p, nullptr);
+    if (rc) return rc;
+    std::vector<sono_frame_features> feat(frames);
+    HIP_TRY(hipMemcpyAsync(feat.data(), e->d_out.p, frames * sizeof(sono_frame_features), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    size_t row = 0;
+    for (size_t i = 0; i < off.size(); ++i) {
+        const size_t F = sono_frames_for((size_t)len[i], N, b.noverlap);
+        if (first_row_out) (*first_row_out)[i] = row;
+        for (size_t f = 0; f < F; ++f) {
+            peak_db[feat_rows[i] + f] = feat[row + f].peak_db;
+            peak_bin[feat_rows[i] + f] = feat[row + f].peak_bin;
+        }
+        row += F;
+    }
+    return SONO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sono_roi_rows(const sono_segment *rois, size_t n_rois, uint32_t fft_size, double hop_percent, uint64_t *row0)
+{
+    if (!row0 || (n_rois && !rois)) return fail(SONO_EINVAL, "sono_roi_rows: NULL argument");
+    const Band b = band_of(fft_size, 2.0 * fft_size, 0.0, 1e9, hop_percent);      // only the hop matters here
+    uint64_t rows = 0;
+    for (size_t r = 0; r < n_rois; ++r) {
+        row0[r] = rows;
+        if (rois[r].end < rois[r].start) return fail(SONO_EINVAL, "sono_roi_rows: region with end < start");
+        if (b.hop) rows += sono_frames_for((size_t)(rois[r].end - rois[r].start), fft_size, b.noverlap);
+    }
+    row0[n_rois] = rows;
+    return SONO_OK;
+}
+
+int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segment *rois, size_t n_rois, double sample_rate,
+                      double flow_khz, double fhigh_khz, double hop_percent, int auto_highpass, sono_roi_table *out,
+                      size_t frames_cap, float *x_filtered)
+{
+    if (!e || !out || (n && !x) || (n_rois && !rois)) return fail(SONO_EINVAL, "sono_analyze_rois: NULL argument");
+    if (!(sample_rate > 0)) return fail(SONO_EINVAL, "sono_analyze_rois: sample_rate must be positive");
+    if (n_rois && (!out->row0 || !out->zonal || !out->highpass_khz))
+        return fail(SONO_EINVAL, "sono_analyze_rois: NULL output array");
+    const uint32_t N = e->N;
+    const Band b = band_of(N, sample_rate, flow_khz, fhigh_khz, hop_percent);
+    out->num_zones = 0; out->min_bin = b.min_bin; out->num_bins = b.nb; out->hop = b.hop;
+    for (size_t r = 0; r < n_rois; ++r) {
+        if (rois[r].end < rois[r].start || rois[r].end > n) return fail(SONO_EINVAL, "sono_analyze_rois: region outside the recording");
+        if (r && rois[r].start < rois[r - 1].end) return fail(SONO_EINVAL, "sono_analyze_rois: regions must be sorted and disjoint");
+        out->highpass_khz[r] = 0.0f;
+    }
+    if (!b.ok) {                                             // no region has a spectrogram (js:1309-1335)
+        for (size_t r = 0; r <= n_rois && out->row0; ++r) out->row0[r] = 0;
+        return SONO_OK;
+    }
+    int rc = sono_roi_rows(rois, n_rois, N, hop_percent, out->row0);
+    if (rc) return rc;
+    const size_t total = (size_t)out->row0[n_rois];
+    if (total > frames_cap || (total && (!out->peak_db || !out->peak_bin)))
+        return fail(SONO_ECAPACITY, "sono_analyze_rois: per-frame output arrays too small");
+    // frequency axis and its 10 kHz zones (js:1342-1344, 1837-1839)
+    std::vector<float> freq_bins(b.nb);
+    const double res = sample_rate / (double)N;
+    for (uint32_t i = 0; i < b.nb; ++i) freq_bins[i] = (float)((double)(b.min_bin + i) * res);
+    std::vector<uint8_t> zone_of_bin;
+    const size_t zones = sono::host_zone_map(freq_bins.data(), b.nb, zone_of_bin);
+    if (zones == 0 || zones > SONO_MAX_ZONES) return fail(SONO_EINVAL, "sono_analyze_rois: frequency axis needs more than SONO_MAX_ZONES zones");
+    out->num_zones = (uint32_t)zones;
+    // the three corner frequencies of calculateAutoHighpassFilterFreq (js:4028-4035), order 4 (js:4045, 660)
+    sono::HighpassCoef coefs[3];
+    const double corners_khz[3] = {20.0, 25.0, 30.0};
+    bool corner_ok[3];
+    for (int c = 0; c < 3; ++c) {
+        const double norm = corners_khz[c] * 1000.0 / (sample_rate / 2);
+        corner_ok[c] = norm < 1;                                                  // js:4058: otherwise the audio passes unchanged
+        const double wc = std::tan(M_PI * norm / 2), wc2 = wc * wc, s2 = std::sqrt(2.0) * wc, den = wc2 + s2 + 1;
+        coefs[c] = {1 / den, -2 / den, 1 / den, (2 * (wc2 - 1)) / den, (wc2 - s2 + 1) / den};      // js:4117-4124
+    }
+
+    DeviceGuard guard(e->device);
+    hipStream_t s = e->stream;
+    size_t r0 = 0;
+    while (r0 < n_rois) {
+        // ---- one batch: regions r0 .. r1-1 ------------------------------------------------------
+        size_t r1 = r0, frames = 0, samples = 0;
+        while (r1 < n_rois && (r1 == r0 || frames + (out->row0[r1 + 1] - out->row0[r1]) <= kBatchFrames)) {
+            frames += (size_t)(out->row0[r1 + 1] - out->row0[r1]);
+            samples += (size_t)(rois[r1].end - rois[r1].start);
+            ++r1;
+        }
+        const size_t cnt = r1 - r0;
+        if (frames == 0) { for (size_t r = r0; r < r1; ++r) for (size_t z = 0; z < SONO_MAX_ZONES; ++z) out->zonal[r * SONO_MAX_ZONES + z] = -102.0; r0 = r1; continue; }
+        // pack the batch's samples and upload them in one copy
+        std::vector<float> packed(samples ? samples : 1);
+        std::vector<uint64_t> off(cnt), len(cnt), rows(cnt), first_row(cnt);
+        size_t pos = 0;
+        for (size_t i = 0; i < cnt; ++i) {
+            const sono_segment &g = rois[r0 + i];
+            off[i] = pos; len[i] = g.end - g.start; rows[i] = out->row0[r0 + i];
+            std::memcpy(packed.data() + pos, x + g.start, (size_t)len[i] * sizeof(float));
+            pos += (size_t)len[i];
+        }
+        HIP_TRY(e->d_in.reserve(packed.size() * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(e->d_in.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        rc = peaks_pass(e, (const float *)e->d_in.p, off, len, rows, b, frames, out->peak_db, out->peak_bin, &first_row);
+        if (rc) return rc;
+        // ---- noise floors of every region's first six frames (js:622-627), from the unfiltered spectrogram ----
+        {
+            std::vector<unsigned long long> fr(cnt);
+            std::vector<unsigned int> used(cnt);
+            for (size_t i = 0; i < cnt; ++i) {
+                const size_t F = (size_t)(out->row0[r0 + i + 1] - out->row0[r0 + i]);
+                fr[i] = first_row[i];
+                used[i] = (unsigned int)(F < 6 ? F : 6);
+            }
+            const size_t tb = cnt * sizeof(unsigned long long), ub = cnt * sizeof(unsigned int);
+            const size_t fb = cnt * SONO_MAX_ZONES * sizeof(double);
+            HIP_TRY(e->d_edges.reserve(tb + ub + b.nb + 8 + fb));
+            char *base = (char *)e->d_edges.p;
+            double *d_floors = (double *)base;
+            unsigned long long *d_fr = (unsigned long long *)(base + fb);
+            unsigned int *d_used = (unsigned int *)(base + fb + tb);
+            uint8_t *d_zone = (uint8_t *)(base + fb + tb + ub);
+            HIP_TRY(hipMemcpyAsync(d_fr, fr.data(), tb, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d_used, used.data(), ub, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d_zone, zone_of_bin.data(), b.nb, hipMemcpyHostToDevice, s));
+            HIP_TRY(sono::launch_zone_floors_regions((const float *)e->d_db.p, d_fr, d_used, cnt, b.nb, d_zone, (uint32_t)zones,
+                                                     SONO_MAX_ZONES, d_floors, s));
+            HIP_TRY(hipMemcpyAsync(out->zonal + r0 * SONO_MAX_ZONES, d_floors, fb, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+        // ---- automatic high-pass (js:631-671): regions whose loudest bin lies at 30 kHz or above ----
+        if (auto_highpass) {
+            std::vector<sono::HighpassJob> jobs;
+            std::vector<size_t> job_region;                  // index of each job's region inside the batch
+            std::vector<uint64_t> off2, len2, rows2;
+            size_t fpos = 0, frames2 = 0;
+            for (size_t i = 0; i < cnt; ++i) {
+                const size_t F = (size_t)(out->row0[r0 + i + 1] - out->row0[r0 + i]);
+                if (F == 0) continue;
+                float best = -INFINITY;
+                int32_t bin = 0;
+                for (size_t f = 0; f < F; ++f)                                     // first maximum in frame order (js:635-644)
+                    if (out->peak_db[rows[i] + f] > best) { best = out->peak_db[rows[i] + f]; bin = out->peak_bin[rows[i] + f]; }
+                if (bin < 0) bin = 0;
+                const double cutoff = sono::host_auto_highpass_khz((double)freq_bins[bin] / 1000);      // js:646-647
+                out->highpass_khz[r0 + i] = (float)cutoff;
+                if (!(cutoff > 0)) continue;
+                const int c = cutoff == 20.0 ? 0 : cutoff == 25.0 ? 1 : 2;
+                if (!corner_ok[c]) continue;
+                jobs.push_back({off[i], fpos, len[i], (unsigned int)c, 0u});
+                job_region.push_back(i);
+                off2.push_back(fpos); len2.push_back(len[i]); rows2.push_back(rows[i]);
+                fpos += (size_t)len[i];
+                frames2 += F;
+            }
+            if (!jobs.empty()) {
+                const size_t jb = jobs.size() * sizeof(sono::HighpassJob);
+                HIP_TRY(e->d_runs.reserve(fpos * sizeof(float)));
+                HIP_TRY(e->d_flags.reserve(jb + sizeof(coefs)));
+                sono::HighpassJob *d_jobs = (sono::HighpassJob *)e->d_flags.p;
+                sono::HighpassCoef *d_coefs = (sono::HighpassCoef *)((char *)e->d_flags.p + jb);
+                HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jb, hipMemcpyHostToDevice, s));
+                HIP_TRY(hipMemcpyAsync(d_coefs, coefs, sizeof(coefs), hipMemcpyHostToDevice, s));
+                HIP_TRY(sono::launch_highpass_regions((const float *)e->d_in.p, (float *)e->d_runs.p, d_jobs, jobs.size(), d_coefs, s));
+                if (x_filtered) {
+                    std::vector<float> filt(fpos);
+                    HIP_TRY(hipMemcpyAsync(filt.data(), e->d_runs.p, fpos * sizeof(float), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(hipStreamSynchronize(s));
+                    for (size_t k = 0; k < jobs.size(); ++k)
+                        std::memcpy(x_filtered + rois[r0 + job_region[k]].start, filt.data() + jobs[k].dst,
+                                    (size_t)jobs[k].len * sizeof(float));
+                }
+                rc = peaks_pass(e, (const float *)e->d_runs.p, off2, len2, rows2, b, frames2, out->peak_db, out->peak_bin, nullptr);
+                if (rc) return rc;
+            }
+        }
+        r0 = r1;
+    }
+    return SONO_OK;
+}
+
+int sono_frame_roi_calls(const float *x, size_t n, const sono_segment *rois, size_t n_rois, const sono_roi_table *t,
+                         double sample_rate, uint32_t fft_size, double call_threshold_db, double min_call_duration_ms,
+                         sono_roi_call *out, size_t cap, size_t *count)
+{
+    if (count) *count = 0;
+    if (!t || (n && !x) || (n_rois && (!rois || !t->row0)) || !(sample_rate > 0) || fft_size == 0)
+        return fail(SONO_EINVAL, "sono_frame_roi_calls: NULL or non-positive argument");
+    size_t made = 0;
+    std::vector<double> tf;
+    std::vector<sono::CallFrame> framed;
+    struct Cand { uint64_t s, e, peak_frame; double power, time; };
+    std::vector<Cand> cands, kept;
+    for (size_t r = 0; r < n_rois; ++r) {
+        const size_t row = (size_t)t->row0[r], F = (size_t)(t->row0[r + 1] - t->row0[r]);
+        if (F == 0) continue;
+        if (rois[r].end > n || rois[r].end < rois[r].start) return fail(SONO_EINVAL, "sono_frame_roi_calls: region outside the recording");
+        const float *pdb = t->peak_db + row;
+        tf.resize(F);
+        for (size_t f = 0; f < F; ++f) tf[f] = ((double)f * (double)t->hop + (double)fft_size / 2) / sample_rate;    // js:1350-1351
+        float gmax = -INFINITY;
+        for (size_t f = 0; f < F; ++f) if (pdb[f] > gmax) gmax = pdb[f];           // js:1544-1550
+        const double threshold = (double)gmax + call_threshold_db;                  // js:1553
+        cands.clear();
+        size_t f = 0;
+        while (f < F) {                                                             // maximal runs of active frames, js:1556-1595
+            if (!((double)pdb[f] > threshold)) { ++f; continue; }
+            size_t g = f;
+            while (g + 1 < F && (double)pdb[g + 1] > threshold) ++g;
+            if (!(tf[g] - tf[f] < min_call_duration_ms / 1000)) {                   // js:688-689
+                size_t pk = f;
+                for (size_t k = f; k <= g; ++k) if (pdb[k] > pdb[pk]) pk = k;       // first maximum, js:695-703
+                cands.push_back({f, g, pk, (double)pdb[pk], tf[pk]});
+            }
+            f = g + 1;
+        }
+        std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.power > b.power; });   // js:714
+        kept.clear();
+        for (const Cand &c : cands) {                                               // js:720-734
+            bool close = false;
+            for (const Cand &k : kept) if (std::fabs(c.time - k.time) < 0.030) { close = true; break; }
+            if (!close) kept.push_back(c);
+        }
+        const double offset = (double)rois[r].start / sample_rate;                  // js:737
+        for (const Cand &c : kept) {
+            const sono::FrameRun run{c.s, c.e};
+            if (!sono::host_frame_calls(&run, 1, tf.data(), F, x + rois[r].start, (size_t)(rois[r].end - rois[r].start), sample_rate,
+                                        fft_size, 5.0, min_call_duration_ms, true, framed))              // js:743-810
+                return fail(SONO_EINVAL, "sono_frame_roi_calls: sample rate below 20 kHz (the 0.1 ms window has no hop)");
+            for (const sono::CallFrame &k : framed) {
+                if (made >= cap || !out) return fail(SONO_ECAPACITY, "sono_frame_roi_calls: output buffer too small");
+                size_t pk = (size_t)k.start_frame;
+                for (size_t q = pk; q <= (size_t)k.end_frame; ++q) if (pdb[q] > pdb[pk]) pk = q;
+                sono_roi_call &o = out[made++];
+                o.roi = r; o.start_frame = k.start_frame; o.end_frame = k.end_frame; o.peak_frame = pk;
+                o.start_time_s = k.start_time_s + offset;                           // js:822-823
+                o.end_time_s = k.end_time_s + offset;
+                o.duration_ms = k.duration_ms;
+                o.peak_time_s = tf[pk] + offset;
+                o.peak_power_db = pdb[pk];
+                o.peak_bin = t->peak_bin[row + pk];
+            }
+        }
+    }
+    if (count) *count = made;
+    return SONO_OK;
+}
+
+}  // extern "C"

@@ -49,6 +49,26 @@ constexpr int kZoneHistBins = 141;
 hipError_t launch_zone_hist(const float *d_db, size_t count, uint32_t nb, const uint8_t *d_zone_of_bin,
                             uint32_t num_zones, unsigned int *d_hist, hipStream_t s);
 
+// The same histogram pass for many regions at once, mode included: region r covers rows
+// d_first_row[r] .. + d_rows_used[r] - 1 of d_db; d_floors[r*zone_stride + z] = noise floor of zone z
+// (batCallDetector.js:1886-1921: lowest dB wins a tie, -2 dB offset, -102 for an empty zone).
+hipError_t launch_zone_floors_regions(const float *d_db, const unsigned long long *d_first_row,
+                                      const unsigned int *d_rows_used, size_t regions, uint32_t nb,
+                                      const uint8_t *d_zone_of_bin, uint32_t num_zones, uint32_t zone_stride,
+                                      double *d_floors, hipStream_t s);
+
+// Butterworth high-pass of many regions at once, one lane per region
+// (applyHighpassFilter at its default order 4 = two identical second-order sections,
+// batCallDetector.js:4045-4140): doubles, every product and sum rounded on its own, the
+// output of each section rounded to float like the reference's Float32Array.
+struct HighpassCoef { double b0, b1, b2, a1, a2; };
+struct HighpassJob {
+    unsigned long long src, dst, len;   // sample offsets into d_src / d_dst, number of samples
+    unsigned int coef, pad;             // index into the coefficient table
+};
+hipError_t launch_highpass_regions(const float *d_src, float *d_dst, const HighpassJob *d_jobs, size_t jobs,
+                                   const HighpassCoef *d_coefs, hipStream_t s);
+
 // Ascending sort of `count` finite floats (d_in -> d_out).  d_temp == nullptr: size query.
 hipError_t sort_floats(void *d_temp, size_t &temp_bytes, const float *d_in, float *d_out, size_t count, hipStream_t s);
 

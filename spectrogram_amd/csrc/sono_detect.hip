@@ -186,7 +186,92 @@ __global__ __launch_bounds__(kThreads) void zone_hist_kernel(const float *db, si
         if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
 }
 
+__global__ __launch_bounds__(kThreads) void zone_floors_regions_kernel(const float *db, const unsigned long long *first_row,
+                                                                       const unsigned int *rows_used, uint32_t nb,
+                                                                       const uint8_t *zone_of_bin, uint32_t num_zones,
+                                                                       uint32_t zone_stride, double *floors)
+{
+    extern __shared__ unsigned int s_hist[];
+    const size_t r = blockIdx.x;
+    const uint32_t cells = num_zones * (uint32_t)kZoneHistBins;
+    for (uint32_t i = threadIdx.x; i < cells; i += kThreads) s_hist[i] = 0u;
+    __syncthreads();
+    const float *base = db + first_row[r] * nb;
+    const size_t count = (size_t)rows_used[r] * nb;
+    for (size_t i = threadIdx.x; i < count; i += kThreads) {
+        const uint32_t zone = zone_of_bin[i % nb];
+        float v = base[i];
+        if (zone >= num_zones || v != v) continue;
+        v = v < -100.0f ? -100.0f : v;                              // js:1857
+        float fl = floorf(v);                                       // js:1867
+        fl = fl < -120.0f ? -120.0f : fl > 20.0f ? 20.0f : fl;      // js:1870-1871
+        atomicAdd(&s_hist[zone * kZoneHistBins + (uint32_t)((int)fl + 120)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t z = threadIdx.x; z < num_zones; z += kThreads) {
+        unsigned int best = 0;
+        int mode = -100;
+        bool any = false;
+        for (int i = 0; i < kZoneHistBins; ++i) {
+            const unsigned int c = s_hist[z * kZoneHistBins + i];
+            any = any || c > 0;
+            if (c > best) { best = c; mode = i - 120; }             // strict >: lowest dB wins a tie, js:1907
+        }
+        floors[r * zone_stride + z] = any ? (double)mode - 2.0 : -102.0;          // js:1916-1920
+    }
+}
+
+__global__ __launch_bounds__(64) void highpass_regions_kernel(const float *src, float *dst, const HighpassJob *jobs,
+                                                              size_t n_jobs, const HighpassCoef *coefs)
+{
+    const size_t k = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (k >= n_jobs) return;
+    const HighpassJob job = jobs[k];
+    const HighpassCoef c = coefs[job.coef];
+    const float *x = src + job.src;
+    float *y = dst + job.dst;
+    double ax1 = 0, ax2 = 0, ay1 = 0, ay2 = 0;      // first section
+    double bx1 = 0, bx2 = 0, by1 = 0, by2 = 0;      // second section
+    for (unsigned long long i = 0; i < job.len; ++i) {
+        // y0 = b0*x0 + b1*x1 + b2*x2 - a1*y1 - a2*y2, left to right, nothing fused (js:4131)
+        const double x0 = (double)x[i];
+        double s1 = __dadd_rn(__dmul_rn(c.b0, x0), __dmul_rn(c.b1, ax1));
+        s1 = __dadd_rn(s1, __dmul_rn(c.b2, ax2));
+        s1 = __dsub_rn(s1, __dmul_rn(c.a1, ay1));
+        s1 = __dsub_rn(s1, __dmul_rn(c.a2, ay2));
+        ax2 = ax1; ax1 = x0; ay2 = ay1; ay1 = s1;
+        const double m = (double)(float)s1;          // the first section's Float32Array
+        double s2 = __dadd_rn(__dmul_rn(c.b0, m), __dmul_rn(c.b1, bx1));
+        s2 = __dadd_rn(s2, __dmul_rn(c.b2, bx2));
+        s2 = __dsub_rn(s2, __dmul_rn(c.a1, by1));
+        s2 = __dsub_rn(s2, __dmul_rn(c.a2, by2));
+        bx2 = bx1; bx1 = m; by2 = by1; by1 = s2;
+        y[i] = (float)s2;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_zone_floors_regions(const float *d_db, const unsigned long long *d_first_row,
+                                      const unsigned int *d_rows_used, size_t regions, uint32_t nb,
+                                      const uint8_t *d_zone_of_bin, uint32_t num_zones, uint32_t zone_stride,
+                                      double *d_floors, hipStream_t s)
+{
+    if (regions == 0 || num_zones == 0) return hipSuccess;
+    const size_t lds = (size_t)num_zones * kZoneHistBins * sizeof(unsigned int);
+    hipLaunchKernelGGL(zone_floors_regions_kernel, dim3((unsigned int)regions), dim3(kThreads), lds, s, d_db, d_first_row,
+                       d_rows_used, nb, d_zone_of_bin, num_zones, zone_stride, d_floors);
+    return hipGetLastError();
+}
+
+hipError_t launch_highpass_regions(const float *d_src, float *d_dst, const HighpassJob *d_jobs, size_t jobs,
+                                   const HighpassCoef *d_coefs, hipStream_t s)
+{
+    if (jobs == 0) return hipSuccess;
+    hipLaunchKernelGGL(highpass_regions_kernel, dim3((unsigned int)((jobs + 63) / 64)), dim3(64), 0, s, d_src, d_dst, d_jobs,
+                       jobs, d_coefs);
+    return hipGetLastError();
+}
 
 hipError_t launch_zone_hist(const float *d_db, size_t count, uint32_t nb, const uint8_t *d_zone_of_bin,
                             uint32_t num_zones, unsigned int *d_hist, hipStream_t s)

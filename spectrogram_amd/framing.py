@@ -10,12 +10,14 @@ import math
 
 import numpy as np
 
-from . import CallFrame as _CallFrame, Segment as _Segment, _check, _f32, _p, lib
+from . import (CallFrame as _CallFrame, RoiCall as _RoiCall, RoiTable as _RoiTable, Segment as _Segment, SONO_MAX_ZONES, _check,
+               _f32, _p, lib)
 from . import detector as _det
 
 __all__ = ["calculate_zonal_noise_floors", "db_percentile", "refine_end_using_oscillogram", "frame_calls",
            "scan_spectrum_for_frequency", "calculate_auto_highpass_filter_freq", "apply_highpass_filter",
-           "savitzky_golay", "detect_calls_framing", "process_full_file", "DEFAULT_FRAMING_CONFIG"]
+           "savitzky_golay", "detect_calls_framing", "process_full_file", "process_full_file_batched",
+           "DEFAULT_FRAMING_CONFIG"]
 
 # the members of DEFAULT_DETECTION_CONFIG (batCallDetector.js:3-45) this stage reads
 DEFAULT_FRAMING_CONFIG = {"minCallDuration_ms": 1, "callThreshold_dB": -24, "hopPercent": 3.125}
@@ -193,4 +195,51 @@ def process_full_file(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz,
                     "peakFreq_kHz": float(fb[peak_bin[kk]]) / 1000, "snr_dB": float(peak_db[kk]) + 80.0,       # js:818
                     "highpass_kHz": cutoff, "zonalNoiseMap": zonal,
                 })
+    return calls
+
+
+def process_full_file_batched(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options=None, config=None):
+    """process_full_file with the per-region work of ALL regions done in a few launches (sono_analyze_rois: ragged
+    STFT batch, dB crop, per-frame peaks, noise-floor histograms, high-pass, all in HBM) and one host pass
+    (sono_frame_roi_calls).  Same calls, same order, same values as process_full_file."""
+    opt = dict({"threshold_dB": -60, "padding_ms": 5}, **(options or {}))
+    cfg = dict(DEFAULT_FRAMING_CONFIG, **(config or {}))
+    x = _f32(full_audio_data)
+    raw = _det.fast_scan_segments(engine, x, sample_rate, flow_khz, fhigh_khz, opt["threshold_dB"])          # js:594
+    if not raw:
+        return []
+    merged = _det.merge_and_pad_segments(raw, x.size, sample_rate, opt["padding_ms"])                        # js:601
+    n = len(merged)
+    rois = (_Segment * n)(*[_Segment(m["startSample"], m["endSample"]) for m in merged])
+    u64p, i32p, dp = C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    row0 = np.zeros(n + 1, np.uint64)
+    n_fft = engine.get_fft_size()
+    _check(lib().sono_roi_rows(rois, n, n_fft, float(cfg["hopPercent"]), row0.ctypes.data_as(u64p)))
+    total = int(row0[-1])
+    peak_db = np.zeros(max(total, 1), np.float32)
+    peak_bin = np.zeros(max(total, 1), np.int32)
+    zonal = np.zeros(n * SONO_MAX_ZONES, np.float64)
+    hp = np.zeros(n, np.float32)
+    table = _RoiTable(row0.ctypes.data_as(u64p), _p(peak_db), peak_bin.ctypes.data_as(i32p), zonal.ctypes.data_as(dp), _p(hp),
+                      0, 0, 0, 0)
+    xf = x.copy()
+    _check(lib().sono_analyze_rois(engine._handle(), _p(x), x.size, rois, n, float(sample_rate), float(flow_khz), float(fhigh_khz),
+                                   float(cfg["hopPercent"]), 1, C.byref(table), total, _p(xf)))
+    cap = total // 2 + n + 1
+    out = (_RoiCall * cap)()
+    got = C.c_size_t(0)
+    _check(lib().sono_frame_roi_calls(_p(xf), xf.size, rois, n, C.byref(table), float(sample_rate), n_fft,
+                                      float(cfg["callThreshold_dB"]), float(cfg["minCallDuration_ms"]), out, cap, C.byref(got)))
+    res = sample_rate / n_fft
+    calls = []
+    for i in range(got.value):
+        c = out[i]
+        r = int(c.roi)
+        calls.append({
+            "roi": r, "startFrame": int(c.start_frame), "endFrame": int(c.end_frame), "startTime_s": c.start_time_s,
+            "endTime_s": c.end_time_s, "duration_ms": c.duration_ms, "peakPower_dB": float(c.peak_power_db),
+            "peakTime_s": c.peak_time_s, "peakFreq_kHz": float(np.float32((table.min_bin + c.peak_bin) * res)) / 1000,
+            "snr_dB": float(c.peak_power_db) + 80.0, "highpass_kHz": float(hp[r]),
+            "zonalNoiseMap": {10 * z: float(zonal[r * SONO_MAX_ZONES + z]) for z in range(table.num_zones)},
+        })
     return calls

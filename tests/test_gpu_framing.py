@@ -113,3 +113,45 @@ def test_process_full_file_end_to_end(golden):
                                                                                              [k["snr_dB"] for k in calls])
         e.free()
     assert seen >= 6
+
+
+def _same_calls(a, b):
+    assert len(a) == len(b), (len(a), len(b))
+    for p, q in zip(a, b):
+        for k in ("roi", "startFrame", "endFrame", "startTime_s", "endTime_s", "duration_ms", "peakPower_dB", "peakTime_s",
+                  "peakFreq_kHz", "snr_dB", "highpass_kHz"):
+            assert p[k] == q[k], (k, p, q)
+        assert {int(k): v for k, v in p["zonalNoiseMap"].items()} == {int(k): v for k, v in q["zonalNoiseMap"].items()}
+
+
+def test_batched_region_analysis_equals_the_region_by_region_form(golden):
+    g, meta = golden
+    for c in cases(meta, "fullfile"):
+        n = c["name"]
+        e = sa.SpectrogramEngine(c["fft"], c["window"])
+        args = (e, g[n + "/x"], c["sr"], c["flow_khz"], c["fhigh_khz"], {"threshold_dB": c["scan_threshold_db"], "padding_ms": c["padding_ms"]},
+                {"hopPercent": c["hop_percent"], "callThreshold_dB": c["call_threshold_db"], "minCallDuration_ms": c["min_call_duration_ms"]})
+        one, batched = fr.process_full_file(*args), fr.process_full_file_batched(*args)
+        _same_calls(one, batched)
+        want = g[n + "/calls"].reshape(-1, 5)
+        assert [(k["startTime_s"], k["endTime_s"], k["duration_ms"]) for k in batched] == [(w[0], w[1], w[2]) for w in want]
+        e.free()
+
+
+def test_batched_region_analysis_on_a_long_recording():
+    # 6 s at 384 kHz with a pulse every 50 ms: more than a hundred regions in one batch
+    sr = 384000
+    rng = np.random.default_rng(12)
+    x = (0.01 * rng.standard_normal(6 * sr)).astype(np.float32)
+    t = np.arange(1536) / sr
+    for k in range(0, 6 * sr - 4000, 19200):
+        f0 = [80000, 38000, 33000, 25000][(k // 19200) % 4]          # one pulse for each class of the automatic high-pass
+        x[k + 500:k + 2036] += (0.4 * np.hanning(1536) * np.sin(2 * np.pi * (f0 * t - 1e5 * t * t))).astype(np.float32)
+    e = sa.SpectrogramEngine(1024, "hann")
+    cfg = {"hopPercent": 6.25}
+    one = fr.process_full_file(e, x, sr, 15.0, 110.0, {"threshold_dB": -45.0}, cfg)
+    batched = fr.process_full_file_batched(e, x, sr, 15.0, 110.0, {"threshold_dB": -45.0}, cfg)
+    assert len(one) > 50
+    _same_calls(one, batched)
+    assert {c["highpass_kHz"] for c in batched} >= {0.0, 20.0, 25.0, 30.0}
+    e.free()
