@@ -328,6 +328,25 @@ int sono_highpass_filter(const float *in, size_t n, double filter_hz, double sam
 /* savitzkyGolay (batCallDetector.js:1610-1640), window 5, order 2.  Host only. */
 int sono_savitzky_golay(const double *in, size_t n, double *out);
 
+/* calculateRMSbasedSNR (batCallDetector.js:402-571): signal = the bins of the box
+ * frames start_idx..end_idx x centre frequencies in [low_hz, high_hz] that lie
+ * more than a quarter of the box's dynamic range above its minimum; noise =
+ * everything outside the box, or (noise_db != NULL) the columns of an external
+ * noise spectrogram whose frequencies lie in [sel_low_hz, sel_high_hz].  Means
+ * are taken on linear power.  status: 0 = snr_db valid (+inf if there is no
+ * noise at all), 1 = no bin in the box, 2 = no bin above the threshold (the
+ * reference returns null for 1 and 2). */
+typedef struct sono_snr_result {
+    double snr_db, signal_mean_db, noise_mean_db;
+    double threshold_db, signal_max_db, signal_min_db;
+    uint64_t signal_count, noise_count;
+    int32_t status, pad;
+} sono_snr_result;
+int sono_rms_snr(sono_engine *e, const float *power_db, size_t frames, uint32_t num_bins, const float *freq_bins,
+                 int64_t start_idx, int64_t end_idx, double low_hz, double high_hz, const float *noise_db,
+                 size_t noise_frames, uint32_t noise_bins, const float *noise_freq_bins, double sel_low_hz,
+                 double sel_high_hz, sono_snr_result *out);
+
 /* ---- batched region analysis: processFullFile's per-region work
  * (batCallDetector.js:609-711) for all regions of a recording at once ---------- */
 

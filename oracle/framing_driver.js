@@ -37,7 +37,7 @@ function method(name, argNames) {
 }
 const names = ['fastScanSegmentsWasm', 'mergeAndPadSegments', 'generateSpectrogramWasm', 'detectCallSegments', 'savitzkyGolay', 'refineEndUsingOscillogram',
   'calculateZonalNoiseFloors', '_scanSpectrumForFrequency', 'calculateAutoHighpassFilterFreq', 'applyHighpassFilter',
-  '_applyButterworthStage', 'getQualityRating', 'calculateDuration'];
+  '_applyButterworthStage', 'getQualityRating', 'calculateDuration', 'calculateRMSbasedSNR'];
 const fns = {};
 for (const n of names) fns[n] = method(n);
 fns.detectCalls = method('detectCalls', ['audioData', 'sampleRate', 'flowKHz', 'fhighKHz', 'options']);
@@ -136,6 +136,29 @@ async function run() {
         scans.push(r ? r.freq_Hz : -1, r ? r.binIdx : -1);
       }
       emit(c.name, 'scans', f64(scans));
+    } else if (c.kind === 'snr') {
+      const sp = fns.generateSpectrogramWasm.call(self, x, c.sr, c.flow_khz, c.fhigh_khz);
+      const nb = sp.freqBins.length, F = sp.powerMatrix.length;
+      const db = new Float32Array(F * nb);
+      sp.powerMatrix.forEach((row, f) => db.set(row, f * nb));
+      emit(c.name, 'db', db); emit(c.name, 'freq', sp.freqBins); emit(c.name, 'shape', f64([F, nb]));
+      let noise = null;
+      if (c.noise_len > 0) {
+        noise = fns.generateSpectrogramWasm.call(self, inputs.subarray(c.noise_off, c.noise_off + c.noise_len), c.sr, c.flow_khz, c.fhigh_khz);
+        const nF = noise.powerMatrix.length, ndb = new Float32Array(nF * nb);
+        noise.powerMatrix.forEach((row, f) => ndb.set(row, f * nb));
+        emit(c.name, 'noise_db', ndb); emit(c.name, 'noise_shape', f64([nF, nb]));
+      }
+      const num = (v) => (v === null || v === undefined ? NaN : v);
+      const rows = [];
+      for (const q of c.queries) for (const useNoise of [false, true]) {
+        if (useNoise && !noise) continue;
+        const r = fns.calculateRMSbasedSNR.call(self, { lowFreq_kHz: q[0], highFreq_kHz: q[1] }, sp.powerMatrix, sp.freqBins, q[2], q[3],
+          c.flow_khz, c.fhigh_khz, useNoise ? noise : null);
+        rows.push(num(r.snr_dB), num(r.signalPowerMean_dB), num(r.noisePowerMean_dB), r.signalCount, r.noiseCount,
+          num(r.debug.signalThreshold), num(r.debug.signalMax), num(r.debug.signalMin), useNoise ? 1 : 0);
+      }
+      emit(c.name, 'snr', f64(rows));
     } else if (c.kind === 'filter') {
       for (const [hz, order] of c.filters) emit(c.name, 'hp_' + hz + '_' + order, fns.applyHighpassFilter.call(self, x, hz, c.sr, order));
       emit(c.name, 'auto', f64(c.peaks_khz.map((p) => fns.calculateAutoHighpassFilterFreq.call(self, p))));

@@ -279,3 +279,48 @@ def process_full_file(engine, audio, sample_rate, flow_khz, fhigh_khz, threshold
                                 duration_ms=k["duration_ms"], peakPower_dB=float(blk.max()),
                                 frames=k["endFrame"] - k["startFrame"] + 1, highpass_kHz=cutoff, roi=roi))
     return out
+
+
+def rms_snr(power_matrix, freq_bins, start_idx, end_idx, low_khz, high_khz, flow_khz, fhigh_khz, noise_matrix=None,
+            noise_freq_bins=None):
+    """calculateRMSbasedSNR, batCallDetector.js:402-571 ->
+    dict(snr_dB, signalPowerMean_dB, noisePowerMean_dB, signalCount, noiseCount, threshold, max, min); None where the
+    reference leaves null."""
+    p = np.asarray(power_matrix, np.float32).astype(np.float64)
+    fb = np.asarray(freq_bins, np.float32).astype(np.float64)
+    out = dict(snr_dB=None, signalPowerMean_dB=None, noisePowerMean_dB=None, signalCount=0, noiseCount=0, threshold=None,
+               max=None, min=None)
+    lo, hi = low_khz * 1000, high_khz * 1000                               # :423-424
+    in_f = (fb >= lo) & (fb <= hi)
+    t1 = min(end_idx, p.shape[0] - 1)
+    in_t = np.zeros(p.shape[0], bool)
+    if t1 >= start_idx:
+        in_t[max(start_idx, 0):t1 + 1] = True
+    box = in_t[:, None] & in_f[None, :]
+    if not box.any():                                                      # :452
+        return out
+    smax, smin = float(p[box].max()), float(p[box].min())
+    thr = smin + (smax - smin) * 0.25                                      # :460-462
+    out.update(threshold=thr, max=smax, min=smin)
+    sig = box & (p > thr)
+    signal_sum = float(np.sum(10.0 ** (p[sig] / 10)))                      # :479
+    signal_count = int(sig.sum())
+    if noise_matrix is not None and len(noise_matrix) > 0:                 # :496-516
+        q = np.asarray(noise_matrix, np.float32).astype(np.float64)
+        nfb = np.asarray(noise_freq_bins, np.float32).astype(np.float64)
+        sel = (nfb >= flow_khz * 1000) & (nfb <= fhigh_khz * 1000)
+        noise_sum = float(np.sum(10.0 ** (q[:, sel] / 10)))
+        noise_count = int(sel.sum()) * q.shape[0]
+    else:                                                                  # :522-538
+        noise_sum = float(np.sum(10.0 ** (p[~box] / 10)))
+        noise_count = int((~box).sum())
+    if signal_count == 0:                                                  # :543
+        return out
+    if noise_count == 0:                                                   # :548
+        out["snr_dB"] = math.inf
+        return out
+    s_mean, n_mean = signal_sum / signal_count, noise_sum / noise_count
+    out.update(signalPowerMean_dB=10 * math.log10(max(s_mean, 1e-16)), noisePowerMean_dB=10 * math.log10(max(n_mean, 1e-16)),
+               signalCount=signal_count, noiseCount=noise_count)
+    out["snr_dB"] = math.inf if n_mean < 1e-16 else 10 * math.log10(s_mean / n_mean)       # :562-568
+    return out

@@ -108,6 +108,12 @@ def build_cases():
         scan_stride=2)
     add("zonal_digital_silence", "zonal", np.zeros(5000, np.float32), sr, flow=5.0, fhigh=60.0, hop_percent=25.0,
         ranges=[[0, 5]], thresholds=[-100.0, -170.0], scan_stride=1)
+    # --- RMS-based SNR of a call box, against the rest of the selection or against an external noise spectrogram
+    h = pulse(9000, sr, 74, 3000, 4.0, 80000, 40000, 0.5, noise=0.03)
+    add("snr", "snr", h, sr, flow=20.0, fhigh=110.0, hop_percent=12.5, noise=0.03 * white(5000, 75, 1.0),
+        queries=[[40.0, 80.0, 20, 36], [45.0, 60.0, 24, 30], [20.0, 110.0, 0, 10000], [100.0, 105.0, 0, 5], [500.0, 600.0, 0, 5],
+                 [50.0, 50.2, 25, 25], [50.2, 50.3, 25, 25], [60.0, 40.0, 10, 20], [40.0, 80.0, 30, 20]])
+    add("snr_no_noise_case", "snr", h[:3000], sr, flow=30.0, fhigh=60.0, hop_percent=25.0, queries=[[30.0, 60.0, 0, 100], [0.0, 200.0, 0, 3]])
     # --- Butterworth high-pass, automatic corner frequency, Savitzky-Golay
     g = chirp(6000, sr, 73, period=0.01, t0=0.002) + 0.2 * tone(6000, sr, 8000.0, amp=1.0)
     add("filter", "filter", g, sr, filters=[[30000, 4], [25000, 2], [20000, 1], [20000, 3], [15000, 8], [10000, 12], [0, 4],
@@ -150,6 +156,8 @@ def main():
             print(f"  {n}: calls {arrays[n + '/calls'].reshape(-1, 5).round(5).tolist()}")
         elif c["kind"] == "calls":
             print(f"  {n}: calls {arrays[n + '/calls'].reshape(-1, 6).round(5).tolist()} zonal {arrays[n + '/zonal'].tolist()}")
+        elif c["kind"] == "snr":
+            print(f"  {n}: snr rows {arrays[n + '/snr'].reshape(-1, 9)[:, [0, 3, 4, 8]].round(4).tolist()}")
         elif c["kind"] == "refine":
             print(f"  {n}: refined {arrays[n + '/refined'].tolist()}")
         elif c["kind"] == "zonal":

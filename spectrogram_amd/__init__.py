@@ -73,6 +73,13 @@ class RoiCall(C.Structure):
 SONO_MAX_ZONES = 32
 
 
+class SnrResult(C.Structure):
+    """struct sono_snr_result."""
+    _fields_ = [("snr_db", C.c_double), ("signal_mean_db", C.c_double), ("noise_mean_db", C.c_double),
+                ("threshold_db", C.c_double), ("signal_max_db", C.c_double), ("signal_min_db", C.c_double),
+                ("signal_count", C.c_uint64), ("noise_count", C.c_uint64), ("status", C.c_int32), ("pad", C.c_int32)]
+
+
 class CallFrame(C.Structure):
     """struct sono_call_frame."""
     _fields_ = [("start_frame", C.c_uint64), ("end_frame", C.c_uint64), ("start_time_s", C.c_double),
@@ -160,6 +167,8 @@ _SIGNATURES = {
                                               C.POINTER(C.c_double), C.c_size_t, _szp, C.c_void_p]),
     "sono_db_percentile": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_double, C.POINTER(C.c_float)]),
     "sono_db_percentile_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.POINTER(C.c_float), C.c_void_p]),
+    "sono_rms_snr": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_uint32, _f32p, C.c_int64, C.c_int64, C.c_double, C.c_double,
+                               _f32p, C.c_size_t, C.c_uint32, _f32p, C.c_double, C.c_double, C.POINTER(SnrResult)]),
     "sono_refine_end_oscillogram": (C.c_int, [_f32p, C.c_size_t, C.c_double, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
     "sono_frame_calls": (C.c_int, [_segp, C.c_size_t, C.POINTER(C.c_double), C.c_size_t, _f32p, C.c_size_t, C.c_double,
                                    C.c_uint32, C.c_double, C.c_double, C.c_int, C.POINTER(CallFrame), C.c_size_t, _szp]),

@@ -345,6 +345,78 @@ int sono_db_percentile(sono_engine *e, const float *power_db, size_t count, doub
     return sono_db_percentile_dev(e, (const float *)e->d_db.p, count, fraction, value, nullptr);
 }
 
+int sono_rms_snr(sono_engine *e, const float *power_db, size_t frames, uint32_t nb, const float *freq_bins, int64_t start_idx,
+                 int64_t end_idx, double low_hz, double high_hz, const float *noise_db, size_t noise_frames, uint32_t noise_nb,
+                 const float *noise_freq_bins, double sel_low_hz, double sel_high_hz, sono_snr_result *out)
+{
+    if (!e || !out || (frames && nb && (!power_db || !freq_bins)))
+        return fail(SONO_EINVAL, "sono_rms_snr: NULL argument");
+    const bool external = noise_db && noise_frames && noise_nb;
+    if (external && !noise_freq_bins) return fail(SONO_EINVAL, "sono_rms_snr: noise_freq_bins is NULL");
+    std::memset(out, 0, sizeof(*out));
+    out->snr_db = out->signal_mean_db = out->noise_mean_db = NAN;
+    out->threshold_db = out->signal_max_db = out->signal_min_db = NAN;
+    out->status = 1;
+    if (frames == 0 || nb == 0 || end_idx < 0 || end_idx < start_idx || start_idx >= (int64_t)frames) return SONO_OK;
+    const size_t t0 = start_idx > 0 ? (size_t)start_idx : 0;
+    const size_t t1 = (uint64_t)end_idx < frames - 1 ? (size_t)end_idx : frames - 1;      // js:437: stop at the matrix end
+    std::vector<uint8_t> in_box(nb), sel(external ? noise_nb : 0);
+    bool any = false;
+    for (uint32_t b = 0; b < nb; ++b) {
+        const double f = (double)freq_bins[b];
+        in_box[b] = f >= low_hz && f <= high_hz;                                  // js:442
+        any = any || in_box[b];
+    }
+    if (!any) return SONO_OK;
+    for (uint32_t b = 0; b < (external ? noise_nb : 0u); ++b) {
+        const double f = (double)noise_freq_bins[b];
+        sel[b] = f >= sel_low_hz && f <= sel_high_hz;                             // js:510
+    }
+    DeviceGuard guard(e->device);
+    hipStream_t s = e->stream;
+    const size_t total = frames * (size_t)nb, ntotal = external ? noise_frames * (size_t)noise_nb : 0;
+    HIP_TRY(e->d_db.reserve((total + ntotal) * sizeof(float)));
+    float *d_db = (float *)e->d_db.p, *d_noise = d_db + total;
+    HIP_TRY(hipMemcpyAsync(d_db, power_db, total * sizeof(float), hipMemcpyHostToDevice, s));
+    if (external) HIP_TRY(hipMemcpyAsync(d_noise, noise_db, ntotal * sizeof(float), hipMemcpyHostToDevice, s));
+    // scratch: [2 doubles sums][2 u64 counts][2 u32 keys][nb box flags][noise_nb selection flags]
+    HIP_TRY(e->d_edges.reserve(48 + nb + sel.size() + 16));
+    char *base = (char *)e->d_edges.p;
+    double *d_sums = (double *)base;
+    unsigned long long *d_counts = (unsigned long long *)(base + 16);
+    uint32_t *d_keys = (uint32_t *)(base + 32);
+    uint8_t *d_box = (uint8_t *)(base + 48), *d_sel = d_box + nb;
+    struct { double sums[2]; unsigned long long counts[2]; uint32_t keys[2]; uint32_t pad[2]; } init = {{0, 0}, {0, 0}, {0u, 0xFFFFFFFFu}, {0, 0}};
+    HIP_TRY(hipMemcpyAsync(base, &init, 48, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_box, in_box.data(), nb, hipMemcpyHostToDevice, s));
+    if (external) HIP_TRY(hipMemcpyAsync(d_sel, sel.data(), sel.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(sono::launch_box_minmax(d_db, frames, nb, t0, t1, d_box, d_keys, s));
+    uint32_t keys[2];
+    HIP_TRY(hipMemcpyAsync(keys, d_keys, sizeof(keys), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (keys[0] == 0u || keys[1] == 0xFFFFFFFFu) return SONO_OK;                  // nothing comparable in the box
+    const double smax = (double)sono::detect_unkey(keys[0]), smin = (double)sono::detect_unkey(keys[1]);
+    if (smax == -INFINITY) return SONO_OK;                                        // js:452
+    const double threshold = smin + (smax - smin) * 0.25;                         // js:460-462
+    out->threshold_db = threshold; out->signal_max_db = smax; out->signal_min_db = smin;
+    HIP_TRY(sono::launch_box_sums(d_db, frames, nb, t0, t1, d_box, threshold, external ? 0 : 1, d_sums, d_counts, s));
+    if (external) HIP_TRY(sono::launch_band_linear_sum(d_noise, noise_frames, noise_nb, d_sel, d_sums, d_counts, s));
+    double sums[2];
+    unsigned long long counts[2];
+    HIP_TRY(hipMemcpyAsync(sums, d_sums, sizeof(sums), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (counts[0] == 0) { out->status = 2; return SONO_OK; }                      // js:543
+    out->status = 0;
+    if (counts[1] == 0) { out->snr_db = INFINITY; return SONO_OK; }               // js:548
+    const double s_mean = sums[0] / (double)counts[0], n_mean = sums[1] / (double)counts[1];
+    out->signal_mean_db = 10 * std::log10(s_mean > 1e-16 ? s_mean : 1e-16);       // js:557-558
+    out->noise_mean_db = 10 * std::log10(n_mean > 1e-16 ? n_mean : 1e-16);
+    out->signal_count = counts[0]; out->noise_count = counts[1];
+    out->snr_db = n_mean < 1e-16 ? INFINITY : 10 * std::log10(s_mean / n_mean);  // js:562-568
+    return SONO_OK;
+}
+
 int sono_refine_end_oscillogram(const float *audio, size_t n, double sample_rate, int64_t start_sample, int64_t end_sample,
                                 int64_t *refined)
 {

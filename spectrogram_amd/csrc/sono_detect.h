@@ -69,6 +69,19 @@ struct HighpassJob {
 hipError_t launch_highpass_regions(const float *d_src, float *d_dst, const HighpassJob *d_jobs, size_t jobs,
                                    const HighpassCoef *d_coefs, hipStream_t s);
 
+// calculateRMSbasedSNR's matrix passes (batCallDetector.js:436-538).  Box = rows t0..t1 (inclusive) x bins with
+// d_bin_in_box[b] != 0.  Pass 1: largest / smallest dB value inside the box, as detect_key()s in d_keys[0..1]
+// (the caller sets them to 0 and 0xFFFFFFFF).  Pass 2: d_sums[0] += 10^(dB/10) over box values > threshold,
+// d_counts[0] their number; if outside_is_noise, d_sums[1] / d_counts[1] the same over every value outside the box.
+hipError_t launch_box_minmax(const float *d_db, size_t frames, uint32_t nb, size_t t0, size_t t1,
+                             const uint8_t *d_bin_in_box, uint32_t *d_keys, hipStream_t s);
+hipError_t launch_box_sums(const float *d_db, size_t frames, uint32_t nb, size_t t0, size_t t1, const uint8_t *d_bin_in_box,
+                           double threshold_db, int outside_is_noise, double *d_sums, unsigned long long *d_counts,
+                           hipStream_t s);
+// d_sums[1] += 10^(dB/10) over the columns with d_bin_sel[b] != 0 of a whole matrix, d_counts[1] their number (js:505-516).
+hipError_t launch_band_linear_sum(const float *d_db, size_t frames, uint32_t nb, const uint8_t *d_bin_sel, double *d_sums,
+                                  unsigned long long *d_counts, hipStream_t s);
+
 // Ascending sort of `count` finite floats (d_in -> d_out).  d_temp == nullptr: size query.
 hipError_t sort_floats(void *d_temp, size_t &temp_bytes, const float *d_in, float *d_out, size_t count, hipStream_t s);
 

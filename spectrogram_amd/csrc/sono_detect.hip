@@ -186,6 +186,92 @@ __global__ __launch_bounds__(kThreads) void zone_hist_kernel(const float *db, si
         if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
 }
 
+__device__ __forceinline__ double block_sum(double v, double *s_part)
+{
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) for (int w = 0; w < kThreads / 64; ++w) t += s_part[w];
+    __syncthreads();
+    return t;                                   // valid in thread 0
+}
+
+__global__ __launch_bounds__(kThreads) void box_minmax_kernel(const float *db, uint32_t nb, size_t t0, size_t rows,
+                                                              const uint8_t *bin_in_box, uint32_t *keys)
+{
+    uint32_t hi = 0u, lo = 0xFFFFFFFFu;
+    const size_t count = rows * nb;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (size_t)gridDim.x * kThreads) {
+        if (!bin_in_box[i % nb]) continue;
+        const float v = db[t0 * nb + i];
+        if (v != v) continue;                    // a NaN loses both comparisons of the reference (js:444-445)
+        const uint32_t k = detect_key(v);
+        hi = k > hi ? k : hi;
+        lo = k < lo ? k : lo;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t oh = __shfl_xor(hi, o, 64), ol = __shfl_xor(lo, o, 64);
+        hi = oh > hi ? oh : hi;
+        lo = ol < lo ? ol : lo;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (hi != 0u) atomicMax(&keys[0], hi);
+        if (lo != 0xFFFFFFFFu) atomicMin(&keys[1], lo);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void box_sums_kernel(const float *db, size_t frames, uint32_t nb, size_t t0, size_t t1,
+                                                            const uint8_t *bin_in_box, double threshold, int outside_is_noise,
+                                                            double *sums, unsigned long long *counts)
+{
+    __shared__ double s_part[kThreads / 64];
+    double sig = 0.0, noise = 0.0;
+    unsigned long long n_sig = 0, n_noise = 0;
+    const size_t count = frames * nb;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (size_t)gridDim.x * kThreads) {
+        const size_t t = i / nb;
+        const bool in_box = t >= t0 && t <= t1 && bin_in_box[i - t * nb];
+        if (!in_box && !outside_is_noise) continue;
+        const double v = (double)db[i];
+        if (in_box) {
+            if (v > threshold) { sig += pow(10.0, v / 10); ++n_sig; }             // js:478-481
+        } else {
+            noise += pow(10.0, v / 10);                                          // js:532-536
+            ++n_noise;
+        }
+    }
+    const double a = block_sum(sig, s_part), b = block_sum(noise, s_part);
+    for (int o = 32; o > 0; o >>= 1) { n_sig += __shfl_xor(n_sig, o, 64); n_noise += __shfl_xor(n_noise, o, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_sig) atomicAdd(&counts[0], n_sig);
+        if (n_noise) atomicAdd(&counts[1], n_noise);
+    }
+    if (threadIdx.x == 0) {
+        if (a != 0.0) atomicAdd(&sums[0], a);
+        if (b != 0.0) atomicAdd(&sums[1], b);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void band_linear_sum_kernel(const float *db, size_t frames, uint32_t nb,
+                                                                   const uint8_t *bin_sel, double *sums,
+                                                                   unsigned long long *counts)
+{
+    __shared__ double s_part[kThreads / 64];
+    double acc = 0.0;
+    unsigned long long n = 0;
+    const size_t count = frames * nb;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (size_t)gridDim.x * kThreads) {
+        if (!bin_sel[i % nb]) continue;
+        acc += pow(10.0, (double)db[i] / 10);                                    // js:512
+        ++n;
+    }
+    const double a = block_sum(acc, s_part);
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(&counts[1], n);
+    if (threadIdx.x == 0 && a != 0.0) atomicAdd(&sums[1], a);
+}
+
 __global__ __launch_bounds__(kThreads) void zone_floors_regions_kernel(const float *db, const unsigned long long *first_row,
                                                                        const unsigned int *rows_used, uint32_t nb,
                                                                        const uint8_t *zone_of_bin, uint32_t num_zones,
@@ -261,6 +347,40 @@ hipError_t launch_zone_floors_regions(const float *d_db, const unsigned long lon
     const size_t lds = (size_t)num_zones * kZoneHistBins * sizeof(unsigned int);
     hipLaunchKernelGGL(zone_floors_regions_kernel, dim3((unsigned int)regions), dim3(kThreads), lds, s, d_db, d_first_row,
                        d_rows_used, nb, d_zone_of_bin, num_zones, zone_stride, d_floors);
+    return hipGetLastError();
+}
+
+static unsigned int reduce_grid(size_t count)
+{
+    size_t blocks = (count + (size_t)kThreads * 8 - 1) / ((size_t)kThreads * 8);
+    return (unsigned int)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks);
+}
+
+hipError_t launch_box_minmax(const float *d_db, size_t frames, uint32_t nb, size_t t0, size_t t1, const uint8_t *d_bin_in_box,
+                             uint32_t *d_keys, hipStream_t s)
+{
+    if (frames == 0 || nb == 0 || t0 > t1 || t0 >= frames) return hipSuccess;
+    const size_t rows = (t1 < frames - 1 ? t1 : frames - 1) - t0 + 1;
+    hipLaunchKernelGGL(box_minmax_kernel, dim3(reduce_grid(rows * nb)), dim3(kThreads), 0, s, d_db, nb, t0, rows, d_bin_in_box,
+                       d_keys);
+    return hipGetLastError();
+}
+
+hipError_t launch_box_sums(const float *d_db, size_t frames, uint32_t nb, size_t t0, size_t t1, const uint8_t *d_bin_in_box,
+                           double threshold_db, int outside_is_noise, double *d_sums, unsigned long long *d_counts, hipStream_t s)
+{
+    if (frames == 0 || nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(box_sums_kernel, dim3(reduce_grid(frames * nb)), dim3(kThreads), 0, s, d_db, frames, nb, t0, t1,
+                       d_bin_in_box, threshold_db, outside_is_noise, d_sums, d_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_band_linear_sum(const float *d_db, size_t frames, uint32_t nb, const uint8_t *d_bin_sel, double *d_sums,
+                                  unsigned long long *d_counts, hipStream_t s)
+{
+    if (frames == 0 || nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(band_linear_sum_kernel, dim3(reduce_grid(frames * nb)), dim3(kThreads), 0, s, d_db, frames, nb, d_bin_sel,
+                       d_sums, d_counts);
     return hipGetLastError();
 }
 

@@ -10,13 +10,14 @@ import math
 
 import numpy as np
 
+from . import SnrResult as _SnrResult
 from . import (CallFrame as _CallFrame, RoiCall as _RoiCall, RoiTable as _RoiTable, Segment as _Segment, SONO_MAX_ZONES, _check,
                _f32, _p, lib)
 from . import detector as _det
 
 __all__ = ["calculate_zonal_noise_floors", "db_percentile", "refine_end_using_oscillogram", "frame_calls",
            "scan_spectrum_for_frequency", "calculate_auto_highpass_filter_freq", "apply_highpass_filter",
-           "savitzky_golay", "detect_calls_framing", "process_full_file", "process_full_file_batched",
+           "savitzky_golay", "detect_calls_framing", "process_full_file", "process_full_file_batched", "calculate_rms_based_snr",
            "DEFAULT_FRAMING_CONFIG"]
 
 # the members of DEFAULT_DETECTION_CONFIG (batCallDetector.js:3-45) this stage reads
@@ -243,3 +244,28 @@ def process_full_file_batched(engine, full_audio_data, sample_rate, flow_khz, fh
             "zonalNoiseMap": {10 * z: float(zonal[r * SONO_MAX_ZONES + z]) for z in range(table.num_zones)},
         })
     return calls
+
+
+def calculate_rms_based_snr(engine, call, spectrogram, freq_bins, signal_start_idx, signal_end_idx, flow_khz, fhigh_khz,
+                            noise_spectrogram=None):
+    """calculateRMSbasedSNR (batCallDetector.js:402-571).  call: {'lowFreq_kHz', 'highFreq_kHz'}; noise_spectrogram:
+    generate_spectrogram's dict or None.  -> {'snr_dB' (None where the reference leaves null), 'mechanism',
+    'signalPowerMean_dB', 'noisePowerMean_dB', 'signalCount', 'noiseCount', 'signalThreshold', 'signalMax', 'signalMin'}."""
+    p = np.ascontiguousarray(spectrogram, dtype=np.float32)
+    fb = _f32(freq_bins)
+    F, B = (p.shape if p.ndim == 2 else (0, fb.size))
+    ext = noise_spectrogram is not None and len(noise_spectrogram["powerMatrix"]) > 0
+    if ext:
+        q = np.ascontiguousarray(noise_spectrogram["powerMatrix"], dtype=np.float32)
+        nfb = _f32(noise_spectrogram["freqBins"])
+    r = _SnrResult()
+    _check(lib().sono_rms_snr(engine._handle(), _p(p) if p.size else None, F, B, _p(fb), int(signal_start_idx), int(signal_end_idx),
+                              float(call["lowFreq_kHz"]) * 1000, float(call["highFreq_kHz"]) * 1000,
+                              _p(q) if ext else None, q.shape[0] if ext else 0, q.shape[1] if ext else 0, _p(nfb) if ext else None,
+                              float(flow_khz) * 1000, float(fhigh_khz) * 1000, C.byref(r)))
+    nn = lambda v: None if v != v else v
+    return {"snr_dB": r.snr_db if r.status == 0 else None,
+            "mechanism": "RMS-based (Last 10ms)" if ext else "RMS-based (Fallback Internal)",
+            "signalPowerMean_dB": nn(r.signal_mean_db), "noisePowerMean_dB": nn(r.noise_mean_db),
+            "signalCount": int(r.signal_count), "noiseCount": int(r.noise_count), "signalThreshold": nn(r.threshold_db),
+            "signalMax": nn(r.signal_max_db), "signalMin": nn(r.signal_min_db)}

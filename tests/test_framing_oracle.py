@@ -99,3 +99,33 @@ def test_process_full_file(golden):
             assert abs(k["peakPower_dB"] + 80 - w[3]) < 2e-3 and k["frames"] == int(w[4])
             seen += 1
     assert seen >= 6
+
+
+def _snr_row(r, used_noise):
+    nan = float("nan")
+    f = lambda v: nan if v is None else v
+    return [f(r["snr_dB"]), f(r["signalPowerMean_dB"]), f(r["noisePowerMean_dB"]), r["signalCount"], r["noiseCount"],
+            f(r["threshold"]), f(r["max"]), f(r["min"]), 1 if used_noise else 0]
+
+
+def test_rms_snr(golden):
+    g, meta = golden
+    for c in cases(meta, "snr"):
+        n = c["name"]
+        F, nb = (int(v) for v in g[n + "/shape"])
+        db, fb = g[n + "/db"].reshape(F, nb), g[n + "/freq"]
+        noise = g[n + "/noise_db"].reshape(-1, nb) if n + "/noise_db" in g.files else None
+        rows = []
+        for q in c["queries"]:
+            for use in (False, True):
+                if use and noise is None:
+                    continue
+                rows.append(_snr_row(fo.rms_snr(db, fb, q[2], q[3], q[0], q[1], c["flow_khz"], c["fhigh_khz"],
+                                                noise if use else None, fb), use))
+        want = g[n + "/snr"].reshape(-1, 9)
+        got = np.asarray(rows, np.float64)
+        assert got.shape == want.shape
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want)), n
+        fin = np.isfinite(want)
+        assert np.array_equal(got[:, [3, 4, 8]], want[:, [3, 4, 8]])            # counts: exact
+        assert np.allclose(got[fin], want[fin], rtol=1e-12, atol=1e-12), n      # sums in another order

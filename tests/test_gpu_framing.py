@@ -155,3 +155,37 @@ def test_batched_region_analysis_on_a_long_recording():
     _same_calls(one, batched)
     assert {c["highpass_kHz"] for c in batched} >= {0.0, 20.0, 25.0, 30.0}
     e.free()
+
+
+def test_rms_based_snr(golden):
+    g, meta = golden
+    e = sa.SpectrogramEngine(1024, "hann")
+    for c in cases(meta, "snr"):
+        n = c["name"]
+        F, nb = (int(v) for v in g[n + "/shape"])
+        db, fb = g[n + "/db"].reshape(F, nb), g[n + "/freq"]
+        noise = None
+        if n + "/noise_db" in g.files:
+            noise = {"powerMatrix": g[n + "/noise_db"].reshape(-1, nb), "freqBins": fb}
+        want = g[n + "/snr"].reshape(-1, 9)
+        k = 0
+        for q in c["queries"]:
+            for use in (False, True):
+                if use and noise is None:
+                    continue
+                r = fr.calculate_rms_based_snr(e, {"lowFreq_kHz": q[0], "highFreq_kHz": q[1]}, db, fb, q[2], q[3],
+                                               c["flow_khz"], c["fhigh_khz"], noise if use else None)
+                w = want[k]
+                k += 1
+                if np.isnan(w[0]):
+                    assert r["snr_dB"] is None, (n, q, r)
+                elif np.isinf(w[0]):
+                    assert r["snr_dB"] == float("inf")
+                else:
+                    assert abs(r["snr_dB"] - w[0]) <= 1e-10 * max(1.0, abs(w[0])), (n, q, r, w)
+                    assert abs(r["signalPowerMean_dB"] - w[1]) <= 1e-10 and abs(r["noisePowerMean_dB"] - w[2]) <= 1e-10
+                    assert (r["signalCount"], r["noiseCount"]) == (int(w[3]), int(w[4]))
+                if not np.isnan(w[5]):
+                    assert (r["signalThreshold"], r["signalMax"], r["signalMin"]) == (w[5], w[6], w[7])
+        assert k == len(want)
+    e.free()
