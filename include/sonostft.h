@@ -317,6 +317,11 @@ int sono_frame_calls(const sono_segment *segs, size_t count, const double *time_
 int sono_scan_spectrum_for_frequency(const float *row_db, const float *freq_bins, size_t num_bins,
                                      double threshold_db, int high_to_low, double *freq_hz, int64_t *bin);
 
+/* First step of measureFrequencyParameters (batCallDetector.js:3021-3036): the
+ * peak frequency in kHz of the row's bin `bin`, moved by a parabola through the
+ * bin and its two neighbours where it has both.  Host only. */
+int sono_peak_frequency_khz(const float *row_db, const float *freq_bins, size_t num_bins, int64_t bin, double *khz);
+
 /* calculateAutoHighpassFilterFreq (batCallDetector.js:4028-4035): corner in kHz. */
 double sono_auto_highpass_khz(double peak_freq_khz);
 
@@ -358,6 +363,8 @@ typedef struct sono_roi_table {
     float *peak_db;        /* one per analysis frame: largest dB value of the frame inside the band
                               (after the automatic high-pass where it applies) */
     int32_t *peak_bin;     /* its bin, counted from the band's first bin */
+    float *peak_left_db;   /* one per frame: the dB values next to the peak bin (NaN where the peak sits on the */
+    float *peak_right_db;  /* band's edge): inputs of the parabolic peak interpolation (js:3021-3034) */
     double *zonal;         /* n_rois * SONO_MAX_ZONES: calculateZonalNoiseFloors of the region's first six frames */
     float *highpass_khz;   /* n_rois: corner of the automatic high-pass, 0 = none */
     /* filled in by sono_analyze_rois */
@@ -384,6 +391,8 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
 typedef struct sono_roi_call {
     uint64_t roi, start_frame, end_frame, peak_frame;           /* frames inside the region */
     double start_time_s, end_time_s, duration_ms, peak_time_s;  /* times from the start of the recording */
+    double peak_freq_khz;   /* measureFrequencyParameters' first step (js:3009-3036): parabolic peak frequency ... */
+    double peak_freq_ms;    /* ... and the peak's time after the call's first frame (js:3039-3045) */
     float peak_power_db;
     int32_t peak_bin;
 } sono_roi_call;

@@ -41,6 +41,16 @@ const names = ['fastScanSegmentsWasm', 'mergeAndPadSegments', 'generateSpectrogr
 const fns = {};
 for (const n of names) fns[n] = method(n);
 fns.detectCalls = method('detectCalls', ['audioData', 'sampleRate', 'flowKHz', 'fhighKHz', 'options']);
+// STEP 0 of measureFrequencyParameters (peak bin, parabolic peak frequency, peak time): the method's text up to the
+// comment that opens its next step; that prefix is a complete sequence of statements.
+const peakStep = (() => {
+  const m = /\n  measureFrequencyParameters\(([^)]*)\) \{/.exec(src);
+  const start = m.index + m[0].length;
+  const cut = src.indexOf('[STEP 0.5]', start);
+  if (cut < 0) throw new Error('STEP 0.5 marker not found');
+  const end = src.lastIndexOf('// ====', cut);            // the banner line above the marker
+  return new Function(...m[1].split(',').map((t) => t.trim()), src.slice(start, end));
+})();
 
 const cases = JSON.parse(fs.readFileSync(path.join(work, 'cases.json'), 'utf8'));
 const inBuf = fs.readFileSync(path.join(work, 'inputs.bin'));
@@ -82,7 +92,10 @@ async function run() {
       for (const row of call.spectrogram) for (let b = 0; b < row.length; b++) if (row[b] > peak) peak = row[b];
       call.peakPower_dB = peak;
       call.lowFreq_kHz = 0; call.highFreq_kHz = 0;
-      captured.push({ frames: call.spectrogram.length, zonal: zoneArray(zonalNoiseMap) });
+      peakStep.call(self, call, flowKHz, fhighKHz, freqBins, freqResolution, zonalNoiseMap);      // the reference's own STEP 0
+      if (call.peakPower_dB !== peak) throw new Error('stand-in and STEP 0 disagree on the peak power');
+      captured.push({ frames: call.spectrogram.length, zonal: zoneArray(zonalNoiseMap), peakFreq_kHz: call.peakFreq_kHz,
+        peakFreq_ms: call.peakFreq_ms, peakFrameIdx: call.peakFrameIdx });
     };
 
     function BatCall() {
@@ -103,6 +116,7 @@ async function run() {
       const calls = await processFullFile.call(self, BatCall, CallTypeClassifier, x, c.sr, c.flow_khz, c.fhigh_khz,
         { threshold_dB: c.scan_threshold_db, padding_ms: c.padding_ms });
       emit(c.name, 'calls', f64([].concat(...calls.map((k) => [k.startTime_s, k.endTime_s, k.duration_ms, k.snr_dB, k.spectrogram.length]))));
+      emit(c.name, 'peaks', f64([].concat(...calls.map((k) => [k.peakFreq_kHz, k.peakFreq_ms, k.peakFrameIdx, k.peakPower_dB]))));
       emit(c.name, 'zonal_first', captured.length ? captured[0].zonal : new Float64Array(0));
       emit(c.name, 'measured_frames', f64(captured.map((k) => k.frames)));
     } else if (c.kind === 'calls') {
@@ -112,6 +126,7 @@ async function run() {
       const calls = await detectCalls.call(self, BatCall, CallTypeClassifier, x, c.sr, c.flow_khz, c.fhigh_khz, { skipSNR: true, noiseSpectrogram: noise });
       emit(c.name, 'calls', f64([].concat(...calls.map((k) => [k.startTime_s, k.endTime_s, k.duration_ms, k.noiseFloor_dB, k.snr_dB, k.spectrogram.length]))));
       emit(c.name, 'measured_frames', f64(captured.map((k) => k.frames)));
+      emit(c.name, 'peaks', f64([].concat(...calls.map((k) => [k.peakFreq_kHz, k.peakFreq_ms, k.peakFrameIdx, k.peakPower_dB]))));
       emit(c.name, 'zonal', captured.length ? captured[0].zonal : new Float64Array(0));
     } else if (c.kind === 'refine') {
       const out = [];

@@ -459,6 +459,17 @@ int sono_scan_spectrum_for_frequency(const float *row_db, const float *freq_bins
     return SONO_OK;
 }
 
+int sono_peak_frequency_khz(const float *row_db, const float *freq_bins, size_t num_bins, int64_t bin, double *khz)
+{
+    if (!row_db || !freq_bins || !khz || bin < 0 || (uint64_t)bin >= num_bins)
+        return fail(SONO_EINVAL, "sono_peak_frequency_khz: NULL argument or bin outside the row");
+    const bool interior = bin > 0 && (uint64_t)bin + 1 < num_bins;
+    const double width = num_bins > 1 ? (double)freq_bins[1] - (double)freq_bins[0] : 0.0;          // js:3031
+    *khz = sono::host_peak_freq_khz(interior ? row_db[bin - 1] : 0.0f, row_db[bin], interior ? row_db[bin + 1] : 0.0f, interior,
+                                    freq_bins[bin], width);
+    return SONO_OK;
+}
+
 double sono_auto_highpass_khz(double peak_freq_khz) { return sono::host_auto_highpass_khz(peak_freq_khz); }
 
 int sono_highpass_filter(const float *in, size_t n, double filter_hz, double sample_rate, double order, float *out)

@@ -46,31 +46,31 @@ Band band_of(uint32_t N, double sample_rate, double flow_khz, double fhigh_khz, 
 // One pass over a set of regions whose samples sit at d_src + off[i]: magnitudes -> dB crop -> per-frame peak.
 // feat_rows[i] = where region i's records go in the host arrays.
 int peaks_pass(sono_engine *e, const float *d_src, const std::vector<uint64_t> &off, const std::vector<uint64_t> &len,
-               const std::vector<uint64_t> &feat_rows, const Band &b, size_t frames, float *peak_db, int32_t *peak_bin,
+               const std::vector<uint64_t> &feat_rows, const Band &b, size_t frames, const sono_roi_table *t,
                std::vector<uint64_t> *first_row_out)
 {
     const uint32_t N = e->N, bins = N / 2;
     HIP_TRY(e->d_mags.reserve(frames * bins * sizeof(float)));
     HIP_TRY(e->d_db.reserve(frames * b.nb * sizeof(float)));
-    HIP_TRY(e->d_out.reserve(frames * sizeof(sono_frame_features)));
+    HIP_TRY(e->d_out.reserve(frames * sizeof(sono::FramePeak)));
     sono_ragged_batch rb{d_src, off.size(), off.data(), len.data()};
     int rc = sono_stft_mag_f32_ragged_dev(e, &rb, b.noverlap, (float *)e->d_mags.p, nullptr);
     if (rc) return rc;
     rc = sono_detect_power_db_dev(e, (const float *)e->d_mags.p, frames, bins, b.min_bin, b.nb, (float *)e->d_db.p, nullptr);
     if (rc) return rc;
-    rc = sono_detect_frame_features_dev(e, (const float *)e->d_db.p, frames, b.nb, 0, b.nb - 1, 0, INFINITY, b.nb, INFINITY,
-                                        (sono_frame_features *)e->d_out.p, nullptr);
-    if (rc) return rc;
-    std::vector<sono_frame_features> feat(frames);
-    HIP_TRY(hipMemcpyAsync(feat.data(), e->d_out.p, frames * sizeof(sono_frame_features), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(sono::launch_frame_peaks((const float *)e->d_db.p, frames, b.nb, (sono::FramePeak *)e->d_out.p, e->stream));
+    std::vector<sono::FramePeak> feat(frames);
+    HIP_TRY(hipMemcpyAsync(feat.data(), e->d_out.p, frames * sizeof(sono::FramePeak), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     size_t row = 0;
     for (size_t i = 0; i < off.size(); ++i) {
         const size_t F = sono_frames_for((size_t)len[i], N, b.noverlap);
         if (first_row_out) (*first_row_out)[i] = row;
         for (size_t f = 0; f < F; ++f) {
-            peak_db[feat_rows[i] + f] = feat[row + f].peak_db;
-            peak_bin[feat_rows[i] + f] = feat[row + f].peak_bin;
+            t->peak_db[feat_rows[i] + f] = feat[row + f].db;
+            t->peak_bin[feat_rows[i] + f] = feat[row + f].bin;
+            t->peak_left_db[feat_rows[i] + f] = feat[row + f].left;
+            t->peak_right_db[feat_rows[i] + f] = feat[row + f].right;
         }
         row += F;
     }
@@ -118,7 +118,7 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
     int rc = sono_roi_rows(rois, n_rois, N, hop_percent, out->row0);
     if (rc) return rc;
     const size_t total = (size_t)out->row0[n_rois];
-    if (total > frames_cap || (total && (!out->peak_db || !out->peak_bin)))
+    if (total > frames_cap || (total && (!out->peak_db || !out->peak_bin || !out->peak_left_db || !out->peak_right_db)))
         return fail(SONO_ECAPACITY, "sono_analyze_rois: per-frame output arrays too small");
     // frequency axis and its 10 kHz zones (js:1342-1344, 1837-1839)
     std::vector<float> freq_bins(b.nb);
@@ -164,7 +164,7 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
         }
         HIP_TRY(e->d_in.reserve(packed.size() * sizeof(float)));
         HIP_TRY(hipMemcpyAsync(e->d_in.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, s));
-        rc = peaks_pass(e, (const float *)e->d_in.p, off, len, rows, b, frames, out->peak_db, out->peak_bin, &first_row);
+        rc = peaks_pass(e, (const float *)e->d_in.p, off, len, rows, b, frames, out, &first_row);
         if (rc) return rc;
         // ---- noise floors of every region's first six frames (js:622-627), from the unfiltered spectrogram ----
         {
@@ -233,7 +233,7 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
                         std::memcpy(x_filtered + rois[r0 + job_region[k]].start, filt.data() + jobs[k].dst,
                                     (size_t)jobs[k].len * sizeof(float));
                 }
-                rc = peaks_pass(e, (const float *)e->d_runs.p, off2, len2, rows2, b, frames2, out->peak_db, out->peak_bin, nullptr);
+                rc = peaks_pass(e, (const float *)e->d_runs.p, off2, len2, rows2, b, frames2, out, nullptr);
                 if (rc) return rc;
             }
         }
@@ -302,6 +302,16 @@ int sono_frame_roi_calls(const float *x, size_t n, const sono_segment *rois, siz
                 o.peak_time_s = tf[pk] + offset;
                 o.peak_power_db = pdb[pk];
                 o.peak_bin = t->peak_bin[row + pk];
+                {
+                    const int32_t pb = o.peak_bin;
+                    const bool interior = pb > 0 && (uint32_t)pb + 1 < t->num_bins;                      // js:3023
+                    const double res = sample_rate / (double)fft_size;
+                    const float f_bin = (float)((double)(t->min_bin + (uint32_t)(pb < 0 ? 0 : pb)) * res);
+                    const double width = (double)(float)((double)(t->min_bin + 1) * res) - (double)(float)((double)t->min_bin * res);
+                    o.peak_freq_khz = sono::host_peak_freq_khz(t->peak_left_db[row + pk], pdb[pk], t->peak_right_db[row + pk], interior,
+                                                               f_bin, width);
+                    o.peak_freq_ms = (tf[pk] - tf[(size_t)k.start_frame]) * 1000;                        // js:3041-3043
+                }
             }
         }
     }

@@ -33,6 +33,11 @@ hipError_t launch_frame_features(const float *d_db, size_t frames, uint32_t nb, 
                                  uint32_t low_max_bin, double low_threshold_db, uint32_t high_min_bin,
                                  double high_threshold_db, sono_frame_features *d_out, hipStream_t s);
 
+// Per row: first bin of the largest value, the value, and its two neighbours (NaN at the ends of the row) --
+// what the parabolic peak interpolation of measureFrequencyParameters needs (batCallDetector.js:3010-3034).
+struct FramePeak { int32_t bin; float db, left, right; };
+hipError_t launch_frame_peaks(const float *d_db, size_t frames, uint32_t nb, FramePeak *d_out, hipStream_t s);
+
 // First / last frame of every maximal run of non-zero flags, as two flag arrays.
 hipError_t launch_run_edges(const uint8_t *d_active, size_t frames, uint8_t *d_is_start, uint8_t *d_is_end,
                             hipStream_t s);

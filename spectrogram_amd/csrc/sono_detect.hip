@@ -124,6 +124,34 @@ __global__ __launch_bounds__(kThreads) void frame_features_kernel(const float *d
     }
 }
 
+__global__ __launch_bounds__(kThreads) void frame_peaks_kernel(const float *db, size_t frames, uint32_t nb, FramePeak *out)
+{
+    const size_t f = (size_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (f >= frames) return;
+    const float *row = db + f * nb;
+    float best = -INFINITY;
+    int best_bin = -1;
+    for (uint32_t b = lane; b < nb; b += 64) {
+        const float v = row[b];
+        if (v > best) { best = v; best_bin = (int)b; }              // strict >, b ascends: the first maximum of the lane
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int ob = __shfl_xor(best_bin, o, 64);
+        const bool take = ob >= 0 && (best_bin < 0 || ov > best || (ov == best && ob < best_bin));
+        if (take) { best = ov; best_bin = ob; }
+    }
+    if (lane == 0) {
+        FramePeak r;
+        r.bin = best_bin;
+        r.db = best;
+        r.left = best_bin > 0 ? row[best_bin - 1] : NAN;
+        r.right = best_bin >= 0 && (uint32_t)best_bin + 1 < nb ? row[best_bin + 1] : NAN;
+        out[f] = r;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void run_edges_kernel(const uint8_t *active, size_t frames, uint8_t *is_start,
                                                              uint8_t *is_end)
 {
@@ -454,6 +482,13 @@ hipError_t launch_frame_features(const float *d_db, size_t frames, uint32_t nb, 
     if (frames == 0) return hipSuccess;
     hipLaunchKernelGGL(frame_features_kernel, dim3(rows_grid(frames)), dim3(kThreads), 0, s, d_db, frames, nb, peak_b0,
                        peak_b1, low_max_bin, low_thr, high_min_bin, high_thr, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_frame_peaks(const float *d_db, size_t frames, uint32_t nb, FramePeak *d_out, hipStream_t s)
+{
+    if (frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(frame_peaks_kernel, dim3(rows_grid(frames)), dim3(kThreads), 0, s, d_db, frames, nb, d_out);
     return hipGetLastError();
 }
 

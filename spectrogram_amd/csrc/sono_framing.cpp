@@ -186,6 +186,17 @@ bool host_frame_calls(const FrameRun *segs, size_t count, const double *tf, size
     return true;
 }
 
+double host_peak_freq_khz(float left_db, float peak_db, float right_db, bool interior, float bin_freq_hz, double bin_width_hz)
+{
+    double f = (double)bin_freq_hz;                                              // js:3022
+    if (interior) {
+        const double db0 = (double)left_db, db1 = (double)peak_db, db2 = (double)right_db;
+        const double a = (db2 - 2 * db1 + db0) / 2;                              // js:3028
+        if (std::fabs(a) > 1e-10) f = (double)bin_freq_hz + ((db0 - db2) / (4 * a)) * bin_width_hz;    // js:3029-3032
+    }
+    return f / 1000;                                                             // js:3036
+}
+
 size_t host_zone_map(const float *fb, size_t n, std::vector<uint8_t> &zone_of_bin)
 {
     zone_of_bin.assign(n, 255);

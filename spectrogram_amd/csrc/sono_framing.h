@@ -39,6 +39,10 @@ bool host_frame_calls(const FrameRun *segs, size_t count, const double *time_fra
                       size_t n, double sample_rate, uint32_t fft_size, double padding_ms, double min_call_duration_ms,
                       bool full_file_rules, std::vector<CallFrame> &out);
 
+// Peak frequency of measureFrequencyParameters' first step (batCallDetector.js:3021-3036), kHz: the peak bin's
+// centre, moved by a parabola through the peak and its two neighbours where it has both (interior = true).
+double host_peak_freq_khz(float left_db, float peak_db, float right_db, bool interior, float bin_freq_hz, double bin_width_hz);
+
 // Zone bookkeeping of calculateZonalNoiseFloors (batCallDetector.js:1837-1839, 1863-1864):
 // zone index of every bin, number of zones.
 size_t host_zone_map(const float *freq_bins, size_t n, std::vector<uint8_t> &zone_of_bin);

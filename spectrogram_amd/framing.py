@@ -141,7 +141,8 @@ def process_full_file(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz,
     """processFullFile (batCallDetector.js:584-840) without the measurement stage: fast scan -> merge & pad ->
     per region: analysis spectrogram, automatic high-pass, call segments, strongest-first 30 ms echo filter,
     5 ms padding + oscillogram refinement -> calls in the reference's order (per region, strongest first):
-    {'startTime_s', 'endTime_s', 'duration_ms' (file time), 'peakPower_dB', 'peakTime_s', 'peakFreq_kHz', 'snr_dB'
+    {'startTime_s', 'endTime_s', 'duration_ms' (file time), 'peakPower_dB', 'peakTime_s', 'peakFreq_kHz' and 'peakFreq_ms'
+    (the first step of measureFrequencyParameters, js:3009-3045), 'snr_dB'
     (peak + 80, js:818), 'roi', 'startFrame', 'endFrame', 'highpass_kHz', 'zonalNoiseMap'}.
     options: {'threshold_dB': -60, 'padding_ms': 5} as in the reference."""
     opt = dict({"threshold_dB": -60, "padding_ms": 5}, **(options or {}))
@@ -189,11 +190,14 @@ def process_full_file(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz,
             for k in framed:
                 f0, f1 = k["startFrame"], k["endFrame"]
                 kk = f0 + int(np.argmax(peak_db[f0:f1 + 1]))
+                khz = C.c_double(0)
+                _check(lib().sono_peak_frequency_khz(_p(power[kk]), _p(fb), nb, int(peak_bin[kk]), C.byref(khz)))       # js:3021-3036
                 calls.append({
                     "roi": roi, "startFrame": f0, "endFrame": f1, "startTime_s": k["startTime_s"] + offset,
                     "endTime_s": k["endTime_s"] + offset, "duration_ms": k["duration_ms"],
                     "peakPower_dB": float(peak_db[kk]), "peakTime_s": float(tf[kk]) + offset,
-                    "peakFreq_kHz": float(fb[peak_bin[kk]]) / 1000, "snr_dB": float(peak_db[kk]) + 80.0,       # js:818
+                    "peakFreq_kHz": khz.value, "peakFreq_ms": (float(tf[kk]) - float(tf[f0])) * 1000,           # js:3036-3043
+                    "snr_dB": float(peak_db[kk]) + 80.0,                                                       # js:818
                     "highpass_kHz": cutoff, "zonalNoiseMap": zonal,
                 })
     return calls
@@ -221,8 +225,9 @@ def process_full_file_batched(engine, full_audio_data, sample_rate, flow_khz, fh
     peak_bin = np.zeros(max(total, 1), np.int32)
     zonal = np.zeros(n * SONO_MAX_ZONES, np.float64)
     hp = np.zeros(n, np.float32)
-    table = _RoiTable(row0.ctypes.data_as(u64p), _p(peak_db), peak_bin.ctypes.data_as(i32p), zonal.ctypes.data_as(dp), _p(hp),
-                      0, 0, 0, 0)
+    left, right = np.zeros_like(peak_db), np.zeros_like(peak_db)
+    table = _RoiTable(row0.ctypes.data_as(u64p), _p(peak_db), peak_bin.ctypes.data_as(i32p), _p(left), _p(right),
+                      zonal.ctypes.data_as(dp), _p(hp), 0, 0, 0, 0)
     xf = x.copy()
     _check(lib().sono_analyze_rois(engine._handle(), _p(x), x.size, rois, n, float(sample_rate), float(flow_khz), float(fhigh_khz),
                                    float(cfg["hopPercent"]), 1, C.byref(table), total, _p(xf)))
@@ -231,7 +236,6 @@ def process_full_file_batched(engine, full_audio_data, sample_rate, flow_khz, fh
     got = C.c_size_t(0)
     _check(lib().sono_frame_roi_calls(_p(xf), xf.size, rois, n, C.byref(table), float(sample_rate), n_fft,
                                       float(cfg["callThreshold_dB"]), float(cfg["minCallDuration_ms"]), out, cap, C.byref(got)))
-    res = sample_rate / n_fft
     calls = []
     for i in range(got.value):
         c = out[i]
@@ -239,7 +243,7 @@ def process_full_file_batched(engine, full_audio_data, sample_rate, flow_khz, fh
         calls.append({
             "roi": r, "startFrame": int(c.start_frame), "endFrame": int(c.end_frame), "startTime_s": c.start_time_s,
             "endTime_s": c.end_time_s, "duration_ms": c.duration_ms, "peakPower_dB": float(c.peak_power_db),
-            "peakTime_s": c.peak_time_s, "peakFreq_kHz": float(np.float32((table.min_bin + c.peak_bin) * res)) / 1000,
+            "peakTime_s": c.peak_time_s, "peakFreq_kHz": c.peak_freq_khz, "peakFreq_ms": c.peak_freq_ms,
             "snr_dB": float(c.peak_power_db) + 80.0, "highpass_kHz": float(hp[r]),
             "zonalNoiseMap": {10 * z: float(zonal[r * SONO_MAX_ZONES + z]) for z in range(table.num_zones)},
         })

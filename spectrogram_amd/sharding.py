@@ -63,7 +63,7 @@ def calls_to_rows(calls, file_id, channel=0):
         for k in ("startTime_s", "endTime_s", "duration_ms", "peakFreq_kHz", "peakPower_dB", "snr_dB"):
             if k in c:
                 rows[r, col[k]] = c[k]
-        rows[r, col["peakFreq_ms"]] = (c["peakTime_s"] - c["startTime_s"]) * 1000
+        rows[r, col["peakFreq_ms"]] = c["peakFreq_ms"] if "peakFreq_ms" in c else (c["peakTime_s"] - c["startTime_s"]) * 1000
     return rows
 
 

@@ -119,7 +119,7 @@ def _same_calls(a, b):
     assert len(a) == len(b), (len(a), len(b))
     for p, q in zip(a, b):
         for k in ("roi", "startFrame", "endFrame", "startTime_s", "endTime_s", "duration_ms", "peakPower_dB", "peakTime_s",
-                  "peakFreq_kHz", "snr_dB", "highpass_kHz"):
+                  "peakFreq_kHz", "peakFreq_ms", "snr_dB", "highpass_kHz"):
             assert p[k] == q[k], (k, p, q)
         assert {int(k): v for k, v in p["zonalNoiseMap"].items()} == {int(k): v for k, v in q["zonalNoiseMap"].items()}
 
@@ -135,6 +135,10 @@ def test_batched_region_analysis_equals_the_region_by_region_form(golden):
         _same_calls(one, batched)
         want = g[n + "/calls"].reshape(-1, 5)
         assert [(k["startTime_s"], k["endTime_s"], k["duration_ms"]) for k in batched] == [(w[0], w[1], w[2]) for w in want]
+        # the reference's own peak step, run inside the golden capture: peak frequency (parabolic), peak time, peak frame
+        for k, w in zip(batched, g[n + "/peaks"].reshape(-1, 4)):
+            assert abs(k["peakFreq_kHz"] - w[0]) < 2e-3                      # dB values agree to ~1e-4 dB; the parabola amplifies that
+            assert k["peakFreq_ms"] == w[1] and abs(k["peakPower_dB"] - w[3]) < 2e-3
         e.free()
 
 
