@@ -322,6 +322,13 @@ int sono_scan_spectrum_for_frequency(const float *row_db, const float *freq_bins
  * bin and its two neighbours where it has both.  Host only. */
 int sono_peak_frequency_khz(const float *row_db, const float *freq_bins, size_t num_bins, int64_t bin, double *khz);
 
+/* The vertical-click filter of measureFrequencyParameters (batCallDetector.js:3059-3088):
+ * instantaneous bandwidth in kHz of a dB row = (highest - lowest bin above
+ * peak_db - 12) * freq_resolution_hz / 1000; the reference discards a call whose
+ * peak frame exceeds 20 kHz.  Host only. */
+int sono_instant_bandwidth_khz(const float *row_db, size_t num_bins, double peak_db, double freq_resolution_hz,
+                               double *khz);
+
 /* calculateAutoHighpassFilterFreq (batCallDetector.js:4028-4035): corner in kHz. */
 double sono_auto_highpass_khz(double peak_freq_khz);
 
@@ -365,6 +372,8 @@ typedef struct sono_roi_table {
     int32_t *peak_bin;     /* its bin, counted from the band's first bin */
     float *peak_left_db;   /* one per frame: the dB values next to the peak bin (NaN where the peak sits on the */
     float *peak_right_db;  /* band's edge): inputs of the parabolic peak interpolation (js:3021-3034) */
+    int32_t *inst_lo_bin;  /* one per frame: lowest / highest bin above (the frame's peak - 12 dB), */
+    int32_t *inst_hi_bin;  /* the extent the vertical-click filter measures (js:3059-3088) */
     double *zonal;         /* n_rois * SONO_MAX_ZONES: calculateZonalNoiseFloors of the region's first six frames */
     float *highpass_khz;   /* n_rois: corner of the automatic high-pass, 0 = none */
     /* filled in by sono_analyze_rois */
@@ -393,8 +402,11 @@ typedef struct sono_roi_call {
     double start_time_s, end_time_s, duration_ms, peak_time_s;  /* times from the start of the recording */
     double peak_freq_khz;   /* measureFrequencyParameters' first step (js:3009-3036): parabolic peak frequency ... */
     double peak_freq_ms;    /* ... and the peak's time after the call's first frame (js:3039-3045) */
+    double inst_bandwidth_khz;  /* of the peak frame (js:3061-3077) */
     float peak_power_db;
     int32_t peak_bin;
+    int32_t discarded;      /* 1 = instantaneous bandwidth above 20 kHz: a vertical click, the reference drops it (js:3080-3087, 802) */
+    int32_t pad;
 } sono_roi_call;
 
 /* The rest of processFullFile's per-region work (js:677-828, without the

@@ -41,13 +41,14 @@ const names = ['fastScanSegmentsWasm', 'mergeAndPadSegments', 'generateSpectrogr
 const fns = {};
 for (const n of names) fns[n] = method(n);
 fns.detectCalls = method('detectCalls', ['audioData', 'sampleRate', 'flowKHz', 'fhighKHz', 'options']);
-// STEP 0 of measureFrequencyParameters (peak bin, parabolic peak frequency, peak time): the method's text up to the
-// comment that opens its next step; that prefix is a complete sequence of statements.
+// STEP 0 and STEP 0.5 of measureFrequencyParameters (peak bin, parabolic peak frequency, peak time; rejection of
+// vertical clicks by the peak frame's instantaneous bandwidth): the method's text up to the comment that opens
+// STEP 1; that prefix is a complete sequence of statements.
 const peakStep = (() => {
   const m = /\n  measureFrequencyParameters\(([^)]*)\) \{/.exec(src);
   const start = m.index + m[0].length;
-  const cut = src.indexOf('[STEP 0.5]', start);
-  if (cut < 0) throw new Error('STEP 0.5 marker not found');
+  const cut = src.indexOf('[STEP 1]', start);
+  if (cut < 0) throw new Error('STEP 1 marker not found');
   const end = src.lastIndexOf('// ====', cut);            // the banner line above the marker
   return new Function(...m[1].split(',').map((t) => t.trim()), src.slice(start, end));
 })();
@@ -92,10 +93,10 @@ async function run() {
       for (const row of call.spectrogram) for (let b = 0; b < row.length; b++) if (row[b] > peak) peak = row[b];
       call.peakPower_dB = peak;
       call.lowFreq_kHz = 0; call.highFreq_kHz = 0;
-      peakStep.call(self, call, flowKHz, fhighKHz, freqBins, freqResolution, zonalNoiseMap);      // the reference's own STEP 0
+      peakStep.call(self, call, flowKHz, fhighKHz, freqBins, freqResolution, zonalNoiseMap);      // the reference's own STEP 0 / 0.5
       if (call.peakPower_dB !== peak) throw new Error('stand-in and STEP 0 disagree on the peak power');
       captured.push({ frames: call.spectrogram.length, zonal: zoneArray(zonalNoiseMap), peakFreq_kHz: call.peakFreq_kHz,
-        peakFreq_ms: call.peakFreq_ms, peakFrameIdx: call.peakFrameIdx });
+        peakFreq_ms: call.peakFreq_ms, peakFrameIdx: call.peakFrameIdx, discarded: call.isDiscarded ? 1 : 0 });
     };
 
     function BatCall() {
@@ -117,6 +118,7 @@ async function run() {
         { threshold_dB: c.scan_threshold_db, padding_ms: c.padding_ms });
       emit(c.name, 'calls', f64([].concat(...calls.map((k) => [k.startTime_s, k.endTime_s, k.duration_ms, k.snr_dB, k.spectrogram.length]))));
       emit(c.name, 'peaks', f64([].concat(...calls.map((k) => [k.peakFreq_kHz, k.peakFreq_ms, k.peakFrameIdx, k.peakPower_dB]))));
+      emit(c.name, 'discarded', f64(captured.map((k) => k.discarded)));
       emit(c.name, 'zonal_first', captured.length ? captured[0].zonal : new Float64Array(0));
       emit(c.name, 'measured_frames', f64(captured.map((k) => k.frames)));
     } else if (c.kind === 'calls') {

@@ -275,6 +275,10 @@ def process_full_file(engine, audio, sample_rate, flow_khz, fhigh_khz, threshold
                              padding_ms=5, full_file_rules=True)                                     # :743-810
             for k in fr:
                 blk = p[k["startFrame"]:k["endFrame"] + 1]
+                row = blk[int(np.argmax(blk)) // p.shape[1]].astype(np.float64)                      # the peak frame
+                above = np.flatnonzero(row > float(blk.max()) - 12)                                  # :3061-3073
+                if len(above) and (above[-1] - above[0]) * sp["freqResolution"] / 1000 > 20.0:       # :3075-3087: a click
+                    continue
                 out.append(dict(startTime_s=k["startTime_s"] + offset, endTime_s=k["endTime_s"] + offset,
                                 duration_ms=k["duration_ms"], peakPower_dB=float(blk.max()),
                                 frames=k["endFrame"] - k["startFrame"] + 1, highpass_kHz=cutoff, roi=roi))

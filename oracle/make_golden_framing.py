@@ -88,6 +88,8 @@ def build_cases():
                                                  (95000, 4.0, 27000, 21000, 0.5),      # below 30 kHz: no high-pass
                                                  (110000, 0.6, 60000, 58000, 0.4)]):   # very short
         ff = ff + pulse(n, sr, 81 + k, at, dur, f0, f1, amp, noise=0.0)
+    ff[52000:52400] += 0.8 * white(400, 89, 1.0)                                        # a 1 ms burst of white noise: broadband
+    ff[101000:101150] += 0.9 * white(150, 88, 1.0)
     add("full_file", "fullfile", ff, sr, flow=15.0, fhigh=110.0, hop_percent=6.25, scan_threshold_db=-45.0, padding_ms=5.0)
     add("full_file_512_quiet", "fullfile", 0.001 * white(30000, 90, 1.0), 500000, fft=512, flow=20.0, fhigh=120.0,
         hop_percent=12.5, scan_threshold_db=-30.0, padding_ms=5.0)

@@ -59,7 +59,8 @@ class Segment(C.Structure):
 class RoiTable(C.Structure):
     """struct sono_roi_table."""
     _fields_ = [("row0", C.POINTER(C.c_uint64)), ("peak_db", C.POINTER(C.c_float)), ("peak_bin", C.POINTER(C.c_int32)),
-                ("peak_left_db", C.POINTER(C.c_float)), ("peak_right_db", C.POINTER(C.c_float)), ("zonal", C.POINTER(C.c_double)), ("highpass_khz", C.POINTER(C.c_float)), ("num_zones", C.c_uint32),
+                ("peak_left_db", C.POINTER(C.c_float)), ("peak_right_db", C.POINTER(C.c_float)),
+                ("inst_lo_bin", C.POINTER(C.c_int32)), ("inst_hi_bin", C.POINTER(C.c_int32)), ("zonal", C.POINTER(C.c_double)), ("highpass_khz", C.POINTER(C.c_float)), ("num_zones", C.c_uint32),
                 ("min_bin", C.c_uint32), ("num_bins", C.c_uint32), ("hop", C.c_uint32)]
 
 
@@ -68,7 +69,8 @@ class RoiCall(C.Structure):
     _fields_ = [("roi", C.c_uint64), ("start_frame", C.c_uint64), ("end_frame", C.c_uint64), ("peak_frame", C.c_uint64),
                 ("start_time_s", C.c_double), ("end_time_s", C.c_double), ("duration_ms", C.c_double),
                 ("peak_time_s", C.c_double), ("peak_freq_khz", C.c_double), ("peak_freq_ms", C.c_double),
-                ("peak_power_db", C.c_float), ("peak_bin", C.c_int32)]
+                ("inst_bandwidth_khz", C.c_double), ("peak_power_db", C.c_float), ("peak_bin", C.c_int32),
+                ("discarded", C.c_int32), ("pad", C.c_int32)]
 
 
 SONO_MAX_ZONES = 32
@@ -176,6 +178,7 @@ _SIGNATURES = {
     "sono_scan_spectrum_for_frequency": (C.c_int, [_f32p, _f32p, C.c_size_t, C.c_double, C.c_int, C.POINTER(C.c_double),
                                                    C.POINTER(C.c_int64)]),
     "sono_auto_highpass_khz": (C.c_double, [C.c_double]),
+    "sono_instant_bandwidth_khz": (C.c_int, [_f32p, C.c_size_t, C.c_double, C.c_double, C.POINTER(C.c_double)]),
     "sono_peak_frequency_khz": (C.c_int, [_f32p, _f32p, C.c_size_t, C.c_int64, C.POINTER(C.c_double)]),
     "sono_highpass_filter": (C.c_int, [_f32p, C.c_size_t, C.c_double, C.c_double, C.c_double, _f32p]),
     "sono_savitzky_golay": (C.c_int, [C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double)]),

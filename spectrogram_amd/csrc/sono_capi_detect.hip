@@ -470,6 +470,17 @@ int sono_peak_frequency_khz(const float *row_db, const float *freq_bins, size_t 
     return SONO_OK;
 }
 
+int sono_instant_bandwidth_khz(const float *row_db, size_t num_bins, double peak_db, double freq_resolution_hz, double *khz)
+{
+    if (!khz || (num_bins && !row_db)) return fail(SONO_EINVAL, "sono_instant_bandwidth_khz: NULL argument");
+    int32_t lo = -1, hi = -1;
+    const double thr = peak_db - 12;                                             // js:3061
+    for (size_t b = 0; b < num_bins; ++b)
+        if ((double)row_db[b] > thr) { if (lo < 0) lo = (int32_t)b; hi = (int32_t)b; }
+    *khz = sono::host_instant_bandwidth_khz(lo, hi, freq_resolution_hz);
+    return SONO_OK;
+}
+
 double sono_auto_highpass_khz(double peak_freq_khz) { return sono::host_auto_highpass_khz(peak_freq_khz); }
 
 int sono_highpass_filter(const float *in, size_t n, double filter_hz, double sample_rate, double order, float *out)

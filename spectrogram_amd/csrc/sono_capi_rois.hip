@@ -71,6 +71,8 @@ int peaks_pass(sono_engine *e, const float *d_src, const std::vector<uint64_t> &
             t->peak_bin[feat_rows[i] + f] = feat[row + f].bin;
             t->peak_left_db[feat_rows[i] + f] = feat[row + f].left;
             t->peak_right_db[feat_rows[i] + f] = feat[row + f].right;
+            t->inst_lo_bin[feat_rows[i] + f] = feat[row + f].lo12;
+            t->inst_hi_bin[feat_rows[i] + f] = feat[row + f].hi12;
         }
         row += F;
     }
@@ -118,7 +120,8 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
     int rc = sono_roi_rows(rois, n_rois, N, hop_percent, out->row0);
     if (rc) return rc;
     const size_t total = (size_t)out->row0[n_rois];
-    if (total > frames_cap || (total && (!out->peak_db || !out->peak_bin || !out->peak_left_db || !out->peak_right_db)))
+    if (total > frames_cap || (total && (!out->peak_db || !out->peak_bin || !out->peak_left_db || !out->peak_right_db || !out->inst_lo_bin ||
+                                    !out->inst_hi_bin)))
         return fail(SONO_ECAPACITY, "sono_analyze_rois: per-frame output arrays too small");
     // frequency axis and its 10 kHz zones (js:1342-1344, 1837-1839)
     std::vector<float> freq_bins(b.nb);
@@ -311,6 +314,9 @@ int sono_frame_roi_calls(const float *x, size_t n, const sono_segment *rois, siz
                     o.peak_freq_khz = sono::host_peak_freq_khz(t->peak_left_db[row + pk], pdb[pk], t->peak_right_db[row + pk], interior,
                                                                f_bin, width);
                     o.peak_freq_ms = (tf[pk] - tf[(size_t)k.start_frame]) * 1000;                        // js:3041-3043
+                    o.inst_bandwidth_khz = sono::host_instant_bandwidth_khz(t->inst_lo_bin[row + pk], t->inst_hi_bin[row + pk], res);
+                    o.discarded = o.inst_bandwidth_khz > 20.0 ? 1 : 0;                                   // js:3080
+                    o.pad = 0;
                 }
             }
         }

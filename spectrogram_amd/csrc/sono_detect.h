@@ -35,7 +35,9 @@ hipError_t launch_frame_features(const float *d_db, size_t frames, uint32_t nb, 
 
 // Per row: first bin of the largest value, the value, and its two neighbours (NaN at the ends of the row) --
 // what the parabolic peak interpolation of measureFrequencyParameters needs (batCallDetector.js:3010-3034).
-struct FramePeak { int32_t bin; float db, left, right; };
+// lo12 / hi12: lowest and highest bin of the row above (its peak - 12 dB): the "instantaneous bandwidth" of the
+// vertical-click filter (batCallDetector.js:3059-3088).
+struct FramePeak { int32_t bin; float db, left, right; int32_t lo12, hi12; };
 hipError_t launch_frame_peaks(const float *d_db, size_t frames, uint32_t nb, FramePeak *d_out, hipStream_t s);
 
 // First / last frame of every maximal run of non-zero flags, as two flag arrays.

@@ -142,8 +142,21 @@ __global__ __launch_bounds__(kThreads) void frame_peaks_kernel(const float *db, 
         const bool take = ob >= 0 && (best_bin < 0 || ov > best || (ov == best && ob < best_bin));
         if (take) { best = ov; best_bin = ob; }
     }
+    // second sweep: extent of the bins above peak - 12 dB (js:3061-3073)
+    const double thr = (double)best - 12;
+    int lo = 0x7FFFFFFF, hi = -1;
+    for (uint32_t b = lane; b < nb; b += 64) {
+        if ((double)row[b] > thr) { if ((int)b < lo) lo = (int)b; hi = (int)b; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const int ol = __shfl_xor(lo, o, 64), oh = __shfl_xor(hi, o, 64);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
     if (lane == 0) {
         FramePeak r;
+        r.lo12 = lo == 0x7FFFFFFF ? -1 : lo;
+        r.hi12 = hi;
         r.bin = best_bin;
         r.db = best;
         r.left = best_bin > 0 ? row[best_bin - 1] : NAN;

@@ -197,6 +197,12 @@ double host_peak_freq_khz(float left_db, float peak_db, float right_db, bool int
     return f / 1000;                                                             // js:3036
 }
 
+double host_instant_bandwidth_khz(int32_t lo_bin, int32_t hi_bin, double freq_resolution_hz)
+{
+    if (lo_bin < 0 || hi_bin < lo_bin) return 0.0;                               // js:3075
+    return ((double)(hi_bin - lo_bin) * freq_resolution_hz) / 1000;              // js:3076-3077
+}
+
 size_t host_zone_map(const float *fb, size_t n, std::vector<uint8_t> &zone_of_bin)
 {
     zone_of_bin.assign(n, 255);

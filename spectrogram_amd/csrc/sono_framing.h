@@ -43,6 +43,11 @@ bool host_frame_calls(const FrameRun *segs, size_t count, const double *time_fra
 // centre, moved by a parabola through the peak and its two neighbours where it has both (interior = true).
 double host_peak_freq_khz(float left_db, float peak_db, float right_db, bool interior, float bin_freq_hz, double bin_width_hz);
 
+// The vertical-click filter of measureFrequencyParameters (batCallDetector.js:3059-3088): instantaneous bandwidth in
+// kHz of the peak frame from its lowest / highest bin above peak - 12 dB (-1 / -1 if none: bandwidth 0); a call is
+// discarded when it exceeds 20 kHz.
+double host_instant_bandwidth_khz(int32_t lo_bin, int32_t hi_bin, double freq_resolution_hz);
+
 // Zone bookkeeping of calculateZonalNoiseFloors (batCallDetector.js:1837-1839, 1863-1864):
 // zone index of every bin, number of zones.
 size_t host_zone_map(const float *freq_bins, size_t n, std::vector<uint8_t> &zone_of_bin);

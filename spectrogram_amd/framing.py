@@ -192,11 +192,17 @@ def process_full_file(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz,
                 kk = f0 + int(np.argmax(peak_db[f0:f1 + 1]))
                 khz = C.c_double(0)
                 _check(lib().sono_peak_frequency_khz(_p(power[kk]), _p(fb), nb, int(peak_bin[kk]), C.byref(khz)))       # js:3021-3036
+                bw = C.c_double(0)
+                _check(lib().sono_instant_bandwidth_khz(_p(power[kk]), nb, float(peak_db[kk]), sample_rate / engine.get_fft_size(),
+                                                        C.byref(bw)))                                           # js:3059-3077
+                if bw.value > 20.0:                          # a vertical click: the reference drops the call (js:3080-3087, 802)
+                    continue
                 calls.append({
                     "roi": roi, "startFrame": f0, "endFrame": f1, "startTime_s": k["startTime_s"] + offset,
                     "endTime_s": k["endTime_s"] + offset, "duration_ms": k["duration_ms"],
                     "peakPower_dB": float(peak_db[kk]), "peakTime_s": float(tf[kk]) + offset,
                     "peakFreq_kHz": khz.value, "peakFreq_ms": (float(tf[kk]) - float(tf[f0])) * 1000,           # js:3036-3043
+                    "instBandwidth_kHz": bw.value,
                     "snr_dB": float(peak_db[kk]) + 80.0,                                                       # js:818
                     "highpass_kHz": cutoff, "zonalNoiseMap": zonal,
                 })
@@ -226,8 +232,9 @@ def process_full_file_batched(engine, full_audio_data, sample_rate, flow_khz, fh
     zonal = np.zeros(n * SONO_MAX_ZONES, np.float64)
     hp = np.zeros(n, np.float32)
     left, right = np.zeros_like(peak_db), np.zeros_like(peak_db)
+    ilo, ihi = np.zeros_like(peak_bin), np.zeros_like(peak_bin)
     table = _RoiTable(row0.ctypes.data_as(u64p), _p(peak_db), peak_bin.ctypes.data_as(i32p), _p(left), _p(right),
-                      zonal.ctypes.data_as(dp), _p(hp), 0, 0, 0, 0)
+                      ilo.ctypes.data_as(i32p), ihi.ctypes.data_as(i32p), zonal.ctypes.data_as(dp), _p(hp), 0, 0, 0, 0)
     xf = x.copy()
     _check(lib().sono_analyze_rois(engine._handle(), _p(x), x.size, rois, n, float(sample_rate), float(flow_khz), float(fhigh_khz),
                                    float(cfg["hopPercent"]), 1, C.byref(table), total, _p(xf)))
@@ -239,12 +246,14 @@ def process_full_file_batched(engine, full_audio_data, sample_rate, flow_khz, fh
     calls = []
     for i in range(got.value):
         c = out[i]
+        if c.discarded:                                      # a vertical click: the reference drops the call (js:802)
+            continue
         r = int(c.roi)
         calls.append({
             "roi": r, "startFrame": int(c.start_frame), "endFrame": int(c.end_frame), "startTime_s": c.start_time_s,
             "endTime_s": c.end_time_s, "duration_ms": c.duration_ms, "peakPower_dB": float(c.peak_power_db),
             "peakTime_s": c.peak_time_s, "peakFreq_kHz": c.peak_freq_khz, "peakFreq_ms": c.peak_freq_ms,
-            "snr_dB": float(c.peak_power_db) + 80.0, "highpass_kHz": float(hp[r]),
+            "instBandwidth_kHz": c.inst_bandwidth_khz, "snr_dB": float(c.peak_power_db) + 80.0, "highpass_kHz": float(hp[r]),
             "zonalNoiseMap": {10 * z: float(zonal[r * SONO_MAX_ZONES + z]) for z in range(table.num_zones)},
         })
     return calls

@@ -105,7 +105,8 @@ def test_process_full_file_end_to_end(golden):
             assert abs(k["snr_dB"] - w[3]) < 2e-3 and k["endFrame"] - k["startFrame"] + 1 == int(w[4])
             seen += 1
         if n == "full_file":
-            assert [k["highpass_kHz"] for k in calls] == [30, 25, 20, 0, 30] or sorted(k["highpass_kHz"] for k in calls) == [0, 20, 25, 30, 30]
+            assert sorted(k["highpass_kHz"] for k in calls) == [0, 20, 25, 30, 30]
+            assert g[n + "/discarded"].sum() == 1 and all(k["instBandwidth_kHz"] <= 20.0 for k in calls)     # the noise burst is gone
             rows = sh.calls_to_rows(calls, file_id=3)
             col = {k: i for i, k in enumerate(sh.COLUMNS)}
             assert rows.shape == (len(calls), len(sh.COLUMNS)) and (rows[:, col["file"]] == 3).all()
@@ -119,7 +120,7 @@ def _same_calls(a, b):
     assert len(a) == len(b), (len(a), len(b))
     for p, q in zip(a, b):
         for k in ("roi", "startFrame", "endFrame", "startTime_s", "endTime_s", "duration_ms", "peakPower_dB", "peakTime_s",
-                  "peakFreq_kHz", "peakFreq_ms", "snr_dB", "highpass_kHz"):
+                  "peakFreq_kHz", "peakFreq_ms", "instBandwidth_kHz", "snr_dB", "highpass_kHz"):
             assert p[k] == q[k], (k, p, q)
         assert {int(k): v for k, v in p["zonalNoiseMap"].items()} == {int(k): v for k, v in q["zonalNoiseMap"].items()}
 
