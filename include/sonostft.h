@@ -359,6 +359,43 @@ int sono_rms_snr(sono_engine *e, const float *power_db, size_t frames, uint32_t 
                  size_t noise_frames, uint32_t noise_bins, const float *noise_freq_bins, double sel_low_hz,
                  double sel_high_hz, sono_snr_result *out);
 
+/* ---- measurement stage, threshold searches (host only, serial per call) ------- */
+
+/* The call's slice of the analysis spectrogram and what the searches need beside it. */
+typedef struct sono_call_matrix {
+    const float *power_db;     /* frames x num_bins, row-major */
+    size_t frames;
+    uint32_t num_bins;
+    const float *freq_bins;    /* num_bins centre frequencies, Hz */
+    const double *time_frames; /* frames centre times, s (the high-frequency search reads them) */
+    const double *zonal;       /* floors of the 10 kHz zones (sono_zonal_noise_floors), or NULL: the searches
+                                  compute them from the slice over the frames the reference uses */
+    size_t num_zones;
+} sono_call_matrix;
+
+/* findOptimalLowFrequencyThreshold (batCallDetector.js:2413-2909).  has_freq = 0
+ * where the reference returns null frequencies; discard = the call bottoms out
+ * at or below 10 kHz (noise); reference_throws = the reference, outside its debug
+ * mode, raises a TypeError on these inputs (js:2815) and the other fields are unset. */
+typedef struct sono_low_threshold {
+    double threshold_db, low_freq_hz, end_freq_hz;
+    int64_t low_freq_frame, low_freq_bin;
+    int32_t has_freq, has_frame, warning, discard, reference_throws, pad;
+} sono_low_threshold;
+int sono_find_optimal_low_frequency_threshold(const sono_call_matrix *m, double call_peak_power_db, int64_t peak_frame,
+                                              int64_t limit_frame /* < 0: none */, sono_low_threshold *out);
+
+/* findOptimalHighFrequencyThreshold (batCallDetector.js:1931-2401).  has_limit = 0
+ * in the reference's "nothing found" return, which carries neither
+ * finalSearchLimitFrame nor isCFStablePattern; reference_throws as above (js:2261). */
+typedef struct sono_high_threshold {
+    double threshold_db, high_freq_hz, start_freq_hz;
+    int64_t high_freq_bin, high_freq_frame, final_search_limit_frame;
+    int32_t has_freq, has_start, has_limit, warning, is_cf_stable_pattern, reference_throws;
+} sono_high_threshold;
+int sono_find_optimal_high_frequency_threshold(const sono_call_matrix *m, double call_peak_power_db, int64_t peak_frame,
+                                               sono_high_threshold *out);
+
 /* ---- batched region analysis: processFullFile's per-region work
  * (batCallDetector.js:609-711) for all regions of a recording at once ---------- */
 

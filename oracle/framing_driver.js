@@ -37,7 +37,8 @@ function method(name, argNames) {
 }
 const names = ['fastScanSegmentsWasm', 'mergeAndPadSegments', 'generateSpectrogramWasm', 'detectCallSegments', 'savitzkyGolay', 'refineEndUsingOscillogram',
   'calculateZonalNoiseFloors', '_scanSpectrumForFrequency', 'calculateAutoHighpassFilterFreq', 'applyHighpassFilter',
-  '_applyButterworthStage', 'getQualityRating', 'calculateDuration', 'calculateRMSbasedSNR'];
+  '_applyButterworthStage', 'getQualityRating', 'calculateDuration', 'calculateRMSbasedSNR',
+  'findOptimalLowFrequencyThreshold', 'findOptimalHighFrequencyThreshold'];
 const fns = {};
 for (const n of names) fns[n] = method(n);
 fns.detectCalls = method('detectCalls', ['audioData', 'sampleRate', 'flowKHz', 'fhighKHz', 'options']);
@@ -153,6 +154,34 @@ async function run() {
         scans.push(r ? r.freq_Hz : -1, r ? r.binIdx : -1);
       }
       emit(c.name, 'scans', f64(scans));
+    } else if (c.kind === 'thresholds') {
+      const sp = fns.generateSpectrogramWasm.call(self, x, c.sr, c.flow_khz, c.fhigh_khz);
+      const nb = sp.freqBins.length, F = sp.powerMatrix.length;
+      const db = new Float32Array(F * nb);
+      sp.powerMatrix.forEach((row, f) => db.set(row, f * nb));
+      emit(c.name, 'db', db); emit(c.name, 'freq', sp.freqBins); emit(c.name, 'shape', f64([F, nb]));
+      emit(c.name, 'time', f64(sp.timeFrames));
+      const num = (v) => (v === null || v === undefined ? NaN : (v === true ? 1 : v === false ? 0 : v));
+      const low = [], high = [];
+      for (const q of c.slices) {                      // [firstFrame, lastFrame, useZonalMap, limitFrame (-1 = null)]
+        const a = Math.max(0, q[0]), b = Math.min(F - 1, q[1]);
+        const spec = sp.powerMatrix.slice(a, b + 1), tf = sp.timeFrames.slice(a, b + 2);
+        let peak = -Infinity, peakFrame = 0;
+        spec.forEach((row, f) => { for (let k = 0; k < row.length; k++) if (row[k] > peak) { peak = row[k]; peakFrame = f; } });
+        const zonal = q[2] ? fns.calculateZonalNoiseFloors.call(self, sp.powerMatrix, sp.freqBins, 0, Math.min(5, F - 1)) : null;
+        const limit = q[3] < 0 ? null : q[3];
+        let r;
+        try {
+          r = fns.findOptimalLowFrequencyThreshold.call(self, spec, tf, sp.freqBins, c.flow_khz, c.fhigh_khz, peak, peakFrame, limit, zonal);
+          low.push(num(r.threshold), num(r.lowFreq_Hz), num(r.endFreq_Hz), num(r.lowFreqFrameIdx), num(r.lowFreqBinIdx), num(r.warning), num(r.discard), 0);
+        } catch (err) { low.push(NaN, NaN, NaN, NaN, NaN, NaN, NaN, 1); }
+        try {
+          r = fns.findOptimalHighFrequencyThreshold.call(self, spec, tf, sp.freqBins, c.flow_khz, c.fhigh_khz, peak, peakFrame, zonal);
+          high.push(num(r.threshold), num(r.highFreq_Hz), num(r.highFreqBinIdx), num(r.highFreqFrameIdx), num(r.startFreq_Hz),
+            num(r.finalSearchLimitFrame), num(r.warning), num(r.isCFStablePattern), 0);
+        } catch (err) { high.push(NaN, NaN, NaN, NaN, NaN, NaN, NaN, NaN, 1); }
+      }
+      emit(c.name, 'low', f64(low)); emit(c.name, 'high', f64(high));
     } else if (c.kind === 'snr') {
       const sp = fns.generateSpectrogramWasm.call(self, x, c.sr, c.flow_khz, c.fhigh_khz);
       const nb = sp.freqBins.length, F = sp.powerMatrix.length;

@@ -110,6 +110,21 @@ def build_cases():
         scan_stride=2)
     add("zonal_digital_silence", "zonal", np.zeros(5000, np.float32), sr, flow=5.0, fhigh=60.0, hop_percent=25.0,
         ranges=[[0, 5]], thresholds=[-100.0, -170.0], scan_stride=1)
+    # --- the two threshold searches of the measurement stage on call slices of different kinds
+    def slices(F):
+        return [[0, F, 1, -1], [0, F, 0, -1], [10, F - 10, 1, -1], [20, 70, 1, 30], [0, 5, 1, -1], [40, 41, 0, -1], [0, F, 1, 10]]
+    k1 = pulse(12000, sr, 101, 3000, 4.0, 80000, 35000, 0.5, noise=0.02)                      # FM sweep in moderate noise
+    add("thr_fm", "thresholds", k1, sr, flow=15.0, fhigh=120.0, hop_percent=6.25, slices=slices(170))
+    k2 = pulse(12000, sr, 102, 3000, 6.0, 45000, 44000, 0.5, noise=0.002)                     # near-constant frequency, clean
+    add("thr_cf", "thresholds", k2, sr, flow=15.0, fhigh=120.0, hop_percent=6.25, slices=slices(170))
+    k3 = pulse(12000, sr, 103, 3000, 4.0, 60000, 30000, 0.4, noise=0.05)
+    k3 += pulse(12000, sr, 104, 3000, 4.0, 120000, 60000, 0.1, noise=0.0)                     # second harmonic
+    k3 += 0.05 * tone(12000, sr, 9000.0, amp=1.0)                                             # hum below 10 kHz
+    add("thr_harmonic_hum", "thresholds", k3, sr, flow=5.0, fhigh=150.0, hop_percent=6.25, slices=slices(170))
+    k4 = pulse(9000, sr, 105, 2500, 3.0, 70000, 40000, 0.6, tail_db=-20.0, noise=1e-5)        # almost no noise: deep thresholds
+    add("thr_clean_echo", "thresholds", k4, sr, flow=20.0, fhigh=100.0, hop_percent=12.5, slices=slices(60))
+    k5 = pulse(15000, 500000, 106, 4000, 3.5, 110000, 50000, 0.5, noise=0.03)
+    add("thr_500k_512", "thresholds", k5, 500000, fft=512, flow=20.0, fhigh=150.0, hop_percent=12.5, slices=slices(220))
     # --- RMS-based SNR of a call box, against the rest of the selection or against an external noise spectrogram
     h = pulse(9000, sr, 74, 3000, 4.0, 80000, 40000, 0.5, noise=0.03)
     add("snr", "snr", h, sr, flow=20.0, fhigh=110.0, hop_percent=12.5, noise=0.03 * white(5000, 75, 1.0),
@@ -158,6 +173,9 @@ def main():
             print(f"  {n}: calls {arrays[n + '/calls'].reshape(-1, 5).round(5).tolist()}")
         elif c["kind"] == "calls":
             print(f"  {n}: calls {arrays[n + '/calls'].reshape(-1, 6).round(5).tolist()} zonal {arrays[n + '/zonal'].tolist()}")
+        elif c["kind"] == "thresholds":
+            print(f"  {n}: low {arrays[n + '/low'].reshape(-1, 8)[:, [0, 1, 3, 6, 7]].round(2).tolist()}")
+            print(f"  {n}: high {arrays[n + '/high'].reshape(-1, 9)[:, [0, 1, 3, 7, 8]].round(2).tolist()}")
         elif c["kind"] == "snr":
             print(f"  {n}: snr rows {arrays[n + '/snr'].reshape(-1, 9)[:, [0, 3, 4, 8]].round(4).tolist()}")
         elif c["kind"] == "refine":

@@ -76,6 +76,28 @@ class RoiCall(C.Structure):
 SONO_MAX_ZONES = 32
 
 
+class CallMatrix(C.Structure):
+    """struct sono_call_matrix."""
+    _fields_ = [("power_db", C.POINTER(C.c_float)), ("frames", C.c_size_t), ("num_bins", C.c_uint32),
+                ("freq_bins", C.POINTER(C.c_float)), ("time_frames", C.POINTER(C.c_double)), ("zonal", C.POINTER(C.c_double)),
+                ("num_zones", C.c_size_t)]
+
+
+class LowThreshold(C.Structure):
+    """struct sono_low_threshold."""
+    _fields_ = [("threshold_db", C.c_double), ("low_freq_hz", C.c_double), ("end_freq_hz", C.c_double),
+                ("low_freq_frame", C.c_int64), ("low_freq_bin", C.c_int64), ("has_freq", C.c_int32), ("has_frame", C.c_int32),
+                ("warning", C.c_int32), ("discard", C.c_int32), ("reference_throws", C.c_int32), ("pad", C.c_int32)]
+
+
+class HighThreshold(C.Structure):
+    """struct sono_high_threshold."""
+    _fields_ = [("threshold_db", C.c_double), ("high_freq_hz", C.c_double), ("start_freq_hz", C.c_double),
+                ("high_freq_bin", C.c_int64), ("high_freq_frame", C.c_int64), ("final_search_limit_frame", C.c_int64),
+                ("has_freq", C.c_int32), ("has_start", C.c_int32), ("has_limit", C.c_int32), ("warning", C.c_int32),
+                ("is_cf_stable_pattern", C.c_int32), ("reference_throws", C.c_int32)]
+
+
 class SnrResult(C.Structure):
     """struct sono_snr_result."""
     _fields_ = [("snr_db", C.c_double), ("signal_mean_db", C.c_double), ("noise_mean_db", C.c_double),
@@ -170,6 +192,10 @@ _SIGNATURES = {
                                               C.POINTER(C.c_double), C.c_size_t, _szp, C.c_void_p]),
     "sono_db_percentile": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_double, C.POINTER(C.c_float)]),
     "sono_db_percentile_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.POINTER(C.c_float), C.c_void_p]),
+    "sono_find_optimal_low_frequency_threshold": (C.c_int, [C.POINTER(CallMatrix), C.c_double, C.c_int64, C.c_int64,
+                                                            C.POINTER(LowThreshold)]),
+    "sono_find_optimal_high_frequency_threshold": (C.c_int, [C.POINTER(CallMatrix), C.c_double, C.c_int64,
+                                                             C.POINTER(HighThreshold)]),
     "sono_rms_snr": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_uint32, _f32p, C.c_int64, C.c_int64, C.c_double, C.c_double,
                                _f32p, C.c_size_t, C.c_uint32, _f32p, C.c_double, C.c_double, C.POINTER(SnrResult)]),
     "sono_refine_end_oscillogram": (C.c_int, [_f32p, C.c_size_t, C.c_double, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),

@@ -21,7 +21,7 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 HIP_SOURCES = ["sono_kernels.hip", "sono_tile.hip", "sono_detect.hip", "sono_capi.hip", "sono_capi_detect.hip", "sono_capi_rois.hip"]
-CXX_SOURCES = ["sono_host.cpp", "sono_framing.cpp"]
+CXX_SOURCES = ["sono_host.cpp", "sono_framing.cpp", "sono_measure.cpp"]
 # -fno-slp-vectorize: gfx950 executes v_pk_{add,mul,fma}_f32 at half the rate of the scalar forms
 # (measured, tools/microbench.hip), so packing buys nothing and costs the moves that build the pairs.
 HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-slp-vectorize", "-Wall",

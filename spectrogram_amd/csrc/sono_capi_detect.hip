@@ -11,6 +11,7 @@
 #include "sono_detect.h"
 #include "sono_engine.h"
 #include "sono_framing.h"
+#include "sono_measure.h"
 
 using sono::DeviceGuard;
 using sono::fail;
@@ -414,6 +415,46 @@ int sono_rms_snr(sono_engine *e, const float *power_db, size_t frames, uint32_t 
     out->noise_mean_db = 10 * std::log10(n_mean > 1e-16 ? n_mean : 1e-16);
     out->signal_count = counts[0]; out->noise_count = counts[1];
     out->snr_db = n_mean < 1e-16 ? INFINITY : 10 * std::log10(s_mean / n_mean);  // js:562-568
+    return SONO_OK;
+}
+
+namespace {
+
+int check_matrix(const sono_call_matrix *m, bool need_times, const char *who)
+{
+    if (!m) return fail(SONO_EINVAL, std::string(who) + ": NULL argument");
+    if (m->frames && m->num_bins && (!m->power_db || !m->freq_bins)) return fail(SONO_EINVAL, std::string(who) + ": NULL matrix or axis");
+    if (need_times && m->frames && !m->time_frames) return fail(SONO_EINVAL, std::string(who) + ": time_frames is NULL");
+    if (m->zonal && m->num_zones > 256) return fail(SONO_EINVAL, std::string(who) + ": more than 256 zones");
+    return SONO_OK;
+}
+
+}  // namespace
+
+int sono_find_optimal_low_frequency_threshold(const sono_call_matrix *m, double peak, int64_t peak_frame, int64_t limit_frame,
+                                              sono_low_threshold *out)
+{
+    if (!out) return fail(SONO_EINVAL, "sono_find_optimal_low_frequency_threshold: NULL argument");
+    int rc = check_matrix(m, false, "sono_find_optimal_low_frequency_threshold");
+    if (rc) return rc;
+    if (peak_frame < 0) return fail(SONO_EINVAL, "sono_find_optimal_low_frequency_threshold: peak_frame < 0");
+    const sono::CallMatrix cm{m->power_db, m->frames, m->num_bins, m->freq_bins, m->zonal, m->num_zones};
+    const sono::LowResult r = sono::find_optimal_low_threshold(cm, peak, peak_frame, limit_frame);
+    *out = {r.threshold_db, r.low_freq_hz, r.end_freq_hz, r.frame, r.bin, r.has_freq, r.has_frame, r.warning, r.discard,
+            r.reference_throws, 0};
+    return SONO_OK;
+}
+
+int sono_find_optimal_high_frequency_threshold(const sono_call_matrix *m, double peak, int64_t peak_frame, sono_high_threshold *out)
+{
+    if (!out) return fail(SONO_EINVAL, "sono_find_optimal_high_frequency_threshold: NULL argument");
+    int rc = check_matrix(m, true, "sono_find_optimal_high_frequency_threshold");
+    if (rc) return rc;
+    if (peak_frame < 0) return fail(SONO_EINVAL, "sono_find_optimal_high_frequency_threshold: peak_frame < 0");
+    const sono::CallMatrix cm{m->power_db, m->frames, m->num_bins, m->freq_bins, m->zonal, m->num_zones};
+    const sono::HighResult r = sono::find_optimal_high_threshold(cm, m->time_frames, peak, peak_frame);
+    *out = {r.threshold_db, r.high_freq_hz, r.start_freq_hz, r.bin, r.frame, r.final_search_limit_frame, r.has_freq, r.has_start,
+            r.has_limit, r.warning, r.is_cf, r.reference_throws};
     return SONO_OK;
 }
 

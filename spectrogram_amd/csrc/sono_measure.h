@@ -1,0 +1,40 @@
+// sono_measure.h -- the two threshold searches of the detector's measurement
+// stage (host only, serial per call): findOptimalLowFrequencyThreshold and
+// findOptimalHighFrequencyThreshold of batCallDetector.js.  Doubles throughout,
+// like JavaScript numbers; the dB matrix and the frequency axis are float.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace sono {
+
+struct CallMatrix {
+    const float *db;          // frames x bins, row-major: the call's slice of the analysis spectrogram
+    size_t frames;
+    uint32_t bins;
+    const float *freq_bins;   // bins centre frequencies, Hz
+    const double *zonal;      // noise floor of every 10 kHz zone, or nullptr: computed from the slice as the reference does
+    size_t num_zones;
+};
+
+struct LowResult {
+    double threshold_db = -24, low_freq_hz = 0, end_freq_hz = 0;
+    int64_t frame = 0, bin = -1;
+    bool has_freq = false, has_frame = false, warning = false, discard = false, reference_throws = false;
+};
+// batCallDetector.js:2413-2909.  limit_frame < 0 = none.
+LowResult find_optimal_low_threshold(const CallMatrix &m, double peak_power_db, int64_t peak_frame, int64_t limit_frame);
+
+struct HighResult {
+    double threshold_db = -24, high_freq_hz = 0, start_freq_hz = 0;
+    int64_t bin = 0, frame = 0, final_search_limit_frame = 0;
+    bool has_freq = false, has_start = false, has_limit = false, warning = false, is_cf = false, reference_throws = false;
+};
+// batCallDetector.js:1931-2401.  time_frames: m.frames centre times, seconds.
+HighResult find_optimal_high_threshold(const CallMatrix &m, const double *time_frames, double peak_power_db, int64_t peak_frame);
+
+// calculateZonalNoiseFloors (batCallDetector.js:1818-1924) on a host matrix: floors of the zones, their number returned.
+size_t host_zonal_floors(const float *db, size_t frames, uint32_t bins, const float *freq_bins, int64_t start_frame,
+                         int64_t end_frame, double *floors, size_t cap);
+
+}  // namespace sono

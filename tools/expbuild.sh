@@ -9,7 +9,7 @@ cd "$ROOT/spectrogram_amd/csrc"
 for f in sono_kernels.hip sono_tile.hip sono_detect.hip sono_capi.hip sono_capi_detect.hip sono_capi_rois.hip; do
   hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize "$@" -c $f -o "$ROOT/gpurun_exp/obj_$name/$f.o" &
 done
-for c in sono_host sono_framing; do g++ -O2 -std=c++17 -fPIC -ffp-contract=off -c $c.cpp -o "$ROOT/gpurun_exp/obj_$name/$c.o" & done
+for c in sono_host sono_framing sono_measure; do g++ -O2 -std=c++17 -fPIC -ffp-contract=off -c $c.cpp -o "$ROOT/gpurun_exp/obj_$name/$c.o" & done
 wait
 hipcc -shared -fPIC --offload-arch=gfx950 -o "$ROOT/gpurun_exp/lib_$name.so" "$ROOT/gpurun_exp/obj_$name"/*.o
 rm -rf "$ROOT/gpurun_exp/obj_$name"
