@@ -371,6 +371,9 @@ typedef struct sono_call_matrix {
     const double *zonal;       /* floors of the 10 kHz zones (sono_zonal_noise_floors), or NULL: the searches
                                   compute them from the slice over the frames the reference uses */
     size_t num_zones;
+    int32_t debug_mode;        /* the detector's debugMode switch (setDebugMode, batCallDetector.js:359-361): the reference
+                                  keeps a log table only then and raises a TypeError without it on some inputs */
+    int32_t pad;
 } sono_call_matrix;
 
 /* findOptimalLowFrequencyThreshold (batCallDetector.js:2413-2909).  has_freq = 0
@@ -395,6 +398,29 @@ typedef struct sono_high_threshold {
 } sono_high_threshold;
 int sono_find_optimal_high_frequency_threshold(const sono_call_matrix *m, double call_peak_power_db, int64_t peak_frame,
                                                sono_high_threshold *out);
+
+/* measureFrequencyParameters (batCallDetector.js:2994-3894), the whole measurement of one call: peak, vertical-click
+ * filter, both threshold searches, start / end frequency tracing, characteristic frequency, bandwidth, knee and heel,
+ * times relative to the start frequency.  Time expansion (fileState.js) is taken as off.  m->time_frames holds
+ * num_times entries: the call's frames plus, unless the call ends the analysis matrix, one more (js:787, 1201).
+ * In: start_time_s, end_time_s, duration_ms as the framing stage set them.  Out: every field; doubles are NaN and
+ * frame numbers -1 where the reference leaves null.  discarded = call.isDiscarded; reference_throws as for the
+ * searches (then, and when discarded, only the fields of the steps already done are set). */
+typedef struct sono_call_measurement {
+    double start_time_s, end_time_s, duration_ms;
+    double peak_freq_khz, peak_freq_ms, peak_power_db;
+    double high_freq_khz, high_freq_ms;
+    double start_freq_khz, start_freq_ms, start_freq_time_s;
+    double end_freq_khz, end_freq_ms, end_freq_time_s;
+    double low_freq_khz, low_freq_ms;
+    double characteristic_freq_khz, characteristic_freq_ms;
+    double knee_freq_khz, knee_freq_ms, heel_freq_khz, heel_freq_ms;
+    double bandwidth_khz, high_threshold_db_used, low_threshold_db_used;
+    int64_t peak_frame, high_freq_frame, start_freq_frame, start_freq_bin, end_frame_for_low_freq, knee_frame, heel_frame;
+    int32_t discarded, reference_throws;
+} sono_call_measurement;
+int sono_measure_frequency_parameters(const sono_call_matrix *m, size_t num_times, double fhigh_khz,
+                                      double freq_resolution_hz, sono_call_measurement *io);
 
 /* ---- batched region analysis: processFullFile's per-region work
  * (batCallDetector.js:609-711) for all regions of a recording at once ---------- */
@@ -455,6 +481,17 @@ typedef struct sono_roi_call {
 int sono_frame_roi_calls(const float *x, size_t n, const sono_segment *rois, size_t n_rois, const sono_roi_table *table,
                          double sample_rate, uint32_t fft_size, double call_threshold_db, double min_call_duration_ms,
                          sono_roi_call *out, size_t cap, size_t *count);
+
+/* The measurement stage (sono_measure_frequency_parameters) for calls sono_frame_roi_calls returned, all at once:
+ * the calls' frames are transformed again from the recording (x = the x_filtered of sono_analyze_rois) in one ragged
+ * launch -- bit for bit the dB values of the region's own transform -- and the calls are measured on `threads`
+ * host threads (0 = up to 16).  out[i] belongs to calls[i]; its times are relative to the call's region, as
+ * processFullFile has them at that point (batCallDetector.js:786-797; add rois[roi].start / sample_rate for file
+ * time, js:822-825).  Table, band and hop must be those of the sono_analyze_rois call. */
+int sono_measure_roi_calls(sono_engine *e, const float *x, size_t n, const sono_segment *rois, size_t n_rois,
+                           const sono_roi_table *t, const sono_roi_call *calls, size_t n_calls, double sample_rate,
+                           double flow_khz, double fhigh_khz, double hop_percent, int debug_mode, unsigned int threads,
+                           sono_call_measurement *out);
 
 /* mergeAndPadSegments (batCallDetector.js:1028-1056).  Host only; sorts `segs` in place. */
 int sono_merge_and_pad_segments(sono_segment *segs, size_t count, uint64_t total_samples, double sample_rate,

@@ -38,7 +38,7 @@ function method(name, argNames) {
 const names = ['fastScanSegmentsWasm', 'mergeAndPadSegments', 'generateSpectrogramWasm', 'detectCallSegments', 'savitzkyGolay', 'refineEndUsingOscillogram',
   'calculateZonalNoiseFloors', '_scanSpectrumForFrequency', 'calculateAutoHighpassFilterFreq', 'applyHighpassFilter',
   '_applyButterworthStage', 'getQualityRating', 'calculateDuration', 'calculateRMSbasedSNR',
-  'findOptimalLowFrequencyThreshold', 'findOptimalHighFrequencyThreshold'];
+  'findOptimalLowFrequencyThreshold', 'findOptimalHighFrequencyThreshold', 'calculateBandwidth'];
 const fns = {};
 for (const n of names) fns[n] = method(n);
 fns.detectCalls = method('detectCalls', ['audioData', 'sampleRate', 'flowKHz', 'fhighKHz', 'options']);
@@ -53,6 +53,31 @@ const peakStep = (() => {
   const end = src.lastIndexOf('// ====', cut);            // the banner line above the marker
   return new Function(...m[1].split(',').map((t) => t.trim()), src.slice(start, end));
 })();
+
+// The whole measureFrequencyParameters, with the one free identifier of its text (the time-expansion switch of
+// fileState.js, off by default) supplied as a leading parameter.
+const realMeasure = (() => {
+  const m = /\n  measureFrequencyParameters\(([^)]*)\) \{/.exec(src);
+  let i = m.index + m[0].length, depth = 1; const start = i;
+  for (; i < src.length && depth > 0; i++) { if (src[i] === '{') depth++; else if (src[i] === '}') depth--; }
+  const f = new Function('getTimeExpansionMode', ...m[1].split(',').map((t) => t.trim()), src.slice(start, i - 1));
+  return function (...args) { return f.call(this, () => false, ...args); };
+})();
+const CALL_FIELDS = ['startTime_s', 'endTime_s', 'duration_ms', 'peakFreq_kHz', 'peakFreq_ms', 'peakPower_dB', 'highFreq_kHz', 'highFreq_ms',
+  'highFreqFrameIdx', 'startFreq_kHz', 'startFreq_ms', 'startFreqFrameIdx', 'endFreq_kHz', 'endFreq_ms', 'endFrameIdx_forLowFreq',
+  'lowFreq_kHz', 'lowFreq_ms', 'characteristicFreq_kHz', 'characteristicFreq_ms', 'kneeFreq_kHz', 'kneeFreq_ms', 'kneeFrameIdx',
+  'heelFreq_kHz', 'heelFreq_ms', 'heelFrameIdx', 'bandwidth_kHz', 'highFreqThreshold_dB_used', 'lowFreqThreshold_dB_used', 'snr_dB',
+  'startFreqTime_s', 'endFreqTime_s'];
+const callRow = (k) => CALL_FIELDS.map((f) => (k[f] === null || k[f] === undefined ? NaN : k[f]));
+function newBatCall() {
+  const o = {};
+  for (const f of ['startTime_s', 'endTime_s', 'duration_ms', 'peakFreq_kHz', 'peakFreq_ms', 'highFreq_kHz', 'highFreq_ms', 'highFreqFrameIdx',
+    'startFreq_kHz', 'startFreq_ms', 'startFreqFrameIdx', 'startFreqTime_s', 'endFreq_kHz', 'endFreq_ms', 'endFreqTime_s', 'lowFreq_kHz',
+    'lowFreq_ms', 'lowFreqFrameIdx', 'endFrameIdx_forLowFreq', 'characteristicFreq_kHz', 'characteristicFreq_ms', 'kneeFreq_kHz',
+    'kneeFreq_ms', 'kneeTime_ms', 'heelFreq_kHz', 'heelFreq_ms', 'heelFrameIdx', 'bandwidth_kHz', 'peakPower_dB', 'snr_dB',
+    'highFreqThreshold_dB_used', 'lowFreqThreshold_dB_used']) o[f] = null;          // the fields BatCall's constructor sets to null
+  return o;
+}
 
 const cases = JSON.parse(fs.readFileSync(path.join(work, 'cases.json'), 'utf8'));
 const inBuf = fs.readFileSync(path.join(work, 'inputs.bin'));
@@ -89,7 +114,11 @@ async function run() {
     self.generateSpectrogram = fns.generateSpectrogramWasm;
     self.fastScanSegments = fns.fastScanSegmentsWasm;
     // stand-in for the measurement stage: records what it is handed and leaves a peak power behind
-    self.measureFrequencyParameters = function (call, flowKHz, fhighKHz, freqBins, freqResolution, zonalNoiseMap) {
+    if (c.debug_mode) self.debugMode = true;
+    let measureThrew = 0;
+    self.measureFrequencyParameters = c.real_measure ? function (...args) {
+      try { return realMeasure.apply(this, args); } catch (err) { measureThrew++; throw err; }
+    } : function (call, flowKHz, fhighKHz, freqBins, freqResolution, zonalNoiseMap) {
       let peak = -Infinity;
       for (const row of call.spectrogram) for (let b = 0; b < row.length; b++) if (row[b] > peak) peak = row[b];
       call.peakPower_dB = peak;
@@ -100,11 +129,11 @@ async function run() {
         peakFreq_ms: call.peakFreq_ms, peakFrameIdx: call.peakFrameIdx, discarded: call.isDiscarded ? 1 : 0 });
     };
 
-    function BatCall() {
-      this.startTime_s = null; this.endTime_s = null; this.startFreqTime_s = null; this.endFreqTime_s = null;
-      this.duration_ms = null; this.peakPower_dB = null;
-    }
+    function BatCall() { Object.assign(this, newBatCall()); }
     BatCall.prototype.calculateDuration = fns.calculateDuration;
+    BatCall.prototype.calculateBandwidth = function () {          // BatCall.calculateBandwidth (batCallDetector.js:166-170), run as text below
+      fns.calculateBandwidth.call(this);
+    };
     const CallTypeClassifier = { classify: () => 'NA' };
     // a method whose text refers to BatCall and CallTypeClassifier as free identifiers gets them as leading parameters
     const scoped = (name, argNames) => {
@@ -113,12 +142,43 @@ async function run() {
       for (; i < src.length && depth > 0; i++) { if (src[i] === '{') depth++; else if (src[i] === '}') depth--; }
       return new AsyncFunction('BatCall', 'CallTypeClassifier', ...argNames, src.slice(start, i - 1));
     };
-    if (c.kind === 'fullfile') {
+    if (c.kind === 'measure') {
+      const sp = fns.generateSpectrogramWasm.call(self, x, c.sr, c.flow_khz, c.fhigh_khz);
+      const nb = sp.freqBins.length, F = sp.powerMatrix.length;
+      const db = new Float32Array(F * nb);
+      sp.powerMatrix.forEach((row, f) => db.set(row, f * nb));
+      emit(c.name, 'db', db); emit(c.name, 'freq', sp.freqBins); emit(c.name, 'shape', f64([F, nb]));
+      emit(c.name, 'time', f64(sp.timeFrames)); emit(c.name, 'freqres', f64([sp.freqResolution]));
+      const rows = [], rowsDebug = [];
+      for (const q of c.slices) {                      // [firstFrame, lastFrame, useZonalMap]
+        const a = Math.max(0, q[0]), b = Math.min(F - 1, q[1]);
+        const call = new BatCall();
+        call.spectrogram = sp.powerMatrix.slice(a, b + 1);
+        call.timeFrames = sp.timeFrames.slice(a, b + 2);
+        call.startTime_s = sp.timeFrames[a];
+        call.endTime_s = sp.timeFrames[Math.min(b + 1, F - 1)];
+        call.calculateDuration();
+        const zonal = q[2] ? fns.calculateZonalNoiseFloors.call(self, sp.powerMatrix, sp.freqBins, 0, Math.min(5, F - 1)) : null;
+        const fresh = () => Object.assign(new BatCall(), call);
+        for (const debug of [false, true]) {           // outside and inside the detector's debug mode
+          const k = fresh();
+          let threw = 0;
+          self.debugMode = debug;
+          try { realMeasure.call(self, k, c.flow_khz, c.fhigh_khz, sp.freqBins, sp.freqResolution, zonal); } catch (err) { threw = 1; }
+          self.debugMode = false;
+          (debug ? rowsDebug : rows).push(...callRow(k), k.isDiscarded ? 1 : 0, threw);
+        }
+      }
+      emit(c.name, 'measured', f64(rows));
+      emit(c.name, 'measured_debug', f64(rowsDebug));
+    } else if (c.kind === 'fullfile' || c.kind === 'fullfile_measured') {
       const processFullFile = scoped('processFullFile', ['fullAudioData', 'sampleRate', 'flowKHz', 'fhighKHz', 'options']);
       const calls = await processFullFile.call(self, BatCall, CallTypeClassifier, x, c.sr, c.flow_khz, c.fhigh_khz,
         { threshold_dB: c.scan_threshold_db, padding_ms: c.padding_ms });
       emit(c.name, 'calls', f64([].concat(...calls.map((k) => [k.startTime_s, k.endTime_s, k.duration_ms, k.snr_dB, k.spectrogram.length]))));
       emit(c.name, 'peaks', f64([].concat(...calls.map((k) => [k.peakFreq_kHz, k.peakFreq_ms, k.peakFrameIdx, k.peakPower_dB]))));
+      emit(c.name, 'measured', f64([].concat(...calls.map((k) => callRow(k)))));
+      emit(c.name, 'measure_threw', f64([measureThrew]));
       emit(c.name, 'discarded', f64(captured.map((k) => k.discarded)));
       emit(c.name, 'zonal_first', captured.length ? captured[0].zonal : new Float64Array(0));
       emit(c.name, 'measured_frames', f64(captured.map((k) => k.frames)));
@@ -162,8 +222,10 @@ async function run() {
       emit(c.name, 'db', db); emit(c.name, 'freq', sp.freqBins); emit(c.name, 'shape', f64([F, nb]));
       emit(c.name, 'time', f64(sp.timeFrames));
       const num = (v) => (v === null || v === undefined ? NaN : (v === true ? 1 : v === false ? 0 : v));
-      const low = [], high = [];
-      for (const q of c.slices) {                      // [firstFrame, lastFrame, useZonalMap, limitFrame (-1 = null)]
+      const lowPlain = [], highPlain = [], lowDebug = [], highDebug = [];
+      for (const debug of [false, true]) for (const q of c.slices) {   // [firstFrame, lastFrame, useZonalMap, limitFrame (-1 = null)]
+        const low = debug ? lowDebug : lowPlain, high = debug ? highDebug : highPlain;
+        self.debugMode = debug;
         const a = Math.max(0, q[0]), b = Math.min(F - 1, q[1]);
         const spec = sp.powerMatrix.slice(a, b + 1), tf = sp.timeFrames.slice(a, b + 2);
         let peak = -Infinity, peakFrame = 0;
@@ -180,8 +242,10 @@ async function run() {
           high.push(num(r.threshold), num(r.highFreq_Hz), num(r.highFreqBinIdx), num(r.highFreqFrameIdx), num(r.startFreq_Hz),
             num(r.finalSearchLimitFrame), num(r.warning), num(r.isCFStablePattern), 0);
         } catch (err) { high.push(NaN, NaN, NaN, NaN, NaN, NaN, NaN, NaN, 1); }
+        self.debugMode = false;
       }
-      emit(c.name, 'low', f64(low)); emit(c.name, 'high', f64(high));
+      emit(c.name, 'low', f64(lowPlain)); emit(c.name, 'high', f64(highPlain));
+      emit(c.name, 'low_debug', f64(lowDebug)); emit(c.name, 'high_debug', f64(highDebug));
     } else if (c.kind === 'snr') {
       const sp = fns.generateSpectrogramWasm.call(self, x, c.sr, c.flow_khz, c.fhigh_khz);
       const nb = sp.freqBins.length, F = sp.powerMatrix.length;

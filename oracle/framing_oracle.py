@@ -232,10 +232,12 @@ def detect_calls_framing(engine, audio, sample_rate, flow_khz, fhigh_khz, hop_pe
 
 
 def process_full_file(engine, audio, sample_rate, flow_khz, fhigh_khz, threshold_db=-60, padding_ms=5, hop_percent=3.125,
-                      call_threshold_db=-24.0, min_call_duration_ms=1.0):
+                      call_threshold_db=-24.0, min_call_duration_ms=1.0, keep_slices=False):
     """processFullFile, batCallDetector.js:584-840, without the measurement stage ->
     list of dicts {startTime_s, endTime_s, duration_ms, peakPower_dB, frames, highpass_kHz, roi} in the reference's order
-    (per region: strongest call first)."""
+    (per region: strongest call first).  keep_slices: every framed call, clicks included, also carries what the
+    reference hands to measureFrequencyParameters (:786-797): spectrogram, timeFrames, freqBins, freqResolution,
+    zonalNoiseMap, its region-relative times (relStart_s, relEnd_s) and the region's offset_s."""
     audio = np.ascontiguousarray(audio, np.float32)
     raw = do.fast_scan_segments(engine, audio, sample_rate, flow_khz, fhigh_khz, threshold_db)        # :594
     if not raw:
@@ -248,6 +250,7 @@ def process_full_file(engine, audio, sample_rate, flow_khz, fhigh_khz, threshold
         if sp is None:
             continue
         p, tf, fb = sp["powerMatrix"], sp["timeFrames"], sp["freqBins"]
+        floors = zonal_noise_floors(p, fb, 0, min(5, len(p) - 1))                                    # :622-627, before the high-pass
         flat = int(np.argmax(p))                                                                     # first maximum, :635-644
         peak_khz = float(fb[flat % p.shape[1]]) / 1000                                               # :646
         cutoff = auto_highpass_khz(peak_khz)
@@ -277,11 +280,16 @@ def process_full_file(engine, audio, sample_rate, flow_khz, fhigh_khz, threshold
                 blk = p[k["startFrame"]:k["endFrame"] + 1]
                 row = blk[int(np.argmax(blk)) // p.shape[1]].astype(np.float64)                      # the peak frame
                 above = np.flatnonzero(row > float(blk.max()) - 12)                                  # :3061-3073
-                if len(above) and (above[-1] - above[0]) * sp["freqResolution"] / 1000 > 20.0:       # :3075-3087: a click
+                click = len(above) and (above[-1] - above[0]) * sp["freqResolution"] / 1000 > 20.0   # :3075-3087
+                if click and not keep_slices:
                     continue
                 out.append(dict(startTime_s=k["startTime_s"] + offset, endTime_s=k["endTime_s"] + offset,
                                 duration_ms=k["duration_ms"], peakPower_dB=float(blk.max()),
                                 frames=k["endFrame"] - k["startFrame"] + 1, highpass_kHz=cutoff, roi=roi))
+                if keep_slices:
+                    out[-1].update(spectrogram=blk, timeFrames=tf[k["startFrame"]:k["endFrame"] + 2], freqBins=fb,
+                                   freqResolution=sp["freqResolution"], relStart_s=k["startTime_s"], relEnd_s=k["endTime_s"],
+                                   zonalNoiseMap={10 * z: v for z, v in enumerate(floors)}, offset_s=offset)
     return out
 
 

@@ -125,6 +125,22 @@ def build_cases():
     add("thr_clean_echo", "thresholds", k4, sr, flow=20.0, fhigh=100.0, hop_percent=12.5, slices=slices(60))
     k5 = pulse(15000, 500000, 106, 4000, 3.5, 110000, 50000, 0.5, noise=0.03)
     add("thr_500k_512", "thresholds", k5, 500000, fft=512, flow=20.0, fhigh=150.0, hop_percent=12.5, slices=slices(220))
+    # --- the whole measureFrequencyParameters on the same kinds of slices, and inside processFullFile
+    def mslices(F):
+        return [[0, F, 1], [0, F, 0], [10, F - 10, 1], [20, 70, 1], [0, 5, 1], [30, 34, 1]]
+    add("measure_fm", "measure", k1, sr, flow=15.0, fhigh=120.0, hop_percent=6.25, slices=mslices(170))
+    add("measure_cf", "measure", k2, sr, flow=15.0, fhigh=120.0, hop_percent=6.25, slices=mslices(170))
+    add("measure_harmonic_hum", "measure", k3, sr, flow=5.0, fhigh=150.0, hop_percent=6.25, slices=mslices(170))
+    add("measure_clean_echo", "measure", k4, sr, flow=20.0, fhigh=100.0, hop_percent=12.5, slices=mslices(60))
+    add("measure_500k_512", "measure", k5, 500000, fft=512, flow=20.0, fhigh=150.0, hop_percent=12.5, slices=mslices(220))
+    k6 = 0.01 * white(14000, 107, 1.0)                                                      # hooked call: steep sweep, then nearly flat
+    mm = int(sr * 0.006)
+    tt = np.arange(mm) / sr
+    fi = np.where(tt < 0.002, 90000 - 2.0e7 * tt, 50000 - 1.0e6 * (tt - 0.002))
+    k6[3000:3000 + mm] += (0.5 * np.hanning(mm) * np.sin(2 * np.pi * np.cumsum(fi) / sr)).astype(np.float32)
+    add("measure_hook", "measure", k6, sr, flow=15.0, fhigh=120.0, hop_percent=6.25, slices=mslices(200))
+    add("full_file_measured", "fullfile_measured", ff, sr, flow=15.0, fhigh=110.0, hop_percent=6.25, scan_threshold_db=-45.0, padding_ms=5.0,
+        real_measure=1, debug_mode=1)
     # --- RMS-based SNR of a call box, against the rest of the selection or against an external noise spectrogram
     h = pulse(9000, sr, 74, 3000, 4.0, 80000, 40000, 0.5, noise=0.03)
     add("snr", "snr", h, sr, flow=20.0, fhigh=110.0, hop_percent=12.5, noise=0.03 * white(5000, 75, 1.0),
@@ -169,10 +185,13 @@ def main():
     print(f"wrote {OUT}: {len(cases)} cases, {os.path.getsize(OUT)} bytes")
     for c in meta:
         n = c["name"]
-        if c["kind"] == "fullfile":
-            print(f"  {n}: calls {arrays[n + '/calls'].reshape(-1, 5).round(5).tolist()}")
+        if c["kind"] in ("fullfile", "fullfile_measured"):
+            print(f"  {n}: calls {arrays[n + '/calls'].reshape(-1, 5).round(5).tolist()} threw {arrays[n + '/measure_threw'].tolist()}")
         elif c["kind"] == "calls":
             print(f"  {n}: calls {arrays[n + '/calls'].reshape(-1, 6).round(5).tolist()} zonal {arrays[n + '/zonal'].tolist()}")
+        elif c["kind"] == "measure":
+            for key in ("measured", "measured_debug"):
+                print(f"  {n}: {key} {arrays[n + '/' + key].reshape(-1, 33)[:, [2, 3, 6, 9, 12, 15, 17, 19, 22, 31, 32]].round(2).tolist()}")
         elif c["kind"] == "thresholds":
             print(f"  {n}: low {arrays[n + '/low'].reshape(-1, 8)[:, [0, 1, 3, 6, 7]].round(2).tolist()}")
             print(f"  {n}: high {arrays[n + '/high'].reshape(-1, 9)[:, [0, 1, 3, 7, 8]].round(2).tolist()}")

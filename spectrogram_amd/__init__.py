@@ -80,7 +80,20 @@ class CallMatrix(C.Structure):
     """struct sono_call_matrix."""
     _fields_ = [("power_db", C.POINTER(C.c_float)), ("frames", C.c_size_t), ("num_bins", C.c_uint32),
                 ("freq_bins", C.POINTER(C.c_float)), ("time_frames", C.POINTER(C.c_double)), ("zonal", C.POINTER(C.c_double)),
-                ("num_zones", C.c_size_t)]
+                ("num_zones", C.c_size_t), ("debug_mode", C.c_int32), ("pad", C.c_int32)]
+
+
+class CallMeasurement(C.Structure):
+    """struct sono_call_measurement."""
+    _doubles = ("start_time_s", "end_time_s", "duration_ms", "peak_freq_khz", "peak_freq_ms", "peak_power_db", "high_freq_khz",
+                "high_freq_ms", "start_freq_khz", "start_freq_ms", "start_freq_time_s", "end_freq_khz", "end_freq_ms",
+                "end_freq_time_s", "low_freq_khz", "low_freq_ms", "characteristic_freq_khz", "characteristic_freq_ms",
+                "knee_freq_khz", "knee_freq_ms", "heel_freq_khz", "heel_freq_ms", "bandwidth_khz", "high_threshold_db_used",
+                "low_threshold_db_used")
+    _frames = ("peak_frame", "high_freq_frame", "start_freq_frame", "start_freq_bin", "end_frame_for_low_freq", "knee_frame",
+               "heel_frame")
+    _fields_ = ([(n, C.c_double) for n in _doubles] + [(n, C.c_int64) for n in _frames]
+                + [("discarded", C.c_int32), ("reference_throws", C.c_int32)])
 
 
 class LowThreshold(C.Structure):
@@ -192,6 +205,11 @@ _SIGNATURES = {
                                               C.POINTER(C.c_double), C.c_size_t, _szp, C.c_void_p]),
     "sono_db_percentile": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_double, C.POINTER(C.c_float)]),
     "sono_db_percentile_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.POINTER(C.c_float), C.c_void_p]),
+    "sono_measure_roi_calls": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.POINTER(Segment), C.c_size_t, C.POINTER(RoiTable),
+                                         C.POINTER(RoiCall), C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                         C.c_uint, C.POINTER(CallMeasurement)]),
+    "sono_measure_frequency_parameters": (C.c_int, [C.POINTER(CallMatrix), C.c_size_t, C.c_double, C.c_double,
+                                                    C.POINTER(CallMeasurement)]),
     "sono_find_optimal_low_frequency_threshold": (C.c_int, [C.POINTER(CallMatrix), C.c_double, C.c_int64, C.c_int64,
                                                             C.POINTER(LowThreshold)]),
     "sono_find_optimal_high_frequency_threshold": (C.c_int, [C.POINTER(CallMatrix), C.c_double, C.c_int64,

@@ -438,7 +438,7 @@ int sono_find_optimal_low_frequency_threshold(const sono_call_matrix *m, double 
     int rc = check_matrix(m, false, "sono_find_optimal_low_frequency_threshold");
     if (rc) return rc;
     if (peak_frame < 0) return fail(SONO_EINVAL, "sono_find_optimal_low_frequency_threshold: peak_frame < 0");
-    const sono::CallMatrix cm{m->power_db, m->frames, m->num_bins, m->freq_bins, m->zonal, m->num_zones};
+    const sono::CallMatrix cm{m->power_db, m->frames, m->num_bins, m->freq_bins, m->zonal, m->num_zones, m->debug_mode != 0};
     const sono::LowResult r = sono::find_optimal_low_threshold(cm, peak, peak_frame, limit_frame);
     *out = {r.threshold_db, r.low_freq_hz, r.end_freq_hz, r.frame, r.bin, r.has_freq, r.has_frame, r.warning, r.discard,
             r.reference_throws, 0};
@@ -451,10 +451,31 @@ int sono_find_optimal_high_frequency_threshold(const sono_call_matrix *m, double
     int rc = check_matrix(m, true, "sono_find_optimal_high_frequency_threshold");
     if (rc) return rc;
     if (peak_frame < 0) return fail(SONO_EINVAL, "sono_find_optimal_high_frequency_threshold: peak_frame < 0");
-    const sono::CallMatrix cm{m->power_db, m->frames, m->num_bins, m->freq_bins, m->zonal, m->num_zones};
+    const sono::CallMatrix cm{m->power_db, m->frames, m->num_bins, m->freq_bins, m->zonal, m->num_zones, m->debug_mode != 0};
     const sono::HighResult r = sono::find_optimal_high_threshold(cm, m->time_frames, peak, peak_frame);
     *out = {r.threshold_db, r.high_freq_hz, r.start_freq_hz, r.bin, r.frame, r.final_search_limit_frame, r.has_freq, r.has_start,
             r.has_limit, r.warning, r.is_cf, r.reference_throws};
+    return SONO_OK;
+}
+
+int sono_measure_frequency_parameters(const sono_call_matrix *m, size_t num_times, double fhigh_khz, double freq_res,
+                                      sono_call_measurement *io)
+{
+    if (!io) return fail(SONO_EINVAL, "sono_measure_frequency_parameters: NULL argument");
+    int rc = check_matrix(m, true, "sono_measure_frequency_parameters");
+    if (rc) return rc;
+    if (num_times < m->frames) return fail(SONO_EINVAL, "sono_measure_frequency_parameters: fewer times than frames");
+    if (!(freq_res > 0)) return fail(SONO_EINVAL, "sono_measure_frequency_parameters: freq_resolution_hz must be positive");
+    const sono::CallMatrix cm{m->power_db, m->frames, m->num_bins, m->freq_bins, m->zonal, m->num_zones, m->debug_mode != 0};
+    sono::CallMeasure c;
+    c.start_time_s = io->start_time_s; c.end_time_s = io->end_time_s; c.duration_ms = io->duration_ms;
+    sono::measure_frequency_parameters(cm, m->time_frames, num_times, fhigh_khz, freq_res, c);
+    *io = {c.start_time_s, c.end_time_s, c.duration_ms, c.peak_freq_khz, c.peak_freq_ms, c.peak_power_db, c.high_freq_khz,
+           c.high_freq_ms, c.start_freq_khz, c.start_freq_ms, c.start_freq_time_s, c.end_freq_khz, c.end_freq_ms,
+           c.end_freq_time_s, c.low_freq_khz, c.low_freq_ms, c.characteristic_freq_khz, c.characteristic_freq_ms,
+           c.knee_freq_khz, c.knee_freq_ms, c.heel_freq_khz, c.heel_freq_ms, c.bandwidth_khz, c.high_threshold_db_used,
+           c.low_threshold_db_used, c.peak_frame, c.high_freq_frame, c.start_freq_frame, c.start_freq_bin,
+           c.end_frame_for_low_freq, c.knee_frame, c.heel_frame, c.discarded, c.reference_throws};
     return SONO_OK;
 }
 

@@ -6,14 +6,18 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/sonostft.h"
 #include "sono_detect.h"
 #include "sono_engine.h"
 #include "sono_framing.h"
+#include "sono_measure.h"
+#include "sono_tile.h"
 
 using sono::DeviceGuard;
 using sono::fail;
@@ -322,6 +326,112 @@ int sono_frame_roi_calls(const float *x, size_t n, const sono_segment *rois, siz
         }
     }
     if (count) *count = made;
+    return SONO_OK;
+}
+
+int sono_measure_roi_calls(sono_engine *e, const float *x, size_t n, const sono_segment *rois, size_t n_rois, const sono_roi_table *t,
+                           const sono_roi_call *calls, size_t n_calls, double sample_rate, double flow_khz, double fhigh_khz,
+                           double hop_percent, int debug_mode, unsigned int threads, sono_call_measurement *out)
+{
+    if (!e || !t || (n && !x) || (n_rois && (!rois || !t->row0 || !t->zonal)) || (n_calls && (!calls || !out)))
+        return fail(SONO_EINVAL, "sono_measure_roi_calls: NULL argument");
+    if (!(sample_rate > 0)) return fail(SONO_EINVAL, "sono_measure_roi_calls: sample_rate must be positive");
+    if (n_calls == 0) return SONO_OK;
+    const uint32_t N = e->N, bins = N / 2;
+    const Band b = band_of(N, sample_rate, flow_khz, fhigh_khz, hop_percent);
+    if (!b.ok || b.hop != t->hop || b.nb != t->num_bins || b.min_bin != t->min_bin)
+        return fail(SONO_EINVAL, "sono_measure_roi_calls: band or hop differ from the table's");
+    std::vector<float> freq_bins(b.nb);
+    const double res = sample_rate / (double)N;
+    for (uint32_t i = 0; i < b.nb; ++i) freq_bins[i] = (float)((double)(b.min_bin + i) * res);
+    // A call's frames are transformed again from the (filtered) recording.  The slice starts on a tile boundary of its
+    // region and runs to one (or to the region's end), so every frame meets the same partner in the kernel's frame
+    // pairs as it did in the region's own transform and the dB values are the same bit for bit.
+    unsigned int align = sono::tile_frames_per_wave(N);
+    if (align == 0) align = 16;
+    struct Slice { uint64_t first, count, lead; };          // first frame transformed, frames transformed, frames before the call
+    std::vector<Slice> slices(n_calls);
+    for (size_t c = 0; c < n_calls; ++c) {
+        const sono_roi_call &k = calls[c];
+        if (k.roi >= n_rois) return fail(SONO_EINVAL, "sono_measure_roi_calls: call names a region that does not exist");
+        const uint64_t F = t->row0[k.roi + 1] - t->row0[k.roi];
+        if (k.end_frame < k.start_frame || k.end_frame >= F || rois[k.roi].end > n || rois[k.roi].end < rois[k.roi].start)
+            return fail(SONO_EINVAL, "sono_measure_roi_calls: call outside its region");
+        const uint64_t first = k.start_frame - k.start_frame % align;
+        uint64_t last = (k.end_frame / align + 1) * align;                          // one past the last frame transformed
+        if (last > F) last = F;
+        slices[c] = {first, last - first, k.start_frame - first};
+    }
+    DeviceGuard guard(e->device);
+    hipStream_t s = e->stream;
+    if (threads == 0) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    size_t c0 = 0;
+    while (c0 < n_calls) {
+        size_t c1 = c0, frames = 0, samples = 0;
+        while (c1 < n_calls && (c1 == c0 || frames + slices[c1].count <= kBatchFrames)) {
+            frames += (size_t)slices[c1].count;
+            samples += (size_t)(slices[c1].count - 1) * b.hop + N;
+            ++c1;
+        }
+        const size_t cnt = c1 - c0;
+        std::vector<float> packed(samples);
+        std::vector<uint64_t> off(cnt), len(cnt), row(cnt);
+        size_t pos = 0, rows = 0;
+        for (size_t i = 0; i < cnt; ++i) {
+            const sono_roi_call &k = calls[c0 + i];
+            const Slice &sl = slices[c0 + i];
+            off[i] = pos; len[i] = (sl.count - 1) * b.hop + N; row[i] = rows;
+            std::memcpy(packed.data() + pos, x + rois[k.roi].start + sl.first * b.hop, (size_t)len[i] * sizeof(float));
+            pos += (size_t)len[i];
+            rows += (size_t)sl.count;
+        }
+        HIP_TRY(e->d_in.reserve(packed.size() * sizeof(float)));
+        HIP_TRY(e->d_mags.reserve(frames * bins * sizeof(float)));
+        HIP_TRY(e->d_db.reserve(frames * b.nb * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(e->d_in.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        sono_ragged_batch rb{(const float *)e->d_in.p, cnt, off.data(), len.data()};
+        int rc = sono_stft_mag_f32_ragged_dev(e, &rb, b.noverlap, (float *)e->d_mags.p, nullptr);
+        if (rc) return rc;
+        rc = sono_detect_power_db_dev(e, (const float *)e->d_mags.p, frames, bins, b.min_bin, b.nb, (float *)e->d_db.p, nullptr);
+        if (rc) return rc;
+        std::vector<float> db(frames * b.nb);
+        HIP_TRY(hipMemcpyAsync(db.data(), e->d_db.p, db.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        // ---- measureFrequencyParameters per call (js:786-797), calls shared out over host threads ----
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            std::vector<double> tf;
+            for (size_t i = next.fetch_add(1); i < cnt; i = next.fetch_add(1)) {
+                const sono_roi_call &k = calls[c0 + i];
+                const uint64_t F = t->row0[k.roi + 1] - t->row0[k.roi];
+                const size_t call_frames = (size_t)(k.end_frame - k.start_frame + 1);
+                const size_t times = k.end_frame + 1 < F ? call_frames + 1 : call_frames;          // js:787
+                tf.resize(times);
+                for (size_t f = 0; f < times; ++f)
+                    tf[f] = ((double)(k.start_frame + f) * (double)b.hop + (double)N / 2) / sample_rate;     // js:1350-1351
+                const sono::CallMatrix m{db.data() + (row[i] + (size_t)slices[c0 + i].lead) * b.nb, call_frames, b.nb, freq_bins.data(),
+                                         t->zonal + (size_t)k.roi * SONO_MAX_ZONES, t->num_zones, debug_mode != 0};
+                sono::CallMeasure cm;
+                cm.start_time_s = tf[0];                                                           // js:791-794
+                cm.end_time_s = tf[times - 1];
+                cm.duration_ms = k.duration_ms;
+                sono::measure_frequency_parameters(m, tf.data(), times, fhigh_khz, res, cm);
+                out[c0 + i] = {cm.start_time_s, cm.end_time_s, cm.duration_ms, cm.peak_freq_khz, cm.peak_freq_ms, cm.peak_power_db,
+                               cm.high_freq_khz, cm.high_freq_ms, cm.start_freq_khz, cm.start_freq_ms, cm.start_freq_time_s,
+                               cm.end_freq_khz, cm.end_freq_ms, cm.end_freq_time_s, cm.low_freq_khz, cm.low_freq_ms,
+                               cm.characteristic_freq_khz, cm.characteristic_freq_ms, cm.knee_freq_khz, cm.knee_freq_ms,
+                               cm.heel_freq_khz, cm.heel_freq_ms, cm.bandwidth_khz, cm.high_threshold_db_used, cm.low_threshold_db_used,
+                               cm.peak_frame, cm.high_freq_frame, cm.start_freq_frame, cm.start_freq_bin, cm.end_frame_for_low_freq,
+                               cm.knee_frame, cm.heel_frame, cm.discarded, cm.reference_throws};
+            }
+        };
+        const unsigned int nt = (unsigned int)std::min<size_t>(threads, cnt);
+        std::vector<std::thread> pool;
+        for (unsigned int w = 1; w < nt; ++w) pool.emplace_back(work);
+        work();
+        for (std::thread &th : pool) th.join();
+        c0 = c1;
+    }
     return SONO_OK;
 }
 

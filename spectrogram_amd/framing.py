@@ -137,8 +137,26 @@ def detect_calls_framing(engine, audio_data, sample_rate, flow_khz, fhigh_khz, c
     return calls, zonal, floor, sp
 
 
-def process_full_file(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options=None, config=None):
-    """processFullFile (batCallDetector.js:584-840) without the measurement stage: fast scan -> merge & pad ->
+def _measure_framed(power, tf, fb, framed, flow_khz, fhigh_khz, freq_res, zonal, offset, debug_mode):
+    """One framed call of a region through measureFrequencyParameters and processFullFile's follow-up
+    (batCallDetector.js:786-827) -> the finished call dict, or None where the reference drops the call."""
+    from . import measure as _ms
+    f0, f1 = framed["startFrame"], framed["endFrame"]
+    call = {"spectrogram": power[f0:f1 + 1], "timeFrames": tf[f0:f1 + 2], "startTime_s": framed["startTime_s"],
+            "endTime_s": framed["endTime_s"], "duration_ms": framed["duration_ms"]}
+    _ms.measure_frequency_parameters(call, flow_khz, fhigh_khz, fb, freq_res, zonal, debug_mode)
+    call = _ms.finish_full_file_call(call, offset)
+    if call is not None:
+        del call["spectrogram"], call["timeFrames"]
+        call.update(startFrame=f0, endFrame=f1, zonalNoiseMap=zonal)
+    return call
+
+
+def process_full_file(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options=None, config=None, measure=False):
+    """processFullFile (batCallDetector.js:584-840).  measure=True runs the measurement stage on every framed call and
+    returns the reference's BatCall fields (measure.CALL_FIELDS, 'Flow', 'Fhigh', 'callType', 'snr_dB', 'quality', frame
+    numbers; config['debugMode'] is the detector's debug switch, outside which the reference -- and this -- raises on
+    some calls: measure.ReferenceThrows).  measure=False stops before it: fast scan -> merge & pad ->
     per region: analysis spectrogram, automatic high-pass, call segments, strongest-first 30 ms echo filter,
     5 ms padding + oscillogram refinement -> calls in the reference's order (per region, strongest first):
     {'startTime_s', 'endTime_s', 'duration_ms' (file time), 'peakPower_dB', 'peakTime_s', 'peakFreq_kHz' and 'peakFreq_ms'
@@ -188,6 +206,12 @@ def process_full_file(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz,
             framed = frame_calls([c["seg"]], tf, audio, sample_rate, engine.get_fft_size(), cfg["minCallDuration_ms"],
                                  padding_ms=5.0, full_file_rules=True)                                      # js:743-810
             for k in framed:
+                if measure:
+                    done = _measure_framed(power, tf, fb, k, flow_khz, fhigh_khz, spec["freqResolution"], zonal, offset,
+                                           cfg.get("debugMode", False))
+                    if done is not None:
+                        calls.append(dict(done, roi=roi, highpass_kHz=cutoff))
+                    continue
                 f0, f1 = k["startFrame"], k["endFrame"]
                 kk = f0 + int(np.argmax(peak_db[f0:f1 + 1]))
                 khz = C.c_double(0)
@@ -209,10 +233,11 @@ def process_full_file(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz,
     return calls
 
 
-def process_full_file_batched(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options=None, config=None):
+def process_full_file_batched(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options=None, config=None, measure=False):
     """process_full_file with the per-region work of ALL regions done in a few launches (sono_analyze_rois: ragged
     STFT batch, dB crop, per-frame peaks, noise-floor histograms, high-pass, all in HBM) and one host pass
-    (sono_frame_roi_calls).  Same calls, same order, same values as process_full_file."""
+    (sono_frame_roi_calls); with measure=True the measurement stage of all calls follows in one more launch and a
+    pool of host threads (sono_measure_roi_calls).  Same calls, same order, same values as process_full_file."""
     opt = dict({"threshold_dB": -60, "padding_ms": 5}, **(options or {}))
     cfg = dict(DEFAULT_FRAMING_CONFIG, **(config or {}))
     x = _f32(full_audio_data)
@@ -244,6 +269,28 @@ def process_full_file_batched(engine, full_audio_data, sample_rate, flow_khz, fh
     _check(lib().sono_frame_roi_calls(_p(xf), xf.size, rois, n, C.byref(table), float(sample_rate), n_fft,
                                       float(cfg["callThreshold_dB"]), float(cfg["minCallDuration_ms"]), out, cap, C.byref(got)))
     calls = []
+    if measure:
+        from . import CallMeasurement as _Measurement, measure as _ms
+        m = (_Measurement * max(got.value, 1))()
+        _check(lib().sono_measure_roi_calls(engine._handle(), _p(xf), xf.size, rois, n, C.byref(table), out, got.value,
+                                            float(sample_rate), float(flow_khz), float(fhigh_khz), float(cfg["hopPercent"]),
+                                            int(bool(cfg.get("debugMode", False))), 0, m))
+        for i in range(got.value):
+            c, r = out[i], int(out[i].roi)
+            if m[i].reference_throws:
+                raise _ms.ReferenceThrows("measureFrequencyParameters")
+            call = {name: (None if v != v else v) for name, v in ((nm, getattr(m[i], f)) for nm, (f, _) in
+                                                                  zip(_ms.CALL_FIELDS, _Measurement._fields_))}
+            call.update({name: (None if getattr(m[i], f) < 0 else int(getattr(m[i], f)))
+                         for name, f in zip(_ms._FRAME_FIELDS, _Measurement._frames)})
+            if m[i].discarded:
+                call["isDiscarded"] = True
+            zmap = {10 * z: float(zonal[r * SONO_MAX_ZONES + z]) for z in range(table.num_zones)}
+            call = _ms.finish_full_file_call(call, merged[r]["startSample"] / sample_rate)
+            if call is not None:
+                calls.append(dict(call, startFrame=int(c.start_frame), endFrame=int(c.end_frame), zonalNoiseMap=zmap, roi=r,
+                                  highpass_kHz=float(hp[r])))
+        return calls
     for i in range(got.value):
         c = out[i]
         if c.discarded:                                      # a vertical click: the reference drops the call (js:802)

@@ -18,7 +18,7 @@ __all__ = ["COLUMNS", "files_of_rank", "frame_chunks", "chunk_samples", "calls_t
            "reduce_global_max", "FRAME_ALIGN"]
 
 # Numeric columns of the reference's call-summary table (callSummaryTable.js:103-137), after the two
-# keys that identify where a row came from.  Columns the front end does not produce stay NaN.
+# keys that identify where a row came from.  Columns a call does not carry stay NaN.
 COLUMNS = ["file", "channel", "startTime_s", "endTime_s", "duration_ms", "bandwidth_kHz", "startFreq_kHz", "startFreq_ms",
            "endFreq_kHz", "endFreq_ms", "highFreq_kHz", "highFreq_ms", "lowFreq_kHz", "lowFreq_ms", "peakFreq_kHz",
            "peakFreq_ms", "characteristicFreq_kHz", "characteristicFreq_ms", "kneeFreq_kHz", "kneeFreq_ms",
@@ -60,10 +60,11 @@ def calls_to_rows(calls, file_id, channel=0):
     for r, c in enumerate(calls):
         rows[r, col["file"]] = file_id
         rows[r, col["channel"]] = channel
-        for k in ("startTime_s", "endTime_s", "duration_ms", "peakFreq_kHz", "peakPower_dB", "snr_dB"):
-            if k in c:
+        for k in COLUMNS[2:]:                       # measured calls carry every column; None (the reference's null) stays NaN
+            if c.get(k) is not None:
                 rows[r, col[k]] = c[k]
-        rows[r, col["peakFreq_ms"]] = c["peakFreq_ms"] if "peakFreq_ms" in c else (c["peakTime_s"] - c["startTime_s"]) * 1000
+        if "peakFreq_ms" not in c:
+            rows[r, col["peakFreq_ms"]] = (c["peakTime_s"] - c["startTime_s"]) * 1000
     return rows
 
 

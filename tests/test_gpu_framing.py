@@ -143,6 +143,45 @@ def test_batched_region_analysis_equals_the_region_by_region_form(golden):
         e.free()
 
 
+_MEASURED = ["startTime_s", "endTime_s", "duration_ms", "peakFreq_kHz", "peakFreq_ms", "peakPower_dB", "highFreq_kHz", "highFreq_ms",
+             "highFreqFrameIdx", "startFreq_kHz", "startFreq_ms", "startFreqFrameIdx", "endFreq_kHz", "endFreq_ms",
+             "endFrameIdx_forLowFreq", "lowFreq_kHz", "lowFreq_ms", "characteristicFreq_kHz", "characteristicFreq_ms",
+             "kneeFreq_kHz", "kneeFreq_ms", "kneeFrameIdx", "heelFreq_kHz", "heelFreq_ms", "heelFrameIdx", "bandwidth_kHz",
+             "highFreqThreshold_dB_used", "lowFreqThreshold_dB_used", "snr_dB", "startFreqTime_s", "endFreqTime_s"]
+# what ~1e-4 dB between this STFT and the reference's may move; frame-quantised times and thresholds must not move
+_TOL = {"peakFreq_kHz": 2e-3, "peakPower_dB": 2e-3, "highFreq_kHz": 5e-3, "startFreq_kHz": 5e-3, "endFreq_kHz": 5e-3, "lowFreq_kHz": 5e-3,
+        "bandwidth_kHz": 1e-2, "snr_dB": 2e-3, "characteristicFreq_kHz": 5e-3}
+
+
+def test_full_file_with_the_measurement_stage(golden):
+    from spectrogram_amd import measure as ms, sharding as sh
+    g, meta = golden
+    (c,) = cases(meta, "fullfile_measured")
+    n = c["name"]
+    e = sa.SpectrogramEngine(c["fft"], c["window"])
+    args = (e, g[n + "/x"], c["sr"], c["flow_khz"], c["fhigh_khz"], {"threshold_dB": c["scan_threshold_db"], "padding_ms": c["padding_ms"]})
+    cfg = {"hopPercent": c["hop_percent"], "callThreshold_dB": c["call_threshold_db"], "minCallDuration_ms": c["min_call_duration_ms"]}
+    for f in (fr.process_full_file, fr.process_full_file_batched):
+        with pytest.raises(ms.ReferenceThrows):               # outside its debug mode the reference raises on this recording
+            f(*args, cfg, measure=True)
+    one = fr.process_full_file(*args, dict(cfg, debugMode=True), measure=True)
+    batched = fr.process_full_file_batched(*args, dict(cfg, debugMode=True), measure=True)
+    want = g[n + "/measured"].reshape(-1, len(_MEASURED))
+    assert len(one) == len(batched) == len(want)
+    for a, b, w in zip(one, batched, want):
+        assert {k: v for k, v in a.items() if k != "zonalNoiseMap"} == {k: v for k, v in b.items() if k != "zonalNoiseMap"}   # bit for bit
+        for name, ref in zip(_MEASURED, w):
+            got = a.get(name)
+            if ref != ref:
+                assert got is None, (name, got)
+            else:
+                assert abs(got - ref) <= _TOL.get(name, 1e-9), (name, got, ref)
+    assert {k["callType"] for k in one} <= {"CF", "FM", "CF-FM"} and all(k["quality"] for k in one)
+    rows = sh.calls_to_rows(batched, file_id=1)
+    assert rows.shape[0] == len(batched)
+    e.free()
+
+
 def test_batched_region_analysis_on_a_long_recording():
     # 6 s at 384 kHz with a pulse every 50 ms: more than a hundred regions in one batch
     sr = 384000
@@ -159,6 +198,13 @@ def test_batched_region_analysis_on_a_long_recording():
     assert len(one) > 50
     _same_calls(one, batched)
     assert {c["highpass_kHz"] for c in batched} >= {0.0, 20.0, 25.0, 30.0}
+    # the measurement stage on top, both ways: identical rows
+    cfg = dict(cfg, debugMode=True)
+    one = fr.process_full_file(e, x, sr, 15.0, 110.0, {"threshold_dB": -45.0}, cfg, measure=True)
+    batched = fr.process_full_file_batched(e, x, sr, 15.0, 110.0, {"threshold_dB": -45.0}, cfg, measure=True)
+    assert len(one) > 50 and len(one) == len(batched)
+    for a, b in zip(one, batched):
+        assert {k: v for k, v in a.items() if k != "zonalNoiseMap"} == {k: v for k, v in b.items() if k != "zonalNoiseMap"}
     e.free()
 
 
