@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Times the detector's whole-file pass (fast scan -> regions -> analysis -> framed calls) region by region
-(framing.process_full_file) and batched (framing.process_full_file_batched) on a synthetic recording and checks
-that both give the same calls.  usage: python tools/roi_bench.py [seconds] [--skip-single]"""
+"""Times the detector's whole-file pass (fast scan -> regions -> analysis -> framed calls, then the same with the
+measurement stage) region by region (framing.process_full_file) and batched (framing.process_full_file_batched) on a
+synthetic recording and checks that both give the same calls.  usage: python tools/roi_bench.py [seconds] [--skip-single]"""
 import os
 import sys
 import time
@@ -33,6 +33,22 @@ def main():
         print(f"region by region: {len(single)} calls, {t1 - t0:.2f} s ({seconds / (t1 - t0):.0f} x real time)", flush=True)
         keys = ("roi", "startTime_s", "endTime_s", "duration_ms", "peakPower_dB", "peakTime_s", "highpass_kHz")
         same = len(single) == len(batched) and all(all(a[k] == b[k] for k in keys) for a, b in zip(single, batched))
+        print("identical:", same, flush=True)
+        if not same:
+            sys.exit(1)
+    # the measurement stage on top (debug mode on, so that calls on which the reference raises outside it are kept)
+    margs = args[:-1] + ({"debugMode": True},)
+    t0 = time.perf_counter()
+    measured = fr.process_full_file_batched(*margs, measure=True)
+    t1 = time.perf_counter()
+    print(f"batched + measurement: {len(measured)} calls, {t1 - t0:.2f} s ({seconds / (t1 - t0):.0f} x real time)", flush=True)
+    if "--skip-single" not in sys.argv:
+        t0 = time.perf_counter()
+        single = fr.process_full_file(*margs, measure=True)
+        t1 = time.perf_counter()
+        print(f"region by region + measurement: {len(single)} calls, {t1 - t0:.2f} s ({seconds / (t1 - t0):.0f} x real time)", flush=True)
+        strip = lambda c: {k: v for k, v in c.items() if k != "zonalNoiseMap"}
+        same = len(single) == len(measured) and all(strip(a) == strip(b) for a, b in zip(single, measured))
         print("identical:", same, flush=True)
         if not same:
             sys.exit(1)
