@@ -28,7 +28,7 @@ def build_cases():
     cases, bufs, pos = [], [], [0]
 
     def add(name, channels, sr, fft, noverlap=0, canvas_width=800, peak_mode=True, peak_threshold=0.4,
-            split=False, gain=20.0, rng=80.0, window="hann"):
+            split=False, gain=20.0, rng=80.0, window="hann", scale="linear", fmin=0, fmax=0):
         chs = []
         for x in channels:
             x = np.ascontiguousarray(x, np.float32)
@@ -37,7 +37,7 @@ def build_cases():
             pos[0] += x.size
         cases.append(dict(name=name, channels=chs, sr=sr, fft=fft, window=window, noverlap=noverlap,
                           canvas_width=canvas_width, peak_mode=peak_mode, peak_threshold=peak_threshold,
-                          split_channels=split, gain_db=gain, range_db=rng))
+                          split_channels=split, gain_db=gain, range_db=rng, scale=scale, frequency_min=fmin, frequency_max=fmax))
 
     sr = 384000
     add("mono_auto_overlap", [chirp(9000, sr, 61, t0=0.002)], sr, 512, noverlap=0, canvas_width=40)
@@ -49,6 +49,12 @@ def build_cases():
     add("quiet_frames", [np.concatenate([1e-6 * white(3000, 67, 1.0), tone(3000, sr, 30000.0, amp=0.5)])], sr, 512,
         noverlap=384, peak_threshold=0.4)
     add("wide_canvas", [chirp(1150, sr, 68, t0=0.0005)], sr, 1024, noverlap=0, canvas_width=2000, peak_mode=False)
+    # the non-linear frequency scales: two-tap filter banks built by the plugin, applied by the engine
+    for k, scale in enumerate(("mel", "logarithmic", "bark", "erb")):
+        add("scale_" + scale, [chirp(5000, sr, 70 + k, t0=0.001)], sr, 512, noverlap=256, scale=scale, peak_threshold=0.4)
+    add("scale_mel_band", [chirp(5000, sr, 75, t0=0.001)], sr, 256, noverlap=128, scale="mel", fmin=10000, fmax=120000, peak_mode=False)
+    add("scale_log_band_1024", [chirp(6000, sr, 76, t0=0.001)], 250000, 1024, noverlap=768, scale="logarithmic", fmin=5000, fmax=0,
+        peak_mode=False)
     return cases, np.concatenate(bufs)
 
 
@@ -73,9 +79,15 @@ def main():
             flat = np.concatenate(rows) if rows else np.zeros(0, np.uint8)
             frames.append({"count": len(rows), "u8": base64.b64encode(flat.tobytes()).decode()})
         c2 = {k: v for k, v in c.items() if k != "channels"}
-        c2.update(x=chans, frames=frames, peaks=r["peaks"])
+        bank = None
+        if r.get("bank"):                                     # two non-zeros per row: keep positions and values only
+            flat = np.frombuffer(base64.b64decode(r["bank"]), np.float32)
+            nz = np.flatnonzero(flat)
+            bank = {"size": int(flat.size), "idx": base64.b64encode(nz.astype(np.uint32).tobytes()).decode(),
+                    "val": base64.b64encode(flat[nz].tobytes()).decode()}
+        c2.update(x=chans, frames=frames, peaks=r["peaks"], bank=bank)
         out.append(c2)
-        print(f"  {c['name']}: channels {len(frames)} frames {[f['count'] for f in frames]} "
+        print(f"  {c['name']}: channels {len(frames)} frames {[f['count'] for f in frames]} bank {len(r.get('bank') or '')} "
               f"peak lists {[sum(len(p) for p in ch) for ch in r['peaks']]}")
     json.dump(out, open(OUT, "w"))
     print(f"wrote {OUT}: {os.path.getsize(OUT)} bytes")

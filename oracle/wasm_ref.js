@@ -80,6 +80,7 @@ function load(wasmPath) {
     globalMax() { return ex.spectrogramengine_get_global_max(this.h); }
     loadFilterBank(w, nf) { const [p, n] = putF32(w); ex.spectrogramengine_load_filter_bank(this.h, p, n, nf); }
     clearFilterBank() { ex.spectrogramengine_clear_filter_bank(this.h); }
+    numFilters() { return ex.spectrogramengine_get_num_filters(this.h) >>> 0; }
   }
   return {
     Engine,

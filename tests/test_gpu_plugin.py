@@ -21,10 +21,20 @@ def test_get_frequencies_matches_reference(c):
     sp = Spectrogram.create({"fftSamples": c["fft"], "windowFunc": c["window"], "noverlap": c["noverlap"],
                              "gainDB": c["gain_db"], "rangeDB": c["range_db"], "splitChannels": c["split_channels"],
                              "peakMode": c["peak_mode"], "peakThreshold": c["peak_threshold"],
-                             "canvasWidth": c["canvas_width"]})
+                             "canvasWidth": c["canvas_width"], "scale": c["scale"], "frequencyMin": c["frequency_min"],
+                             "frequencyMax": c["frequency_max"]})
     frames = sp.getFrequencies(AudioBuffer(chans, c["sr"]))
     assert len(frames) == len(c["frames"])
     bins = c["fft"] // 2
+    if c["bank"]:
+        # the two-tap filter bank the plugin builds: same taps, weights to float rounding of the scale functions
+        want = np.zeros(c["bank"]["size"], np.float32)
+        want[np.frombuffer(base64.b64decode(c["bank"]["idx"]), np.uint32)] = np.frombuffer(base64.b64decode(c["bank"]["val"]), np.float32)
+        got = sp._filterBankFlat
+        assert got.shape == want.shape and np.array_equal(got != 0, want != 0)
+        assert np.max(np.abs(got - want)) <= 1e-5 and np.mean(got == want) > 0.999
+    else:
+        assert sp._filterBankFlat is None
     for got, want in zip(frames, c["frames"]):
         ref = np.frombuffer(base64.b64decode(want["u8"]), np.uint8).reshape(want["count"], bins)
         assert got.shape == ref.shape and got.dtype == np.uint8              # identical frame arrays: count and length
