@@ -39,6 +39,7 @@ extern "C" {
 #define SONO_ENOMEM    2   /* host or device allocation failed */
 #define SONO_EDEVICE   3   /* no usable GPU / HIP runtime error */
 #define SONO_ECAPACITY 4   /* caller's output buffer is too small */
+#define SONO_EREFERENCE 5  /* the reference itself raises an exception on these inputs (see sono_process_full_file) */
 
 typedef struct sono_engine sono_engine;       /* SpectrogramEngine, lib.rs:8-35 */
 typedef struct sono_waveform sono_waveform;   /* WaveformEngine,    lib.rs:844-849 */
@@ -492,6 +493,36 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, size_t n, const sono_
                            const sono_roi_table *t, const sono_roi_call *calls, size_t n_calls, double sample_rate,
                            double flow_khz, double fhigh_khz, double hop_percent, int debug_mode, unsigned int threads,
                            sono_call_measurement *out);
+
+/* processFullFile (batCallDetector.js:584-840) in one call: fast scan, merge & pad, batched region analysis, framing,
+ * measurement, and the follow-up of js:802-827 (discarded and <= 1 ms calls dropped, classification, placeholder SNR
+ * = peak + 80 dB, quality, region time -> file time).  Calls come in the reference's order (per region, strongest
+ * first).  SONO_EREFERENCE: debug_mode is 0 and the reference would raise on one of the calls (its promise rejects). */
+typedef struct sono_full_file_options {
+    double threshold_db;            /* options.threshold_dB of the fast scan, reference default -60 */
+    double padding_ms;              /* options.padding_ms of mergeAndPadSegments, default 5 */
+    double hop_percent;             /* config.hopPercent, default 3.125 */
+    double call_threshold_db;       /* config.callThreshold_dB, default -24 */
+    double min_call_duration_ms;    /* config.minCallDuration_ms, default 1 */
+    int32_t debug_mode;             /* the detector's debugMode switch */
+    uint32_t threads;               /* host threads of the measurement stage, 0 = up to 16 */
+} sono_full_file_options;
+enum { SONO_CALL_CF = 0, SONO_CALL_FM = 1, SONO_CALL_CF_FM = 2 };
+typedef struct sono_full_file_call {
+    sono_call_measurement m;        /* times in seconds are file time */
+    uint64_t roi, start_frame, end_frame;       /* region, and the call's frames within the region's analysis spectrogram */
+    double highpass_khz;            /* automatic high-pass applied to the region, 0 = none */
+    double flow_hz, fhigh_khz;      /* call.Flow, call.Fhigh (js:813-814) */
+    double snr_db;
+    int32_t call_type;              /* SONO_CALL_* */
+    int32_t quality;                /* 0 'Very Poor', 1 'Poor', 2 'Normal', 3 'Good', 4 'Excellent' */
+} sono_full_file_call;
+int sono_process_full_file(sono_engine *e, const float *x, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
+                           const sono_full_file_options *opt, sono_full_file_call *out, size_t cap, size_t *count);
+/* The engine keeps the calls of its last sono_process_full_file.  When that returned SONO_ECAPACITY (*count = the
+ * number of calls, the first cap of them written), fetch them all here with a larger buffer instead of running the
+ * recording again.  cap = 0 only asks for the count. */
+int sono_full_file_results(sono_engine *e, sono_full_file_call *out, size_t cap, size_t *count);
 
 /* mergeAndPadSegments (batCallDetector.js:1028-1056).  Host only; sorts `segs` in place. */
 int sono_merge_and_pad_segments(sono_segment *segs, size_t count, uint64_t total_samples, double sample_rate,

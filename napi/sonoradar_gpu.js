@@ -27,6 +27,27 @@ if (typeof Symbol.dispose === 'symbol') {
 function initSync() { return module.exports; }
 function init() { return Promise.resolve(module.exports); }
 
+// accelerateBatCallDetector(BatCallDetector, BatCall?): replaces the detector's whole-file pass
+// (BatCallDetector.prototype.processFullFile, batCallDetector.js:584-840) by ONE native call on the detector's own
+// engine (`new BatCallDetector(config, engine)`, js:346-351): fast scan, merge & pad, every region's analysis
+// spectrogram, framing and the measurement stage run batched on the GPU and on host threads.  Same calls, same order;
+// each call is a BatCall (when the class is given) carrying the numeric fields, callType and quality -- not the
+// per-call spectrogram slice, which the whole-file pass only needs internally.  Rejects where the reference's promise
+// rejects; detectors without a GPU engine keep the JavaScript path.
+function accelerateBatCallDetector(BatCallDetector, BatCall) {
+  const original = BatCallDetector.prototype.processFullFile;
+  BatCallDetector.prototype.processFullFile = async function (fullAudioData, sampleRate, flowKHz, fhighKHz, options = {}) {
+    const engine = this.wasmEngine;
+    if (!(engine instanceof addon.SpectrogramEngine)) return original.call(this, fullAudioData, sampleRate, flowKHz, fhighKHz, options);
+    const progress = options.progressCallback || (() => {});
+    const config = Object.assign({}, this.config, { debugMode: !!this.debugMode });
+    const rows = engine.process_full_file(fullAudioData, sampleRate, flowKHz, fhighKHz, options, config);
+    progress(1);
+    return rows.map((row) => Object.assign(BatCall ? new BatCall() : {}, row));
+  };
+  return BatCallDetector;
+}
+
 module.exports = {
   default: init,
   initSync,
@@ -36,5 +57,6 @@ module.exports = {
   find_peak_frequency_from_spectrum: addon.find_peak_frequency_from_spectrum,
   compute_wave_peaks: addon.compute_wave_peaks,
   find_global_max: addon.find_global_max,
+  accelerateBatCallDetector,                 // not in the wasm surface: the detector's whole-file pass as one native call
   device_count: addon.device_count,          // not in the wasm surface: lets a batch driver size its worker pool
 };

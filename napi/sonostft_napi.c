@@ -567,6 +567,111 @@ static napi_value fn_device_count(napi_env env, napi_callback_info info)
 
 #define METHOD(name, fn) { name, NULL, fn, NULL, NULL, NULL, napi_default, NULL }
 
+
+/* ---- not in the wasm surface: BatCallDetector.processFullFile (batCallDetector.js:584-840) as one native call ----
+ * engine.process_full_file(audio: Float32Array, sampleRate, flowKHz, fhighKHz, options, config) -> Array of objects
+ * carrying BatCall's numeric fields under BatCall's own names (null where the reference leaves null).
+ * options: {threshold_dB = -60, padding_ms = 5}; config: {hopPercent = 3.125, callThreshold_dB = -24,
+ * minCallDuration_ms = 1, debugMode = false}.  Throws where the reference's promise rejects. */
+static double prop_f64(napi_env env, napi_value obj, const char *name, double dflt)
+{
+    napi_value v;
+    napi_valuetype t;
+    double d;
+    if (is_nullish(env, obj) || napi_get_named_property(env, obj, name, &v) != napi_ok) return dflt;
+    if (napi_typeof(env, v, &t) != napi_ok) return dflt;
+    if (t == napi_boolean) { bool b = false; napi_get_value_bool(env, v, &b); return b ? 1.0 : 0.0; }
+    if (t != napi_number || napi_get_value_double(env, v, &d) != napi_ok) return dflt;
+    return d;
+}
+
+static int set_f64(napi_env env, napi_value obj, const char *name, double v)
+{
+    napi_value x;
+    if (v != v) { if (napi_get_null(env, &x) != napi_ok) return 0; }
+    else if (napi_create_double(env, v, &x) != napi_ok) return 0;
+    return napi_set_named_property(env, obj, name, x) == napi_ok;
+}
+
+static int set_idx(napi_env env, napi_value obj, const char *name, int64_t v)
+{
+    return set_f64(env, obj, name, v < 0 ? 0.0 / 0.0 : (double)v);
+}
+
+static int set_str(napi_env env, napi_value obj, const char *name, const char *v)
+{
+    napi_value x;
+    return napi_create_string_utf8(env, v, NAPI_AUTO_LENGTH, &x) == napi_ok && napi_set_named_property(env, obj, name, x) == napi_ok;
+}
+
+static napi_value engine_process_full_file(napi_env env, napi_callback_info info)
+{
+    static const char *const types[] = {"CF", "FM", "CF-FM"};
+    static const char *const qualities[] = {"Very Poor", "Poor", "Normal", "Good", "Excellent"};
+    napi_value argv[6], self, arr;
+    if (!get_args(env, info, 6, argv, &self)) return NULL;
+    engine_box *b = engine_of(env, self);
+    if (!b) return NULL;
+    void *x = NULL;
+    size_t n = 0;
+    double sr = 0, flow = 0, fhigh = 0;
+    if (!get_typed(env, argv[0], napi_float32_array, &x, &n) || !get_f64(env, argv[1], &sr) || !get_f64(env, argv[2], &flow) ||
+        !get_f64(env, argv[3], &fhigh)) {
+        napi_throw_type_error(env, NULL, "process_full_file(Float32Array, sampleRate, flowKHz, fhighKHz, options?, config?)");
+        return NULL;
+    }
+    sono_full_file_options opt;
+    opt.threshold_db = prop_f64(env, argv[4], "threshold_dB", -60);
+    if (opt.threshold_db == 0) opt.threshold_db = -60;                 /* `options.threshold_dB || -60`, js:585 */
+    opt.padding_ms = prop_f64(env, argv[4], "padding_ms", 5);
+    if (opt.padding_ms == 0) opt.padding_ms = 5;                       /* js:586 */
+    opt.hop_percent = prop_f64(env, argv[5], "hopPercent", 3.125);
+    opt.call_threshold_db = prop_f64(env, argv[5], "callThreshold_dB", -24);
+    opt.min_call_duration_ms = prop_f64(env, argv[5], "minCallDuration_ms", 1);
+    opt.debug_mode = prop_f64(env, argv[5], "debugMode", 0) != 0;
+    opt.threads = 0;
+    size_t count = 0;
+    int rc = sono_process_full_file(b->e, (const float *)x, n, sr, flow, fhigh, &opt, NULL, 0, &count);
+    if (rc != SONO_OK && rc != SONO_ECAPACITY) return throw_status(env, rc);
+    sono_full_file_call *calls = (sono_full_file_call *)malloc((count ? count : 1) * sizeof(*calls));
+    if (!calls) { napi_throw_error(env, NULL, "sonostft: out of memory"); return NULL; }
+    rc = sono_full_file_results(b->e, calls, count, &count);
+    if (rc != SONO_OK) { free(calls); return throw_status(env, rc); }
+    if (napi_create_array_with_length(env, count, &arr) != napi_ok) { free(calls); return NULL; }
+    for (size_t i = 0; i < count; ++i) {
+        const sono_full_file_call *k = &calls[i];
+        const sono_call_measurement *m = &k->m;
+        napi_value o;
+        int ok = napi_create_object(env, &o) == napi_ok;
+        ok = ok && set_f64(env, o, "startTime_s", m->start_time_s) && set_f64(env, o, "endTime_s", m->end_time_s) &&
+             set_f64(env, o, "duration_ms", m->duration_ms) && set_f64(env, o, "peakFreq_kHz", m->peak_freq_khz) &&
+             set_f64(env, o, "peakFreq_ms", m->peak_freq_ms) && set_f64(env, o, "peakPower_dB", m->peak_power_db) &&
+             set_f64(env, o, "highFreq_kHz", m->high_freq_khz) && set_f64(env, o, "highFreq_ms", m->high_freq_ms) &&
+             set_f64(env, o, "startFreq_kHz", m->start_freq_khz) && set_f64(env, o, "startFreq_ms", m->start_freq_ms) &&
+             set_f64(env, o, "startFreqTime_s", m->start_freq_time_s) && set_f64(env, o, "endFreq_kHz", m->end_freq_khz) &&
+             set_f64(env, o, "endFreq_ms", m->end_freq_ms) && set_f64(env, o, "endFreqTime_s", m->end_freq_time_s) &&
+             set_f64(env, o, "lowFreq_kHz", m->low_freq_khz) && set_f64(env, o, "lowFreq_ms", m->low_freq_ms) &&
+             set_f64(env, o, "characteristicFreq_kHz", m->characteristic_freq_khz) &&
+             set_f64(env, o, "characteristicFreq_ms", m->characteristic_freq_ms) && set_f64(env, o, "kneeFreq_kHz", m->knee_freq_khz) &&
+             set_f64(env, o, "kneeFreq_ms", m->knee_freq_ms) && set_f64(env, o, "kneeTime_ms", m->knee_freq_ms) &&
+             set_f64(env, o, "heelFreq_kHz", m->heel_freq_khz) && set_f64(env, o, "heelFreq_ms", m->heel_freq_ms) &&
+             set_f64(env, o, "bandwidth_kHz", m->bandwidth_khz) &&
+             set_f64(env, o, "highFreqThreshold_dB_used", m->high_threshold_db_used) &&
+             set_f64(env, o, "lowFreqThreshold_dB_used", m->low_threshold_db_used) && set_idx(env, o, "peakFrameIdx", m->peak_frame) &&
+             set_idx(env, o, "highFreqFrameIdx", m->high_freq_frame) && set_idx(env, o, "startFreqFrameIdx", m->start_freq_frame) &&
+             set_idx(env, o, "startFreqBinIdx", m->start_freq_bin) && set_idx(env, o, "endFrameIdx_forLowFreq", m->end_frame_for_low_freq) &&
+             set_idx(env, o, "kneeFrameIdx", m->knee_frame) && set_idx(env, o, "heelFrameIdx", m->heel_frame) &&
+             set_f64(env, o, "Flow", k->flow_hz) && set_f64(env, o, "Fhigh", k->fhigh_khz) && set_f64(env, o, "snr_dB", k->snr_db) &&
+             set_str(env, o, "callType", types[k->call_type]) && set_str(env, o, "quality", qualities[k->quality]) &&
+             set_f64(env, o, "roi", (double)k->roi) && set_f64(env, o, "startFrame", (double)k->start_frame) &&
+             set_f64(env, o, "endFrame", (double)k->end_frame) && set_f64(env, o, "highpass_kHz", k->highpass_khz) &&
+             napi_set_element(env, arr, (uint32_t)i, o) == napi_ok;
+        if (!ok) { free(calls); napi_throw_error(env, NULL, "sonostft: cannot build the result array"); return NULL; }
+    }
+    free(calls);
+    return arr;
+}
+
 static napi_value init(napi_env env, napi_value exports)
 {
     const napi_property_descriptor engine_methods[] = {
@@ -586,6 +691,7 @@ static napi_value init(napi_env env, napi_value exports)
         METHOD("set_spectrum_config", engine_set_spectrum_config),
         METHOD("compute_spectrogram_image", engine_compute_spectrogram_image),
         METHOD("release_memory", engine_release_memory),
+        METHOD("process_full_file", engine_process_full_file),
     };
     const napi_property_descriptor wave_methods[] = {
         METHOD("free", wave_free),

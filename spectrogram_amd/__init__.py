@@ -96,6 +96,20 @@ class CallMeasurement(C.Structure):
                 + [("discarded", C.c_int32), ("reference_throws", C.c_int32)])
 
 
+class FullFileOptions(C.Structure):
+    """struct sono_full_file_options."""
+    _fields_ = [("threshold_db", C.c_double), ("padding_ms", C.c_double), ("hop_percent", C.c_double),
+                ("call_threshold_db", C.c_double), ("min_call_duration_ms", C.c_double), ("debug_mode", C.c_int32),
+                ("threads", C.c_uint32)]
+
+
+class FullFileCall(C.Structure):
+    """struct sono_full_file_call."""
+    _fields_ = [("m", CallMeasurement), ("roi", C.c_uint64), ("start_frame", C.c_uint64), ("end_frame", C.c_uint64),
+                ("highpass_khz", C.c_double), ("flow_hz", C.c_double), ("fhigh_khz", C.c_double), ("snr_db", C.c_double),
+                ("call_type", C.c_int32), ("quality", C.c_int32)]
+
+
 class LowThreshold(C.Structure):
     """struct sono_low_threshold."""
     _fields_ = [("threshold_db", C.c_double), ("low_freq_hz", C.c_double), ("end_freq_hz", C.c_double),
@@ -205,6 +219,9 @@ _SIGNATURES = {
                                               C.POINTER(C.c_double), C.c_size_t, _szp, C.c_void_p]),
     "sono_db_percentile": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_double, C.POINTER(C.c_float)]),
     "sono_db_percentile_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.POINTER(C.c_float), C.c_void_p]),
+    "sono_process_full_file": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_double, C.c_double, C.c_double,
+                                         C.POINTER(FullFileOptions), C.POINTER(FullFileCall), C.c_size_t, _szp]),
+    "sono_full_file_results": (C.c_int, [C.c_void_p, C.POINTER(FullFileCall), C.c_size_t, _szp]),
     "sono_measure_roi_calls": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.POINTER(Segment), C.c_size_t, C.POINTER(RoiTable),
                                          C.POINTER(RoiCall), C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                          C.c_uint, C.POINTER(CallMeasurement)]),

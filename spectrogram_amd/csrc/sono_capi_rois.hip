@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -432,6 +433,87 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, size_t n, const sono_
         for (std::thread &th : pool) th.join();
         c0 = c1;
     }
+    return SONO_OK;
+}
+
+int sono_process_full_file(sono_engine *e, const float *x, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
+                           const sono_full_file_options *opt, sono_full_file_call *out, size_t cap, size_t *count)
+{
+    if (count) *count = 0;
+    if (!e || !opt || (n && !x) || (cap && !out)) return fail(SONO_EINVAL, "sono_process_full_file: NULL argument");
+    e->full_file_calls.clear();
+    if (!(sample_rate > 0)) return fail(SONO_EINVAL, "sono_process_full_file: sample_rate must be positive");
+    const uint32_t N = e->N;
+    // fast scan -> merge & pad (batCallDetector.js:594-601)
+    std::vector<sono_segment> raw(n / std::max<size_t>(N / 2, 1) + 2);
+    size_t n_raw = 0;
+    int rc = sono_fast_scan_segments(e, x, n, sample_rate, flow_khz, fhigh_khz, opt->threshold_db, raw.data(), raw.size(), &n_raw);
+    if (rc) return rc;
+    if (n_raw == 0) return SONO_OK;                                                 // js:595-598
+    std::vector<sono_segment> rois(n_raw);
+    size_t n_rois = 0;
+    rc = sono_merge_and_pad_segments(raw.data(), n_raw, n, sample_rate, opt->padding_ms, rois.data(), rois.size(), &n_rois);
+    if (rc) return rc;
+    // per-region analysis, all regions at once (js:609-711)
+    std::vector<uint64_t> row0(n_rois + 1);
+    rc = sono_roi_rows(rois.data(), n_rois, N, opt->hop_percent, row0.data());
+    if (rc) return rc;
+    const size_t total = (size_t)row0[n_rois];
+    std::vector<float> peak_db(total + 1), left(total + 1), right(total + 1), hp(n_rois + 1);
+    std::vector<int32_t> peak_bin(total + 1), ilo(total + 1), ihi(total + 1);
+    std::vector<double> zonal((n_rois + 1) * SONO_MAX_ZONES);
+    sono_roi_table t{row0.data(), peak_db.data(), peak_bin.data(), left.data(), right.data(), ilo.data(), ihi.data(),
+                     zonal.data(), hp.data(), 0, 0, 0, 0};
+    std::vector<float> xf(x, x + n);
+    rc = sono_analyze_rois(e, x, n, rois.data(), n_rois, sample_rate, flow_khz, fhigh_khz, opt->hop_percent, 1, &t, total, xf.data());
+    if (rc) return rc;
+    // framing (js:677-794), measurement (js:797) and what follows it (js:802-827)
+    std::vector<sono_roi_call> framed(total / 2 + n_rois + 1);
+    size_t n_calls = 0;
+    rc = sono_frame_roi_calls(xf.data(), n, rois.data(), n_rois, &t, sample_rate, N, opt->call_threshold_db,
+                              opt->min_call_duration_ms, framed.data(), framed.size(), &n_calls);
+    if (rc) return rc;
+    std::vector<sono_call_measurement> meas(n_calls + 1);
+    rc = sono_measure_roi_calls(e, xf.data(), n, rois.data(), n_rois, &t, framed.data(), n_calls, sample_rate, flow_khz, fhigh_khz,
+                                opt->hop_percent, opt->debug_mode, opt->threads, meas.data());
+    if (rc) return rc;
+    std::vector<sono_full_file_call> &kept = e->full_file_calls;
+    for (size_t i = 0; i < n_calls; ++i) {
+        sono_call_measurement &m = meas[i];
+        if (m.reference_throws) {
+            kept.clear();
+            return fail(SONO_EREFERENCE, "sono_process_full_file: the reference raises a TypeError on call " + std::to_string(i) +
+                                             " of this recording outside its debug mode (batCallDetector.js:2261, 2815)");
+            }
+        if (m.discarded || m.duration_ms <= 1.0) continue;                          // js:802-810
+        const double offset = (double)rois[framed[i].roi].start / sample_rate;      // js:737, 822-825
+        m.start_time_s += offset;
+        m.end_time_s += offset;
+        if (m.start_freq_time_s == m.start_freq_time_s) m.start_freq_time_s += offset;
+        if (m.end_freq_time_s == m.end_freq_time_s) m.end_freq_time_s += offset;
+        kept.emplace_back();
+        sono_full_file_call &o = kept.back();
+        o.m = m;
+        o.roi = framed[i].roi; o.start_frame = framed[i].start_frame; o.end_frame = framed[i].end_frame;
+        o.highpass_khz = hp[framed[i].roi];
+        o.flow_hz = m.low_freq_khz * 1000;                                          // js:813-814
+        o.fhigh_khz = m.high_freq_khz;
+        o.snr_db = m.peak_power_db - (-80);                                         // js:818
+        const double bw = m.bandwidth_khz;                                          // CallTypeClassifier.classify, js:48-56
+        o.call_type = (!(bw == bw) || bw == 0 || bw < 5) ? SONO_CALL_CF : bw > 20 ? SONO_CALL_FM : SONO_CALL_CF_FM;
+        o.quality = o.snr_db < 10 ? 0 : o.snr_db < 15 ? 1 : o.snr_db < 20 ? 2 : o.snr_db < 30 ? 3 : 4;    // getQualityRating, js:375-387
+    }
+    return sono_full_file_results(e, out, cap, count);
+}
+
+int sono_full_file_results(sono_engine *e, sono_full_file_call *out, size_t cap, size_t *count)
+{
+    if (!e || (cap && !out)) return fail(SONO_EINVAL, "sono_full_file_results: NULL argument");
+    const std::vector<sono_full_file_call> &kept = e->full_file_calls;
+    if (count) *count = kept.size();
+    const size_t take = std::min(cap, kept.size());
+    if (take) std::memcpy(out, kept.data(), take * sizeof(sono_full_file_call));
+    if (kept.size() > cap) return fail(SONO_ECAPACITY, "sono_full_file_results: output buffer too small (count holds the number of calls)");
     return SONO_OK;
 }
 

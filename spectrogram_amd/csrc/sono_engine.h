@@ -98,6 +98,8 @@ struct sono_engine {
     RaggedSlot ragged[2];
     unsigned int ragged_next = 0;
     hipStream_t copy_stream = nullptr;      // uploads the tables without waiting for the caller's stream
+    // calls of the last sono_process_full_file, kept for sono_full_file_results
+    std::vector<sono_full_file_call> full_file_calls;
     // filter bank (lib.rs:20-22)
     std::vector<float> bank;
     unsigned int num_filters = 0;

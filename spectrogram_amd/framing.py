@@ -17,7 +17,8 @@ from . import detector as _det
 
 __all__ = ["calculate_zonal_noise_floors", "db_percentile", "refine_end_using_oscillogram", "frame_calls",
            "scan_spectrum_for_frequency", "calculate_auto_highpass_filter_freq", "apply_highpass_filter",
-           "savitzky_golay", "detect_calls_framing", "process_full_file", "process_full_file_batched", "calculate_rms_based_snr",
+           "savitzky_golay", "detect_calls_framing", "process_full_file", "process_full_file_batched", "process_full_file_native",
+           "calculate_rms_based_snr",
            "DEFAULT_FRAMING_CONFIG"]
 
 # the members of DEFAULT_DETECTION_CONFIG (batCallDetector.js:3-45) this stage reads
@@ -303,6 +304,47 @@ def process_full_file_batched(engine, full_audio_data, sample_rate, flow_khz, fh
             "instBandwidth_kHz": c.inst_bandwidth_khz, "snr_dB": float(c.peak_power_db) + 80.0, "highpass_kHz": float(hp[r]),
             "zonalNoiseMap": {10 * z: float(zonal[r * SONO_MAX_ZONES + z]) for z in range(table.num_zones)},
         })
+    return calls
+
+
+_CALL_TYPES = ("CF", "FM", "CF-FM")
+_QUALITIES = ("Very Poor", "Poor", "Normal", "Good", "Excellent")
+
+
+def process_full_file_native(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options=None, config=None, threads=0):
+    """processFullFile (batCallDetector.js:584-840) as ONE library call (sono_process_full_file): same calls, order and
+    values as process_full_file_batched(..., measure=True), without the per-region tables (zonalNoiseMap).  Raises
+    measure.ReferenceThrows where the reference's promise rejects (config['debugMode'] False and a call on which the
+    reference raises outside its debug mode)."""
+    from . import FullFileCall as _Call, FullFileOptions as _Opt, SonoError, measure as _ms
+    opt = dict({"threshold_dB": -60, "padding_ms": 5}, **(options or {}))
+    cfg = dict(DEFAULT_FRAMING_CONFIG, **(config or {}))
+    x = _f32(full_audio_data)
+    o = _Opt(float(opt["threshold_dB"]), float(opt["padding_ms"]), float(cfg["hopPercent"]), float(cfg["callThreshold_dB"]),
+             float(cfg["minCallDuration_ms"]), int(bool(cfg.get("debugMode", False))), int(threads))
+    cap = 4096
+    out = (_Call * cap)()
+    got = C.c_size_t(0)
+    try:
+        _check(lib().sono_process_full_file(engine._handle(), _p(x), x.size, float(sample_rate), float(flow_khz), float(fhigh_khz),
+                                            C.byref(o), out, cap, C.byref(got)))
+    except SonoError as err:
+        if err.status == 5:                                # SONO_EREFERENCE
+            raise _ms.ReferenceThrows(str(err)) from None
+        if err.status != 4:                                # SONO_ECAPACITY: the engine kept the calls, fetch them all
+            raise
+        cap = got.value
+        out = (_Call * cap)()
+        _check(lib().sono_full_file_results(engine._handle(), out, cap, C.byref(got)))
+    calls = []
+    for i in range(got.value):
+        k, m = out[i], out[i].m
+        call = {name: (None if v != v else v) for name, v in ((nm, getattr(m, f)) for nm, (f, _) in zip(_ms.CALL_FIELDS, type(m)._fields_))}
+        call.update({name: (None if getattr(m, f) < 0 else int(getattr(m, f))) for name, f in zip(_ms._FRAME_FIELDS, type(m)._frames)})
+        call.update(Flow=k.flow_hz, Fhigh=k.fhigh_khz, callType=_CALL_TYPES[k.call_type], snr_dB=k.snr_db,
+                    quality=_QUALITIES[k.quality], startFrame=int(k.start_frame), endFrame=int(k.end_frame), roi=int(k.roi),
+                    highpass_kHz=float(k.highpass_khz))
+        calls.append(call)
     return calls
 
 

@@ -179,6 +179,13 @@ def test_full_file_with_the_measurement_stage(golden):
     assert {k["callType"] for k in one} <= {"CF", "FM", "CF-FM"} and all(k["quality"] for k in one)
     rows = sh.calls_to_rows(batched, file_id=1)
     assert rows.shape[0] == len(batched)
+    # the same as ONE library call
+    with pytest.raises(ms.ReferenceThrows):
+        fr.process_full_file_native(*args, cfg)
+    native = fr.process_full_file_native(*args, dict(cfg, debugMode=True))
+    assert len(native) == len(batched)
+    for a, b in zip(native, batched):
+        assert a == {k: v for k, v in b.items() if k != "zonalNoiseMap"}
     e.free()
 
 
@@ -205,6 +212,11 @@ def test_batched_region_analysis_on_a_long_recording():
     assert len(one) > 50 and len(one) == len(batched)
     for a, b in zip(one, batched):
         assert {k: v for k, v in a.items() if k != "zonalNoiseMap"} == {k: v for k, v in b.items() if k != "zonalNoiseMap"}
+    import spectrogram_amd.framing as frm
+    small = frm.process_full_file_native(e, x[: sr // 2], sr, 15.0, 110.0, {"threshold_dB": -45.0}, cfg)      # results of an earlier run
+    native = frm.process_full_file_native(e, x, sr, 15.0, 110.0, {"threshold_dB": -45.0}, cfg, threads=3)
+    assert 0 < len(small) < len(native) == len(batched)
+    assert all(a == {k: v for k, v in b.items() if k != "zonalNoiseMap"} for a, b in zip(native, batched))
     e.free()
 
 

@@ -14,6 +14,7 @@ ADDON = os.path.join(ROOT, "napi", "sonostft.node")
 # The export surface of the reference's wasm-bindgen module (modules/spectrogram_wasm.d.ts:4-271, 324-334).
 MODULE_EXPORTS = ["default", "initSync", "SpectrogramEngine", "WaveformEngine", "compute_power_spectrum",
                   "find_peak_frequency_from_spectrum", "compute_wave_peaks", "find_global_max"]
+EXTRA_EXPORTS = ["accelerateBatCallDetector", "device_count"]         # beyond the wasm surface
 ENGINE_METHODS = ["free", "get_fft_size", "get_freq_bins", "get_num_filters", "get_window_values", "load_filter_bank",
                   "clear_filter_bank", "compute_spectrogram", "compute_spectrogram_u8", "get_peaks",
                   "get_peak_magnitudes", "get_global_max", "set_color_map", "set_spectrum_config",
@@ -51,7 +52,7 @@ def test_addon_presents_the_wasm_module_surface():
         try { we.clear(); } catch (e) { r.after_free = e.message; }
         w.default().then((m) => { r.init_ok = m === w && w.initSync() === w; console.log(JSON.stringify(r)); });
     """))
-    assert set(MODULE_EXPORTS) <= set(out["exports"])
+    assert set(MODULE_EXPORTS + EXTRA_EXPORTS) == set(out["exports"]) and "process_full_file" in out["engine"]
     assert set(ENGINE_METHODS) <= set(out["engine"]) and set(WAVEFORM_METHODS) <= set(out["wave"])
     assert out["init_ok"] and out["gmax"] == 0.5 and out["peaks"] == [0.5, np.float32(0.3)]
     assert out["chans"] == 2 and out["len"] == [0, 4] and out["range"] == [0.5, np.float32(0.3)]
@@ -106,3 +107,58 @@ def test_addon_results_equal_python_binding_and_oracle(tmp_path):
     assert "noverlap must be < fft_size" in meta["noverlap_error"]        # the reference panics here (lib.rs:118-120)
     assert meta["after_free"] == "null pointer passed to rust"
     e.free()
+
+
+@pytest.mark.gpu
+def test_addon_whole_file_pass_equals_python_binding(tmp_path):
+    """engine.process_full_file and the accelerateBatCallDetector shell against framing.process_full_file_native."""
+    need_node()
+    import spectrogram_amd as sa
+    from spectrogram_amd import framing as fr
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_framing.npz"))
+    meta = json.loads(bytes(g["__meta__"]).decode())
+    (c,) = [c for c in meta if c["kind"] == "fullfile_measured"]
+    x = np.ascontiguousarray(g[c["name"] + "/x"], np.float32)
+    x.tofile(tmp_path / "x.f32")
+    script = """
+        const fs = require('fs');
+        const w = require('./napi/sonoradar_gpu.js');
+        const buf = fs.readFileSync(%r);
+        const x = new Float32Array(buf.buffer, buf.byteOffset, buf.length / 4);
+        const e = new w.SpectrogramEngine(%d, %r, null);
+        const cfg = {hopPercent: %r, callThreshold_dB: %r, minCallDuration_ms: %r};
+        class BatCall { constructor() { this.callType = 'FM'; } }
+        class BatCallDetector {
+          constructor(config, engine) { this.config = config; this.wasmEngine = engine; this.debugMode = false; }
+          async processFullFile() { return 'javascript path'; }
+        }
+        w.accelerateBatCallDetector(BatCallDetector, BatCall);
+        (async () => {
+          const r = {};
+          const d = new BatCallDetector(cfg, e);
+          try { await d.processFullFile(x, %d, %r, %r, {threshold_dB: %r, padding_ms: %r}); } catch (err) { r.rejected = err.message; }
+          d.debugMode = true;
+          let seen = 0;
+          const calls = await d.processFullFile(x, %d, %r, %r, {threshold_dB: %r, padding_ms: %r, progressCallback: (p) => { seen = p; }});
+          r.calls = calls; r.progress = seen; r.isBatCall = calls.every((k) => k instanceof BatCall);
+          r.fallback = await new BatCallDetector(cfg, null).processFullFile(x, 1, 1, 1);
+          e.free();
+          console.log(JSON.stringify(r));
+        })();
+    """ % (str(tmp_path / "x.f32"), c["fft"], c["window"], c["hop_percent"], c["call_threshold_db"], c["min_call_duration_ms"],
+           c["sr"], c["flow_khz"], c["fhigh_khz"], c["scan_threshold_db"], c["padding_ms"],
+           c["sr"], c["flow_khz"], c["fhigh_khz"], c["scan_threshold_db"], c["padding_ms"])
+    out = json.loads(node(script))
+    assert "outside its debug mode" in out["rejected"] and out["progress"] == 1 and out["isBatCall"]
+    assert out["fallback"] == "javascript path"
+    e = sa.SpectrogramEngine(c["fft"], c["window"])
+    want = fr.process_full_file_native(e, x, c["sr"], c["flow_khz"], c["fhigh_khz"],
+                                       {"threshold_dB": c["scan_threshold_db"], "padding_ms": c["padding_ms"]},
+                                       {"hopPercent": c["hop_percent"], "callThreshold_dB": c["call_threshold_db"],
+                                        "minCallDuration_ms": c["min_call_duration_ms"], "debugMode": True})
+    e.free()
+    assert len(out["calls"]) == len(want) > 0
+    for got, ref in zip(out["calls"], want):
+        for k, v in ref.items():
+            assert got[k] == v, (k, got[k], v)                           # same library, doubles through JSON: bit-exact
+        assert got["kneeTime_ms"] == ref["kneeFreq_ms"]
