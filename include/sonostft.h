@@ -476,20 +476,22 @@ typedef struct sono_roi_call {
 /* The rest of processFullFile's per-region work (js:677-828, without the
  * measurement stage) from sono_analyze_rois's table: call segments, duration
  * filter, strongest-first 30 ms echo filter, 5 ms padding, oscillogram
- * refinement, time stamps.  x: the recording with high-passed regions filtered
- * (sono_analyze_rois's x_filtered).  Calls come out region by region, strongest
- * first inside a region, like the reference's.  Host only. */
-int sono_frame_roi_calls(const float *x, size_t n, const sono_segment *rois, size_t n_rois, const sono_roi_table *table,
+ * refinement, time stamps.  x: the recording; x_filtered: what sono_analyze_rois
+ * wrote (read only inside the regions that were high-passed; NULL = read x
+ * everywhere).  Calls come out region by region, strongest first inside a
+ * region, like the reference's.  Host only (regions shared out over threads). */
+int sono_frame_roi_calls(const float *x, const float *x_filtered, size_t n, const sono_segment *rois, size_t n_rois,
+                         const sono_roi_table *table,
                          double sample_rate, uint32_t fft_size, double call_threshold_db, double min_call_duration_ms,
                          sono_roi_call *out, size_t cap, size_t *count);
 
 /* The measurement stage (sono_measure_frequency_parameters) for calls sono_frame_roi_calls returned, all at once:
- * the calls' frames are transformed again from the recording (x = the x_filtered of sono_analyze_rois) in one ragged
+ * the calls' frames are transformed again from the recording (x, x_filtered as for sono_frame_roi_calls) in one ragged
  * launch -- bit for bit the dB values of the region's own transform -- and the calls are measured on `threads`
  * host threads (0 = up to 16).  out[i] belongs to calls[i]; its times are relative to the call's region, as
  * processFullFile has them at that point (batCallDetector.js:786-797; add rois[roi].start / sample_rate for file
  * time, js:822-825).  Table, band and hop must be those of the sono_analyze_rois call. */
-int sono_measure_roi_calls(sono_engine *e, const float *x, size_t n, const sono_segment *rois, size_t n_rois,
+int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filtered, size_t n, const sono_segment *rois, size_t n_rois,
                            const sono_roi_table *t, const sono_roi_call *calls, size_t n_calls, double sample_rate,
                            double flow_khz, double fhigh_khz, double hop_percent, int debug_mode, unsigned int threads,
                            sono_call_measurement *out);

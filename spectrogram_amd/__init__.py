@@ -222,7 +222,7 @@ _SIGNATURES = {
     "sono_process_full_file": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_double, C.c_double, C.c_double,
                                          C.POINTER(FullFileOptions), C.POINTER(FullFileCall), C.c_size_t, _szp]),
     "sono_full_file_results": (C.c_int, [C.c_void_p, C.POINTER(FullFileCall), C.c_size_t, _szp]),
-    "sono_measure_roi_calls": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.POINTER(Segment), C.c_size_t, C.POINTER(RoiTable),
+    "sono_measure_roi_calls": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_size_t, C.POINTER(Segment), C.c_size_t, C.POINTER(RoiTable),
                                          C.POINTER(RoiCall), C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                          C.c_uint, C.POINTER(CallMeasurement)]),
     "sono_measure_frequency_parameters": (C.c_int, [C.POINTER(CallMatrix), C.c_size_t, C.c_double, C.c_double,
@@ -246,7 +246,7 @@ _SIGNATURES = {
     "sono_roi_rows": (C.c_int, [_segp, C.c_size_t, C.c_uint32, C.c_double, C.POINTER(C.c_uint64)]),
     "sono_analyze_rois": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, _segp, C.c_size_t, C.c_double, C.c_double, C.c_double,
                                     C.c_double, C.c_int, C.POINTER(RoiTable), C.c_size_t, _f32p]),
-    "sono_frame_roi_calls": (C.c_int, [_f32p, C.c_size_t, _segp, C.c_size_t, C.POINTER(RoiTable), C.c_double, C.c_uint32,
+    "sono_frame_roi_calls": (C.c_int, [_f32p, _f32p, C.c_size_t, _segp, C.c_size_t, C.POINTER(RoiTable), C.c_double, C.c_uint32,
                                        C.c_double, C.c_double, C.POINTER(RoiCall), C.c_size_t, _szp]),
     "sono_wav_parse": (C.c_int, [_u8p, C.c_size_t, C.POINTER(WavInfo)]),
     "sono_pcm_to_f32_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,

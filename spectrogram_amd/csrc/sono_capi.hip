@@ -143,6 +143,7 @@ void sono_engine_destroy(sono_engine *e)
     e->d_gmax.release(); e->d_mags.release(); e->d_bank.release();
     e->d_db.release(); e->d_flags.release(); e->d_edges.release(); e->d_runs.release();
     e->d_count.release(); e->d_select_tmp.release();
+    e->h_in.release(); e->h_out.release();
     for (auto &slot : e->ragged) {
         if (slot.done) { (void)hipEventSynchronize(slot.done); (void)hipEventDestroy(slot.done); }
         slot.buf.release();
@@ -191,6 +192,7 @@ int sono_engine_release_memory(sono_engine *e)
     e->d_in.release(); e->d_out.release(); e->d_peak_bin.release(); e->d_peak_mag.release();
     e->d_mags.release(); e->d_bank.release();
     e->d_db.release(); e->d_flags.release(); e->d_edges.release(); e->d_runs.release(); e->d_select_tmp.release();
+    e->h_in.release(); e->h_out.release(); e->full_file_calls.clear(); e->full_file_calls.shrink_to_fit();
     return SONO_OK;
 }
 

@@ -7,8 +7,12 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -26,6 +30,7 @@ using sono::fail;
 namespace {
 
 constexpr size_t kBatchFrames = (size_t)1 << 19;      // frames whose magnitudes are in HBM at one time (1 GiB at fft 1024)
+constexpr size_t kMeasureFrames = (size_t)1 << 17;    // frames whose dB matrices cross to the host at one time
 
 struct Band { uint32_t hop, noverlap, min_bin, nb; bool ok; };
 
@@ -48,6 +53,30 @@ Band band_of(uint32_t N, double sample_rate, double flow_khz, double fhigh_khz, 
     return b;
 }
 
+// SONO_TIMING=1 prints the wall time of the stages of the whole-file entry points to stderr.
+struct StageTimer {
+    const char *who;
+    bool on = std::getenv("SONO_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    explicit StageTimer(const char *w) : who(w) {}
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[%s] %-28s %8.2f ms\n", who, what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+
+// Where region r's samples are read from after sono_analyze_rois: its x_filtered holds the regions that went through the
+// automatic high-pass (cutoff > 0 and below Nyquist, js:4058) and nothing else.
+const float *region_audio(const float *x, const float *x_filtered, const sono_roi_table *t, size_t r, double sample_rate)
+{
+    const bool filtered = x_filtered && t->highpass_khz && t->highpass_khz[r] > 0 &&
+                          (double)t->highpass_khz[r] * 1000.0 / (sample_rate / 2) < 1;
+    return filtered ? x_filtered : x;
+}
+
 // One pass over a set of regions whose samples sit at d_src + off[i]: magnitudes -> dB crop -> per-frame peak.
 // feat_rows[i] = where region i's records go in the host arrays.
 int peaks_pass(sono_engine *e, const float *d_src, const std::vector<uint64_t> &off, const std::vector<uint64_t> &len,
@@ -64,8 +93,10 @@ int peaks_pass(sono_engine *e, const float *d_src, const std::vector<uint64_t> &
     rc = sono_detect_power_db_dev(e, (const float *)e->d_mags.p, frames, bins, b.min_bin, b.nb, (float *)e->d_db.p, nullptr);
     if (rc) return rc;
     HIP_TRY(sono::launch_frame_peaks((const float *)e->d_db.p, frames, b.nb, (sono::FramePeak *)e->d_out.p, e->stream));
-    std::vector<sono::FramePeak> feat(frames);
-    HIP_TRY(hipMemcpyAsync(feat.data(), e->d_out.p, frames * sizeof(sono::FramePeak), hipMemcpyDeviceToHost, e->stream));
+    if (!e->h_out.reserve((frames ? frames : 1) * sizeof(sono::FramePeak)))
+        return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
+    const sono::FramePeak *feat = (const sono::FramePeak *)e->h_out.p;
+    HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, frames * sizeof(sono::FramePeak), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     size_t row = 0;
     for (size_t i = 0; i < off.size(); ++i) {
@@ -161,17 +192,19 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
         const size_t cnt = r1 - r0;
         if (frames == 0) { for (size_t r = r0; r < r1; ++r) for (size_t z = 0; z < SONO_MAX_ZONES; ++z) out->zonal[r * SONO_MAX_ZONES + z] = -102.0; r0 = r1; continue; }
         // pack the batch's samples and upload them in one copy
-        std::vector<float> packed(samples ? samples : 1);
+        if (!e->h_in.reserve((samples ? samples : 1) * sizeof(float)))
+            return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
+        float *packed = (float *)e->h_in.p;
         std::vector<uint64_t> off(cnt), len(cnt), rows(cnt), first_row(cnt);
         size_t pos = 0;
         for (size_t i = 0; i < cnt; ++i) {
             const sono_segment &g = rois[r0 + i];
             off[i] = pos; len[i] = g.end - g.start; rows[i] = out->row0[r0 + i];
-            std::memcpy(packed.data() + pos, x + g.start, (size_t)len[i] * sizeof(float));
+            std::memcpy(packed + pos, x + g.start, (size_t)len[i] * sizeof(float));
             pos += (size_t)len[i];
         }
-        HIP_TRY(e->d_in.reserve(packed.size() * sizeof(float)));
-        HIP_TRY(hipMemcpyAsync(e->d_in.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(e->d_in.reserve((samples ? samples : 1) * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(e->d_in.p, packed, samples * sizeof(float), hipMemcpyHostToDevice, s));
         rc = peaks_pass(e, (const float *)e->d_in.p, off, len, rows, b, frames, out, &first_row);
         if (rc) return rc;
         // ---- noise floors of every region's first six frames (js:622-627), from the unfiltered spectrogram ----
@@ -234,11 +267,13 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
                 HIP_TRY(hipMemcpyAsync(d_coefs, coefs, sizeof(coefs), hipMemcpyHostToDevice, s));
                 HIP_TRY(sono::launch_highpass_regions((const float *)e->d_in.p, (float *)e->d_runs.p, d_jobs, jobs.size(), d_coefs, s));
                 if (x_filtered) {
-                    std::vector<float> filt(fpos);
-                    HIP_TRY(hipMemcpyAsync(filt.data(), e->d_runs.p, fpos * sizeof(float), hipMemcpyDeviceToHost, s));
+                    if (!e->h_in.reserve(fpos * sizeof(float)))        // the packed input has been uploaded and used by now
+                        return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
+                    const float *filt = (const float *)e->h_in.p;
+                    HIP_TRY(hipMemcpyAsync(e->h_in.p, e->d_runs.p, fpos * sizeof(float), hipMemcpyDeviceToHost, s));
                     HIP_TRY(hipStreamSynchronize(s));
                     for (size_t k = 0; k < jobs.size(); ++k)
-                        std::memcpy(x_filtered + rois[r0 + job_region[k]].start, filt.data() + jobs[k].dst,
+                        std::memcpy(x_filtered + rois[r0 + job_region[k]].start, filt + jobs[k].dst,
                                     (size_t)jobs[k].len * sizeof(float));
                 }
                 rc = peaks_pass(e, (const float *)e->d_runs.p, off2, len2, rows2, b, frames2, out, nullptr);
@@ -250,67 +285,75 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
     return SONO_OK;
 }
 
-int sono_frame_roi_calls(const float *x, size_t n, const sono_segment *rois, size_t n_rois, const sono_roi_table *t,
+int sono_frame_roi_calls(const float *x, const float *x_filtered, size_t n, const sono_segment *rois, size_t n_rois, const sono_roi_table *t,
                          double sample_rate, uint32_t fft_size, double call_threshold_db, double min_call_duration_ms,
                          sono_roi_call *out, size_t cap, size_t *count)
 {
     if (count) *count = 0;
     if (!t || (n && !x) || (n_rois && (!rois || !t->row0)) || !(sample_rate > 0) || fft_size == 0)
         return fail(SONO_EINVAL, "sono_frame_roi_calls: NULL or non-positive argument");
-    size_t made = 0;
-    std::vector<double> tf;
-    std::vector<sono::CallFrame> framed;
+    for (size_t r = 0; r < n_rois; ++r)
+        if (t->row0[r + 1] > t->row0[r] && (rois[r].end > n || rois[r].end < rois[r].start))
+            return fail(SONO_EINVAL, "sono_frame_roi_calls: region outside the recording");
     struct Cand { uint64_t s, e, peak_frame; double power, time; };
-    std::vector<Cand> cands, kept;
-    for (size_t r = 0; r < n_rois; ++r) {
-        const size_t row = (size_t)t->row0[r], F = (size_t)(t->row0[r + 1] - t->row0[r]);
-        if (F == 0) continue;
-        if (rois[r].end > n || rois[r].end < rois[r].start) return fail(SONO_EINVAL, "sono_frame_roi_calls: region outside the recording");
-        const float *pdb = t->peak_db + row;
-        tf.resize(F);
-        for (size_t f = 0; f < F; ++f) tf[f] = ((double)f * (double)t->hop + (double)fft_size / 2) / sample_rate;    // js:1350-1351
-        float gmax = -INFINITY;
-        for (size_t f = 0; f < F; ++f) if (pdb[f] > gmax) gmax = pdb[f];           // js:1544-1550
-        const double threshold = (double)gmax + call_threshold_db;                  // js:1553
-        cands.clear();
-        size_t f = 0;
-        while (f < F) {                                                             // maximal runs of active frames, js:1556-1595
-            if (!((double)pdb[f] > threshold)) { ++f; continue; }
-            size_t g = f;
-            while (g + 1 < F && (double)pdb[g + 1] > threshold) ++g;
-            if (!(tf[g] - tf[f] < min_call_duration_ms / 1000)) {                   // js:688-689
-                size_t pk = f;
-                for (size_t k = f; k <= g; ++k) if (pdb[k] > pdb[pk]) pk = k;       // first maximum, js:695-703
-                cands.push_back({f, g, pk, (double)pdb[pk], tf[pk]});
+    // Regions are independent: they are shared out over host threads and their calls joined in region order.
+    std::vector<std::vector<sono_roi_call>> per_region(n_rois);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> low_rate{false};
+    auto work = [&]() {
+        std::vector<double> tf;
+        std::vector<sono::CallFrame> framed;
+        std::vector<Cand> cands, kept;
+        for (size_t r = next.fetch_add(1); r < n_rois; r = next.fetch_add(1)) {
+            const size_t row = (size_t)t->row0[r], F = (size_t)(t->row0[r + 1] - t->row0[r]);
+            if (F == 0) continue;
+            const float *pdb = t->peak_db + row;
+            tf.resize(F);
+            for (size_t f = 0; f < F; ++f) tf[f] = ((double)f * (double)t->hop + (double)fft_size / 2) / sample_rate;    // js:1350-1351
+            float gmax = -INFINITY;
+            for (size_t f = 0; f < F; ++f) if (pdb[f] > gmax) gmax = pdb[f];           // js:1544-1550
+            const double threshold = (double)gmax + call_threshold_db;                  // js:1553
+            cands.clear();
+            size_t f = 0;
+            while (f < F) {                                                             // maximal runs of active frames, js:1556-1595
+                if (!((double)pdb[f] > threshold)) { ++f; continue; }
+                size_t g = f;
+                while (g + 1 < F && (double)pdb[g + 1] > threshold) ++g;
+                if (!(tf[g] - tf[f] < min_call_duration_ms / 1000)) {                   // js:688-689
+                    size_t pk = f;
+                    for (size_t k = f; k <= g; ++k) if (pdb[k] > pdb[pk]) pk = k;       // first maximum, js:695-703
+                    cands.push_back({f, g, pk, (double)pdb[pk], tf[pk]});
+                }
+                f = g + 1;
             }
-            f = g + 1;
-        }
-        std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.power > b.power; });   // js:714
-        kept.clear();
-        for (const Cand &c : cands) {                                               // js:720-734
-            bool close = false;
-            for (const Cand &k : kept) if (std::fabs(c.time - k.time) < 0.030) { close = true; break; }
-            if (!close) kept.push_back(c);
-        }
-        const double offset = (double)rois[r].start / sample_rate;                  // js:737
-        for (const Cand &c : kept) {
-            const sono::FrameRun run{c.s, c.e};
-            if (!sono::host_frame_calls(&run, 1, tf.data(), F, x + rois[r].start, (size_t)(rois[r].end - rois[r].start), sample_rate,
-                                        fft_size, 5.0, min_call_duration_ms, true, framed))              // js:743-810
-                return fail(SONO_EINVAL, "sono_frame_roi_calls: sample rate below 20 kHz (the 0.1 ms window has no hop)");
-            for (const sono::CallFrame &k : framed) {
-                if (made >= cap || !out) return fail(SONO_ECAPACITY, "sono_frame_roi_calls: output buffer too small");
-                size_t pk = (size_t)k.start_frame;
-                for (size_t q = pk; q <= (size_t)k.end_frame; ++q) if (pdb[q] > pdb[pk]) pk = q;
-                sono_roi_call &o = out[made++];
-                o.roi = r; o.start_frame = k.start_frame; o.end_frame = k.end_frame; o.peak_frame = pk;
-                o.start_time_s = k.start_time_s + offset;                           // js:822-823
-                o.end_time_s = k.end_time_s + offset;
-                o.duration_ms = k.duration_ms;
-                o.peak_time_s = tf[pk] + offset;
-                o.peak_power_db = pdb[pk];
-                o.peak_bin = t->peak_bin[row + pk];
-                {
+            std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.power > b.power; });   // js:714
+            kept.clear();
+            for (const Cand &c : cands) {                                               // js:720-734
+                bool close = false;
+                for (const Cand &k : kept) if (std::fabs(c.time - k.time) < 0.030) { close = true; break; }
+                if (!close) kept.push_back(c);
+            }
+            const double offset = (double)rois[r].start / sample_rate;                  // js:737
+            for (const Cand &c : kept) {
+                const sono::FrameRun run{c.s, c.e};
+                if (!sono::host_frame_calls(&run, 1, tf.data(), F, region_audio(x, x_filtered, t, r, sample_rate) + rois[r].start,
+                                            (size_t)(rois[r].end - rois[r].start), sample_rate,
+                                            fft_size, 5.0, min_call_duration_ms, true, framed)) {        // js:743-810
+                    low_rate = true;
+                    return;
+                }
+                for (const sono::CallFrame &k : framed) {
+                    size_t pk = (size_t)k.start_frame;
+                    for (size_t q = pk; q <= (size_t)k.end_frame; ++q) if (pdb[q] > pdb[pk]) pk = q;
+                    per_region[r].emplace_back();
+                    sono_roi_call &o = per_region[r].back();
+                    o.roi = r; o.start_frame = k.start_frame; o.end_frame = k.end_frame; o.peak_frame = pk;
+                    o.start_time_s = k.start_time_s + offset;                           // js:822-823
+                    o.end_time_s = k.end_time_s + offset;
+                    o.duration_ms = k.duration_ms;
+                    o.peak_time_s = tf[pk] + offset;
+                    o.peak_power_db = pdb[pk];
+                    o.peak_bin = t->peak_bin[row + pk];
                     const int32_t pb = o.peak_bin;
                     const bool interior = pb > 0 && (uint32_t)pb + 1 < t->num_bins;                      // js:3023
                     const double res = sample_rate / (double)fft_size;
@@ -325,12 +368,25 @@ int sono_frame_roi_calls(const float *x, size_t n, const sono_segment *rois, siz
                 }
             }
         }
+    };
+    const unsigned int nt = (unsigned int)std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())),
+                                                           std::max<size_t>(n_rois / 64, 1));
+    std::vector<std::thread> pool;
+    for (unsigned int w = 1; w < nt; ++w) pool.emplace_back(work);
+    work();
+    for (std::thread &th : pool) th.join();
+    if (low_rate) return fail(SONO_EINVAL, "sono_frame_roi_calls: sample rate below 20 kHz (the 0.1 ms window has no hop)");
+    size_t made = 0;
+    for (size_t r = 0; r < n_rois; ++r) {
+        if (made + per_region[r].size() > cap || (!out && !per_region[r].empty()))
+            return fail(SONO_ECAPACITY, "sono_frame_roi_calls: output buffer too small");
+        for (const sono_roi_call &k : per_region[r]) out[made++] = k;
     }
     if (count) *count = made;
     return SONO_OK;
 }
 
-int sono_measure_roi_calls(sono_engine *e, const float *x, size_t n, const sono_segment *rois, size_t n_rois, const sono_roi_table *t,
+int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filtered, size_t n, const sono_segment *rois, size_t n_rois, const sono_roi_table *t,
                            const sono_roi_call *calls, size_t n_calls, double sample_rate, double flow_khz, double fhigh_khz,
                            double hop_percent, int debug_mode, unsigned int threads, sono_call_measurement *out)
 {
@@ -366,38 +422,44 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, size_t n, const sono_
     DeviceGuard guard(e->device);
     hipStream_t s = e->stream;
     if (threads == 0) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    StageTimer timer("sono_measure_roi_calls");
     size_t c0 = 0;
     while (c0 < n_calls) {
         size_t c1 = c0, frames = 0, samples = 0;
-        while (c1 < n_calls && (c1 == c0 || frames + slices[c1].count <= kBatchFrames)) {
+        while (c1 < n_calls && (c1 == c0 || frames + slices[c1].count <= kMeasureFrames)) {
             frames += (size_t)slices[c1].count;
             samples += (size_t)(slices[c1].count - 1) * b.hop + N;
             ++c1;
         }
         const size_t cnt = c1 - c0;
-        std::vector<float> packed(samples);
+        if (!e->h_in.reserve(samples * sizeof(float)) || !e->h_out.reserve(frames * b.nb * sizeof(float)))
+            return fail(SONO_ENOMEM, "sono_measure_roi_calls: cannot allocate host staging memory");
+        float *packed = (float *)e->h_in.p;
         std::vector<uint64_t> off(cnt), len(cnt), row(cnt);
         size_t pos = 0, rows = 0;
         for (size_t i = 0; i < cnt; ++i) {
             const sono_roi_call &k = calls[c0 + i];
             const Slice &sl = slices[c0 + i];
             off[i] = pos; len[i] = (sl.count - 1) * b.hop + N; row[i] = rows;
-            std::memcpy(packed.data() + pos, x + rois[k.roi].start + sl.first * b.hop, (size_t)len[i] * sizeof(float));
+            std::memcpy(packed + pos, region_audio(x, x_filtered, t, (size_t)k.roi, sample_rate) + rois[k.roi].start + sl.first * b.hop,
+                        (size_t)len[i] * sizeof(float));
             pos += (size_t)len[i];
             rows += (size_t)sl.count;
         }
-        HIP_TRY(e->d_in.reserve(packed.size() * sizeof(float)));
+        timer.lap("pack samples");
+        HIP_TRY(e->d_in.reserve(samples * sizeof(float)));
         HIP_TRY(e->d_mags.reserve(frames * bins * sizeof(float)));
         HIP_TRY(e->d_db.reserve(frames * b.nb * sizeof(float)));
-        HIP_TRY(hipMemcpyAsync(e->d_in.p, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(e->d_in.p, packed, samples * sizeof(float), hipMemcpyHostToDevice, s));
         sono_ragged_batch rb{(const float *)e->d_in.p, cnt, off.data(), len.data()};
         int rc = sono_stft_mag_f32_ragged_dev(e, &rb, b.noverlap, (float *)e->d_mags.p, nullptr);
         if (rc) return rc;
         rc = sono_detect_power_db_dev(e, (const float *)e->d_mags.p, frames, bins, b.min_bin, b.nb, (float *)e->d_db.p, nullptr);
         if (rc) return rc;
-        std::vector<float> db(frames * b.nb);
-        HIP_TRY(hipMemcpyAsync(db.data(), e->d_db.p, db.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+        float *db = (float *)e->h_out.p;
+        HIP_TRY(hipMemcpyAsync(db, e->d_db.p, frames * b.nb * sizeof(float), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        timer.lap("STFT, dB, copy to host");
         // ---- measureFrequencyParameters per call (js:786-797), calls shared out over host threads ----
         std::atomic<size_t> next{0};
         auto work = [&]() {
@@ -410,7 +472,7 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, size_t n, const sono_
                 tf.resize(times);
                 for (size_t f = 0; f < times; ++f)
                     tf[f] = ((double)(k.start_frame + f) * (double)b.hop + (double)N / 2) / sample_rate;     // js:1350-1351
-                const sono::CallMatrix m{db.data() + (row[i] + (size_t)slices[c0 + i].lead) * b.nb, call_frames, b.nb, freq_bins.data(),
+                const sono::CallMatrix m{db + (row[i] + (size_t)slices[c0 + i].lead) * b.nb, call_frames, b.nb, freq_bins.data(),
                                          t->zonal + (size_t)k.roi * SONO_MAX_ZONES, t->num_zones, debug_mode != 0};
                 sono::CallMeasure cm;
                 cm.start_time_s = tf[0];                                                           // js:791-794
@@ -431,6 +493,7 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, size_t n, const sono_
         for (unsigned int w = 1; w < nt; ++w) pool.emplace_back(work);
         work();
         for (std::thread &th : pool) th.join();
+        timer.lap("measure on host threads");
         c0 = c1;
     }
     return SONO_OK;
@@ -444,11 +507,14 @@ int sono_process_full_file(sono_engine *e, const float *x, size_t n, double samp
     e->full_file_calls.clear();
     if (!(sample_rate > 0)) return fail(SONO_EINVAL, "sono_process_full_file: sample_rate must be positive");
     const uint32_t N = e->N;
+    StageTimer timer("sono_process_full_file");
+    auto lap = [&](const char *what) { timer.lap(what); };
     // fast scan -> merge & pad (batCallDetector.js:594-601)
     std::vector<sono_segment> raw(n / std::max<size_t>(N / 2, 1) + 2);
     size_t n_raw = 0;
     int rc = sono_fast_scan_segments(e, x, n, sample_rate, flow_khz, fhigh_khz, opt->threshold_db, raw.data(), raw.size(), &n_raw);
     if (rc) return rc;
+    lap("fast scan");
     if (n_raw == 0) return SONO_OK;                                                 // js:595-598
     std::vector<sono_segment> rois(n_raw);
     size_t n_rois = 0;
@@ -464,19 +530,27 @@ int sono_process_full_file(sono_engine *e, const float *x, size_t n, double samp
     std::vector<double> zonal((n_rois + 1) * SONO_MAX_ZONES);
     sono_roi_table t{row0.data(), peak_db.data(), peak_bin.data(), left.data(), right.data(), ilo.data(), ihi.data(),
                      zonal.data(), hp.data(), 0, 0, 0, 0};
-    std::vector<float> xf(x, x + n);
-    rc = sono_analyze_rois(e, x, n, rois.data(), n_rois, sample_rate, flow_khz, fhigh_khz, opt->hop_percent, 1, &t, total, xf.data());
+    // the samples of the regions that get the automatic high-pass land here; calloc leaves every other page untouched
+    struct Freer { void operator()(float *p) const { std::free(p); } };
+    std::unique_ptr<float, Freer> xf_own((float *)std::calloc(n ? n : 1, sizeof(float)));
+    float *xf = xf_own.get();
+    if (!xf) return fail(SONO_ENOMEM, "sono_process_full_file: cannot allocate the filtered recording");
+    lap("merge, tables");
+    rc = sono_analyze_rois(e, x, n, rois.data(), n_rois, sample_rate, flow_khz, fhigh_khz, opt->hop_percent, 1, &t, total, xf);
     if (rc) return rc;
+    lap("region analysis (GPU)");
     // framing (js:677-794), measurement (js:797) and what follows it (js:802-827)
     std::vector<sono_roi_call> framed(total / 2 + n_rois + 1);
     size_t n_calls = 0;
-    rc = sono_frame_roi_calls(xf.data(), n, rois.data(), n_rois, &t, sample_rate, N, opt->call_threshold_db,
+    rc = sono_frame_roi_calls(x, xf, n, rois.data(), n_rois, &t, sample_rate, N, opt->call_threshold_db,
                               opt->min_call_duration_ms, framed.data(), framed.size(), &n_calls);
     if (rc) return rc;
+    lap("framing (host)");
     std::vector<sono_call_measurement> meas(n_calls + 1);
-    rc = sono_measure_roi_calls(e, xf.data(), n, rois.data(), n_rois, &t, framed.data(), n_calls, sample_rate, flow_khz, fhigh_khz,
+    rc = sono_measure_roi_calls(e, x, xf, n, rois.data(), n_rois, &t, framed.data(), n_calls, sample_rate, flow_khz, fhigh_khz,
                                 opt->hop_percent, opt->debug_mode, opt->threads, meas.data());
     if (rc) return rc;
+    lap("measurement (GPU + threads)");
     std::vector<sono_full_file_call> &kept = e->full_file_calls;
     for (size_t i = 0; i < n_calls; ++i) {
         sono_call_measurement &m = meas[i];

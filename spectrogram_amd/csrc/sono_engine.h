@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -37,6 +38,22 @@ struct DevBuf {
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// Host staging memory that grows and is kept: fresh pages cost a fault each on first touch, so the large
+// per-call staging areas of the whole-file passes are reused instead of allocated per call.
+struct HostBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool reserve(size_t bytes)
+    {
+        if (bytes <= cap) return true;
+        std::free(p);
+        p = std::malloc(bytes);
+        cap = p ? bytes : 0;
+        return p != nullptr;
+    }
+    void release() { std::free(p); p = nullptr; cap = 0; }
 };
 
 struct Tables {
@@ -88,6 +105,7 @@ struct sono_engine {
     sono::DevBuf d_in, d_out, d_peak_bin, d_peak_mag, d_gmax, d_mags, d_bank;
     // device scratch of the detector front end (sono_capi_detect.hip)
     sono::DevBuf d_db, d_flags, d_edges, d_runs, d_count, d_select_tmp;
+    sono::HostBuf h_in, h_out;              // staging of the whole-file passes (packed samples; records / dB matrices)
     // Tables of ragged-batch launches.  A launch returns before its kernel has run, so its tables must stay
     // untouched until then: two slots are used in turn, each guarded by an event recorded behind its kernel.
     struct RaggedSlot {

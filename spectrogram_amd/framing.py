@@ -261,19 +261,19 @@ def process_full_file_batched(engine, full_audio_data, sample_rate, flow_khz, fh
     ilo, ihi = np.zeros_like(peak_bin), np.zeros_like(peak_bin)
     table = _RoiTable(row0.ctypes.data_as(u64p), _p(peak_db), peak_bin.ctypes.data_as(i32p), _p(left), _p(right),
                       ilo.ctypes.data_as(i32p), ihi.ctypes.data_as(i32p), zonal.ctypes.data_as(dp), _p(hp), 0, 0, 0, 0)
-    xf = x.copy()
+    xf = np.empty_like(x)                                 # receives the high-passed regions, nothing else is touched
     _check(lib().sono_analyze_rois(engine._handle(), _p(x), x.size, rois, n, float(sample_rate), float(flow_khz), float(fhigh_khz),
                                    float(cfg["hopPercent"]), 1, C.byref(table), total, _p(xf)))
     cap = total // 2 + n + 1
     out = (_RoiCall * cap)()
     got = C.c_size_t(0)
-    _check(lib().sono_frame_roi_calls(_p(xf), xf.size, rois, n, C.byref(table), float(sample_rate), n_fft,
+    _check(lib().sono_frame_roi_calls(_p(x), _p(xf), x.size, rois, n, C.byref(table), float(sample_rate), n_fft,
                                       float(cfg["callThreshold_dB"]), float(cfg["minCallDuration_ms"]), out, cap, C.byref(got)))
     calls = []
     if measure:
         from . import CallMeasurement as _Measurement, measure as _ms
         m = (_Measurement * max(got.value, 1))()
-        _check(lib().sono_measure_roi_calls(engine._handle(), _p(xf), xf.size, rois, n, C.byref(table), out, got.value,
+        _check(lib().sono_measure_roi_calls(engine._handle(), _p(x), _p(xf), x.size, rois, n, C.byref(table), out, got.value,
                                             float(sample_rate), float(flow_khz), float(fhigh_khz), float(cfg["hopPercent"]),
                                             int(bool(cfg.get("debugMode", False))), 0, m))
         for i in range(got.value):

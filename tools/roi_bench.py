@@ -42,6 +42,14 @@ def main():
     measured = fr.process_full_file_batched(*margs, measure=True)
     t1 = time.perf_counter()
     print(f"batched + measurement: {len(measured)} calls, {t1 - t0:.2f} s ({seconds / (t1 - t0):.0f} x real time)", flush=True)
+    t0 = time.perf_counter()
+    native = fr.process_full_file_native(*margs)
+    t1 = time.perf_counter()
+    print(f"one library call: {len(native)} calls, {t1 - t0:.2f} s ({seconds / (t1 - t0):.0f} x real time)", flush=True)
+    strip = lambda c: {k: v for k, v in c.items() if k != "zonalNoiseMap"}
+    if not (len(native) == len(measured) and all(a == strip(b) for a, b in zip(native, measured))):
+        print("one library call: DIFFERENT", flush=True)
+        sys.exit(1)
     if "--skip-single" not in sys.argv:
         t0 = time.perf_counter()
         single = fr.process_full_file(*margs, measure=True)
