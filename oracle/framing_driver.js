@@ -41,6 +41,13 @@ const names = ['fastScanSegmentsWasm', 'mergeAndPadSegments', 'generateSpectrogr
   'findOptimalLowFrequencyThreshold', 'findOptimalHighFrequencyThreshold', 'calculateBandwidth'];
 const fns = {};
 for (const n of names) fns[n] = method(n);
+// CallTypeClassifier.classify (batCallDetector.js:48-56), a static method
+const classifyCall = (() => {
+  const m = /\n  static classify\(call\) \{/.exec(src);
+  let i = m.index + m[0].length, depth = 1; const start = i;
+  for (; i < src.length && depth > 0; i++) { if (src[i] === '{') depth++; else if (src[i] === '}') depth--; }
+  return new Function('call', src.slice(start, i - 1));
+})();
 fns.detectCalls = method('detectCalls', ['audioData', 'sampleRate', 'flowKHz', 'fhighKHz', 'options']);
 // STEP 0 and STEP 0.5 of measureFrequencyParameters (peak bin, parabolic peak frequency, peak time; rejection of
 // vertical clicks by the peak frame's instantaneous bandwidth): the method's text up to the comment that opens
@@ -134,7 +141,7 @@ async function run() {
     BatCall.prototype.calculateBandwidth = function () {          // BatCall.calculateBandwidth (batCallDetector.js:166-170), run as text below
       fns.calculateBandwidth.call(this);
     };
-    const CallTypeClassifier = { classify: () => 'NA' };
+    const CallTypeClassifier = { classify: c.real_measure ? classifyCall : () => 'NA' };
     // a method whose text refers to BatCall and CallTypeClassifier as free identifiers gets them as leading parameters
     const scoped = (name, argNames) => {
       const m = new RegExp('\\n  async ' + name + '\\(([^)]*)\\) \\{').exec(src);
@@ -182,6 +189,17 @@ async function run() {
       emit(c.name, 'discarded', f64(captured.map((k) => k.discarded)));
       emit(c.name, 'zonal_first', captured.length ? captured[0].zonal : new Float64Array(0));
       emit(c.name, 'measured_frames', f64(captured.map((k) => k.frames)));
+    } else if (c.kind === 'calls_measured') {
+      // the whole detectCalls: measurement stage, classifier and SNR filter loop as the reference has them
+      const detectCalls = scoped('detectCalls', ['audioData', 'sampleRate', 'flowKHz', 'fhighKHz', 'options']);
+      let noise = null;
+      if (c.noise_len > 0) noise = fns.generateSpectrogramWasm.call(self, inputs.subarray(c.noise_off, c.noise_off + c.noise_len), c.sr, c.flow_khz, c.fhigh_khz);
+      const types = ['CF', 'FM', 'CF-FM'], qualities = ['Very Poor', 'Poor', 'Normal', 'Good', 'Excellent'];
+      for (const skip of [false, true]) {
+        const calls = await detectCalls.call(self, BatCall, CallTypeClassifier, x, c.sr, c.flow_khz, c.fhigh_khz, { skipSNR: skip, noiseSpectrogram: noise });
+        emit(c.name, skip ? 'measured_skip_snr' : 'measured', f64([].concat(...calls.map((k) => [...callRow(k), k.noiseFloor_dB,
+          k.isDiscarded ? 1 : 0, types.indexOf(k.callType), qualities.indexOf(k.quality), k.Flow, k.Fhigh === null ? NaN : k.Fhigh]))));
+      }
     } else if (c.kind === 'calls') {
       const detectCalls = scoped('detectCalls', ['audioData', 'sampleRate', 'flowKHz', 'fhighKHz', 'options']);
       let noise = null;

@@ -78,6 +78,12 @@ def build_cases():
     add("loud_noise_only", "calls", 0.3 * white(6000, 68, 1.0), sr, call_thr=-3.0)
     add("pulses500k_512", "calls", pulse(15000, 500000, 69, 4000, 3.5, 110000, 50000, 0.5, tail_db=-26.0), 500000, fft=512,
         flow=20.0, fhigh=150.0, hop_percent=6.25)
+    # --- the whole detectCalls (measurement stage, classifier, SNR loop) on the same signals, debug mode on
+    for nm, sig, kw in (("one_pulse", a, dict(flow=20.0, fhigh=100.0)), ("pulse_with_echo", b, dict(flow=20.0, fhigh=100.0)),
+                        ("three_pulses_min2ms", c, dict(flow=20.0, fhigh=100.0, min_ms=2.0, hop_percent=6.25)),
+                        ("pulse_at_start_ext_noise", d, dict(flow=15.0, fhigh=110.0, noise=0.1 * white(6000, 67, 1.0), hop_percent=6.25)),
+                        ("loud_noise_only", 0.3 * white(6000, 68, 1.0), dict(call_thr=-3.0))):
+        add("detect_" + nm, "calls_measured", sig, sr, real_measure=1, debug_mode=1, **kw)
     # --- processFullFile: fast scan -> ROIs -> auto high-pass -> segments -> strongest-first 30 ms echo filter -> framing
     n = 120000
     ff = 0.01 * white(n, 80, 1.0)
@@ -187,6 +193,9 @@ def main():
         n = c["name"]
         if c["kind"] in ("fullfile", "fullfile_measured"):
             print(f"  {n}: calls {arrays[n + '/calls'].reshape(-1, 5).round(5).tolist()} threw {arrays[n + '/measure_threw'].tolist()}")
+        elif c["kind"] == "calls_measured":
+            for key in ("measured", "measured_skip_snr"):
+                print(f"  {n}: {key} {arrays[n + '/' + key].reshape(-1, 37)[:, [2, 3, 6, 15, 25, 28, 31, 32, 33, 34]].round(2).tolist()}")
         elif c["kind"] == "calls":
             print(f"  {n}: calls {arrays[n + '/calls'].reshape(-1, 6).round(5).tolist()} zonal {arrays[n + '/zonal'].tolist()}")
         elif c["kind"] == "measure":

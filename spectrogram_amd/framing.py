@@ -17,7 +17,7 @@ from . import detector as _det
 
 __all__ = ["calculate_zonal_noise_floors", "db_percentile", "refine_end_using_oscillogram", "frame_calls",
            "scan_spectrum_for_frequency", "calculate_auto_highpass_filter_freq", "apply_highpass_filter",
-           "savitzky_golay", "detect_calls_framing", "process_full_file", "process_full_file_batched", "process_full_file_native",
+           "savitzky_golay", "detect_calls_framing", "detect_calls", "process_full_file", "process_full_file_batched", "process_full_file_native",
            "calculate_rms_based_snr",
            "DEFAULT_FRAMING_CONFIG"]
 
@@ -136,6 +136,54 @@ def detect_calls_framing(engine, audio_data, sample_rate, flow_khz, fhigh_khz, c
     for c in calls:
         c["noiseFloor_dB"] = floor
     return calls, zonal, floor, sp
+
+
+def detect_calls(engine, audio_data, sample_rate, flow_khz, fhigh_khz, options=None, config=None):
+    """detectCalls (batCallDetector.js:1070-1289), whole: framing, the measurement stage on every call, classification,
+    and the noise-floor / SNR loop.  options: {'skipSNR': False, 'noiseSpectrogram': None} as in the reference;
+    config['debugMode'] is the detector's debug switch (outside it the reference raises on some calls:
+    measure.ReferenceThrows).  -> list of call dicts with the reference's BatCall fields.  Unlike processFullFile the
+    reference does not look at isDiscarded here: such calls stay in the list, flagged, with null frequencies."""
+    from . import measure as _ms
+    opt = dict({"skipSNR": False, "noiseSpectrogram": None}, **(options or {}))
+    cfg = dict(DEFAULT_FRAMING_CONFIG, **(config or {}))
+    framed, zonal, floor, sp = detect_calls_framing(engine, audio_data, sample_rate, flow_khz, fhigh_khz, cfg, opt["noiseSpectrogram"])
+    if not framed:
+        return []
+    p, tf, fb = sp["powerMatrix"], sp["timeFrames"], sp["freqBins"]
+    calls = []
+    for k in framed:                                                                                   # js:1139-1218
+        f0, f1 = k["startFrame"], k["endFrame"]
+        call = {"spectrogram": p[f0:f1 + 1], "timeFrames": tf[f0:f1 + 2], "startTime_s": k["startTime_s"],
+                "endTime_s": k["endTime_s"], "duration_ms": k["duration_ms"]}
+        _ms.measure_frequency_parameters(call, flow_khz, fhigh_khz, fb, sp["freqResolution"], zonal, cfg.get("debugMode", False))
+        call["Flow"] = (call["lowFreq_kHz"] or 0.0) * 1000                                             # null * 1000 is 0 in JavaScript
+        call["Fhigh"] = call["highFreq_kHz"]
+        call["callType"] = _ms.classify_call_type(call)
+        call.update(startFrame=f0, endFrame=f1)
+        calls.append(call)
+    kept = []
+    for call in calls:                                                                                 # js:1238-1286
+        if call["peakPower_dB"] is None:
+            continue
+        call["noiseFloor_dB"] = floor
+        spectral = call["peakPower_dB"] - floor
+        if opt["skipSNR"]:
+            call.update(snr_dB=spectral, snrMechanism="Skipped (Filtered Pass)", quality=_ms.get_quality_rating(spectral))
+            kept.append(call)
+            continue
+        box = {"lowFreq_kHz": call["lowFreq_kHz"] or 0.0, "highFreq_kHz": call["highFreq_kHz"] or 0.0}
+        r = calculate_rms_based_snr(engine, box, call["spectrogram"], fb, 0, call["endFrameIdx_forLowFreq"] or 0, flow_khz, fhigh_khz,
+                                    opt["noiseSpectrogram"])
+        if r["snr_dB"] is not None and math.isfinite(r["snr_dB"]):
+            call.update(snr_dB=r["snr_dB"], snrMechanism=r["mechanism"])
+        else:
+            call.update(snr_dB=spectral, snrMechanism="RMS-based (2025) - Calculation failed fallback")
+        call["quality"] = _ms.get_quality_rating(call["snr_dB"])
+        if spectral < -20:                                                                             # js:1280-1283
+            continue
+        kept.append(call)
+    return kept
 
 
 def _measure_framed(power, tf, fb, framed, flow_khz, fhigh_khz, freq_res, zonal, offset, debug_mode):

@@ -153,6 +153,39 @@ _TOL = {"peakFreq_kHz": 2e-3, "peakPower_dB": 2e-3, "highFreq_kHz": 5e-3, "start
         "bandwidth_kHz": 1e-2, "snr_dB": 2e-3, "characteristicFreq_kHz": 5e-3}
 
 
+def test_whole_detect_calls_matches_the_reference(golden):
+    g, meta = golden
+    types, qualities = ["CF", "FM", "CF-FM"], ["Very Poor", "Poor", "Normal", "Good", "Excellent"]
+    seen = discarded = 0
+    for c in cases(meta, "calls_measured"):
+        n = c["name"]
+        e = sa.SpectrogramEngine(c["fft"], c["window"])
+        x = g[n + "/x"]
+        noise = None
+        if n + "/noise" in g.files:
+            noise = det.generate_spectrogram(e, g[n + "/noise"], c["sr"], c["flow_khz"], c["fhigh_khz"], c["hop_percent"])
+        cfg = {"hopPercent": c["hop_percent"], "callThreshold_dB": c["call_threshold_db"], "minCallDuration_ms": c["min_call_duration_ms"],
+               "debugMode": True}
+        for skip, key in ((False, "measured"), (True, "measured_skip_snr")):
+            calls = fr.detect_calls(e, x, c["sr"], c["flow_khz"], c["fhigh_khz"], {"skipSNR": skip, "noiseSpectrogram": noise}, cfg)
+            want = g[n + "/" + key].reshape(-1, len(_MEASURED) + 6)
+            assert len(calls) == len(want), (n, key, len(calls), len(want))
+            for k, w in zip(calls, want):
+                for name, ref in zip(_MEASURED, w):
+                    got = k.get(name)
+                    if ref != ref:
+                        assert got is None, (n, name, got)
+                    else:
+                        assert abs(got - ref) <= _TOL.get(name, 1e-9), (n, key, name, got, ref)
+                assert abs(k["noiseFloor_dB"] - w[31]) < 2e-3 and bool(k.get("isDiscarded")) == bool(w[32])
+                assert k["callType"] == types[int(w[33])] and k["quality"] == qualities[int(w[34])]
+                assert abs(k["Flow"] - w[35]) <= 5.0 and (k["Fhigh"] is None if w[36] != w[36] else abs(k["Fhigh"] - w[36]) <= 5e-3)
+                seen += 1
+                discarded += bool(w[32])
+        e.free()
+    assert seen >= 14 and discarded >= 2
+
+
 def test_full_file_with_the_measurement_stage(golden):
     from spectrogram_amd import measure as ms, sharding as sh
     g, meta = golden
