@@ -172,3 +172,41 @@ def test_full_file_with_the_measurement_stage(golden):
             else:
                 assert abs(got - ref) <= _TOL.get(name, 1e-9), (name, got, ref)
     assert [call["callType"] for call in calls].count("FM") >= 1 and all(call["quality"] for call in calls)
+
+
+def test_measurement_rejects_bad_arguments():
+    import ctypes as C
+    import spectrogram_amd as sa
+    from spectrogram_amd import CallMatrix, CallMeasurement
+    L = sa.lib()
+    db = np.zeros((4, 8), np.float32)
+    fb = (np.arange(8) * 1000).astype(np.float32)
+    tf = np.arange(5) * 1e-3
+    fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+    m = CallMatrix(db.ctypes.data_as(fp), 4, 8, fb.ctypes.data_as(fp), tf.ctypes.data_as(dp), None, 0, 0, 0)
+    r = CallMeasurement()
+    assert L.sono_measure_frequency_parameters(C.byref(m), 5, 100.0, 1000.0, None) == sa.SONO_EINVAL
+    assert L.sono_measure_frequency_parameters(None, 5, 100.0, 1000.0, C.byref(r)) == sa.SONO_EINVAL
+    assert L.sono_measure_frequency_parameters(C.byref(m), 3, 100.0, 1000.0, C.byref(r)) == sa.SONO_EINVAL       # fewer times than frames
+    assert b"fewer times" in L.sono_last_error()
+    assert L.sono_measure_frequency_parameters(C.byref(m), 5, 100.0, 0.0, C.byref(r)) == sa.SONO_EINVAL
+    m.time_frames = None
+    assert L.sono_measure_frequency_parameters(C.byref(m), 5, 100.0, 1000.0, C.byref(r)) == sa.SONO_EINVAL
+    # the whole-file entry points check their handles before anything touches a GPU
+    assert L.sono_process_full_file(None, None, 0, 384000.0, 10.0, 100.0, None, None, 0, None) == sa.SONO_EINVAL
+    assert L.sono_full_file_results(None, None, 0, None) == sa.SONO_EINVAL
+    assert L.sono_measure_roi_calls(None, None, None, 0, None, 0, None, None, 0, 384000.0, 10.0, 100.0, 3.125, 0, 0, None) == sa.SONO_EINVAL
+
+
+def test_flat_call_shows_the_smoothing_edge_quirk():
+    # Every bin equal.  The reference's Savitzky-Golay divides by the full coefficient sum at the edges too
+    # (batCallDetector.js:1625-1636), so a constant contour comes out as 14.86, 21.71, 20, 20, ... and the steep fake
+    # drop-and-recover at the start is taken for a knee at contour point 2.
+    db = np.full((12, 16), -50.0, np.float32)
+    fb = (20000 + np.arange(16) * 1000).astype(np.float32)
+    tf = (np.arange(13) * 32 + 512) / 384000
+    call = {"spectrogram": db, "timeFrames": tf, "startTime_s": float(tf[0]), "endTime_s": float(tf[12]), "duration_ms": 1.0}
+    ms.measure_frequency_parameters(call, 20, 36, fb, 1000.0, None, True)
+    assert call["peakPower_dB"] == -50.0 and call["peakFreq_kHz"] == 20.0
+    assert call["kneeFrameIdx"] == 2 and call["kneeFreq_kHz"] == 20.0 and call["heelFreq_kHz"] is None
+    assert call["bandwidth_kHz"] == 15.0 and call["startFreq_ms"] == 0.0 and call["endFrameIdx_forLowFreq"] == 11
