@@ -51,7 +51,7 @@ struct StftArgs {
     float *out_power;             // MODE_POWER
     float inv_n;                  // 1/N: |2X| * inv_n = |X| * 2/N (lib.rs:150)
     float q_a, q_c;               // code = trunc(q_a * log2(max(|2X|^2, q_floor)) + q_c), saturated to [0,255]
-    float q_floor;
+    float q_floor;                // 0 = no floor (it would not change any code, see make_quant)
     unsigned int band_lo, band_hi;   // MODE_BAND: bins band_lo..band_hi (inclusive, band_hi < N/2)
     double band_target;              // MODE_BAND: a frame is active iff its band energy > band_target
     uint8_t *band_active;            // MODE_BAND: one flag per frame
@@ -89,6 +89,11 @@ inline Quant make_quant(unsigned int N, float gain_db, float range_db)
     q.c = (float)((-20.0 * std::log10((double)N) + (double)gain_db + (double)range_db) * k);
     const double fl = 1e-10 * (double)N;
     q.floor = (float)(fl * fl);
+    // Where the floor's own code is 0 (the defaults: the floor lies 100 dB below the lowest
+    // coded level) the clamp cannot change a code: log2 of anything below the floor, down to
+    // log2(0) = -inf, saturates to 0 as well.  floor = 0 tells the kernels to leave it out.
+    const double floor_code = (double)q.a * std::log2((double)q.floor) + (double)q.c;
+    if (q.a > 0.0f && floor_code < -1.0) q.floor = 0.0f;
     return q;
 }
 
@@ -124,9 +129,10 @@ SONO_HD float max_of_4(float a, float b, float c, float d)
 
 // u8 code of one bin from p = |2X|^2.  Float -> int conversion truncates toward
 // zero like Rust's `as u8`; the clamps make the saturation explicit.
+template <bool FLOOR = true>
 SONO_HD unsigned int quantise(float p, float q_a, float q_c, float q_floor)
 {
-    const float pf = max_nonneg(p, q_floor);
+    const float pf = FLOOR ? max_nonneg(p, q_floor) : p;
     float v = q_a * fast_log2(pf) + q_c;
 #if defined(__HIP_DEVICE_COMPILE__)
     v = __builtin_amdgcn_fmed3f(v, 0.0f, 255.0f);   // one v_med3_f32; a NaN comes out as 0

@@ -98,7 +98,8 @@ __device__ __forceinline__ float column_max(float v)
 }
 
 // RAGGED: streams of different lengths, located through TileIter's tables.
-template <int LOG_R1, int LOG_R2, int MODE, bool RAGGED>
+// HOPQ: 1 / 2 = the launch's hop is N/4 / N/2 (frame B reuses frame A's loads), 0 = any hop.
+template <int LOG_R1, int LOG_R2, int MODE, bool RAGGED, int HOPQ>
 __global__ __launch_bounds__(64 * Occupancy<LOG_R2>::kWavesPerBlock, Occupancy<LOG_R2>::kWavesPerSimd)
 void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *tw_rows)
 {
@@ -139,7 +140,7 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
     const unsigned int blocks_in_part = (gridDim.x - part + parts - 1) / parts;
     const unsigned long long t_first = it.n_tiles * part / parts;
     const unsigned long long t_count = it.n_tiles * (part + 1) / parts - t_first;
-    tile::TileLane<LOG_R1, LOG_R2, MODE> L(a, lane);
+    tile::TileLane<LOG_R1, LOG_R2, MODE, HOPQ> L(a, lane);
     auto claim = [&]() -> unsigned long long {          // -> index of the claimed tile inside the range
         unsigned int c = 0;
         if (lane == 0) c = atomicAdd(&s_next, 1u);
@@ -179,7 +180,7 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
             wave_lds_fence();
             STAMP(2);
         }
-        L.pass2_power(re, im, L.pass2_scale(meta), img);
+        L.pass2_power(re, im, img);
         wave_lds_fence();
         STAMP(3);
         if constexpr (MODE == MODE_BAND) {
@@ -187,7 +188,8 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
             for (int o = G::HALF / 2; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
             L.band_emit(tr, e);
         } else {
-            L.epilogue(tr, img, meta, s_zero, peak_slot, LdsMax64());
+            if (MODE == MODE_U8 && a.q_floor > 0.0f) L.template epilogue<true>(tr, img, meta, s_zero, peak_slot, LdsMax64());
+            else L.template epilogue<false>(tr, img, meta, s_zero, peak_slot, LdsMax64());
         }
         if (MODE == MODE_U8) {
             wave_lds_fence();
@@ -247,10 +249,17 @@ hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, const RaggedPlan
     const unsigned long long resident = (unsigned long long)cus * kBlocksPerCU;
     if (blocks > resident) blocks = resident;
     const dim3 grid((unsigned int)blocks), block(64 * kWavesPerBlock);
-    if (plan)
-        hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, true>), grid, block, 0, stream, a, it, tw_rows);
-    else
-        hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false>), grid, block, 0, stream, a, it, tw_rows);
+    // The hops that let frame B reuse frame A's loads: a quarter frame (75 % overlap) for
+    // the row and magnitude modes, half a frame (the fast scan's 50 %) for the band mode.
+    constexpr int kHopQ = MODE == MODE_BAND ? 2 : 1;
+    const bool q = a.hop * (kHopQ == 2 ? 2u : 4u) == (unsigned int)G::N;
+    if (plan) {
+        if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, true, kHopQ>), grid, block, 0, stream, a, it, tw_rows);
+        else hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, true, 0>), grid, block, 0, stream, a, it, tw_rows);
+    } else {
+        if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, kHopQ>), grid, block, 0, stream, a, it, tw_rows);
+        else hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, 0>), grid, block, 0, stream, a, it, tw_rows);
+    }
     return hipGetLastError();
 }
 

@@ -34,11 +34,16 @@
 //   scale   A + iB in one DFT leaks rounding noise of the louder frame into the
 //           quieter one (about 1e-7 of the LOUDER frame's level).  Frame B is
 //           therefore multiplied by the power of two that brings its largest
-//           sample to A's binade before pass 1 and divided back right after the
-//           separation (both exact); the shared rows stay scaled through pass 2
-//           and their |2X_B|^2 is corrected by the squared factor.  A frame of
+//           sample to A's binade before pass 1 (exact) and stays scaled through
+//           both passes and in the power image; the epilogue undoes it where
+//           that is free: as a per-frame term in the dB constant, in the 1/N
+//           factor of the magnitude, and once on the frame's peak.  A frame of
 //           exact zeros must come out as exact zeros: the epilogue reads such a
 //           frame's bins from a row of zeros instead of the power image.
+//
+//   hop     With hop = N/4 or N/2 (HOPQ = 1, 2) frame B's first samples ARE frame
+//           A's samples R1/4 (R1/2) rows further down the same column, so only
+//           B's last R1/4 (R1/2) rows are loaded; HOPQ = 0 loads both frames whole.
 //
 // Everything is __host__ __device__: tests/host_emul runs the passes lane by
 // lane against an ordinary array standing in for LDS.
@@ -139,11 +144,12 @@ SONO_HD void bfly(float &ar, float &ai, float &br, float &bi)
 
 // In-place N-point DFT (N = 2..64).  Input in bit-reversed order
 // (re[i] = x[bitrev(i)]), output in natural order.
-template <int N>
+// FIRST = 2: the caller has already done the first stage (pairs 2j, 2j+1).
+template <int N, int FIRST = 1>
 SONO_HD void dft_bitrev_in(float (&re)[N], float (&im)[N])
 {
     constexpr int L = ilog2(N);
-    static_for<1, L + 1>([&](auto s_) {
+    static_for<FIRST, L + 1>([&](auto s_) {
         constexpr int len = 1 << decltype(s_)::value, half = len / 2;
         static_for<0, N / len>([&](auto b_) {
             constexpr int base = decltype(b_)::value * len;
@@ -195,12 +201,15 @@ SONO_HD constexpr int image_swizzle(int row) { return LOG_R2 == 5 ? ((row >> 1) 
 template <int LOG_R2>
 SONO_HD constexpr int image_index(int row, int col) { return (row << LOG_R2) + (col ^ image_swizzle<LOG_R2>(row)); }
 
-// Per-wave, per-tile side information handed from pass 1 to the later passes
-// through LDS: [pair q] = g^2, the factor that undoes frame B's scaling in
-// |2X_B|^2 of the pair's shared rows; [kMetaNonZero + frame] = 1 if the frame has
-// a non-zero sample, else 0.
-constexpr int kMetaNonZero = 8;
-constexpr int kMetaFloats = 24;
+// Per-wave, per-tile side information handed from pass 1 to the epilogue through
+// LDS, one entry per frame of the tile: [kMetaGain + frame] = the power of two
+// that undoes the frame's scaling in |2X| (1 for a frame A); [kMetaShift + frame]
+// = 2*log2 of it, as a float; [kMetaNonZero + frame] = 1 if the frame has a
+// non-zero sample, else 0.
+constexpr int kMetaGain = 0;
+constexpr int kMetaNonZero = 16;
+constexpr int kMetaShift = 32;
+constexpr int kMetaFloats = 48;
 
 #if defined(__HIP_DEVICE_COMPILE__)
 SONO_HD int float_exponent(float v) { return __builtin_amdgcn_frexp_expf(v); }
@@ -256,13 +265,17 @@ SONO_HD TileRef locate(const StftArgs &a, const TileIter &it, unsigned long long
 }
 
 // ---- one lane of one wave ------------------------------------------------------
-template <int LOG_R1, int LOG_R2, int MODE>
+// HOPQ: 0 = any hop; 1 = the hop is N/4; 2 = the hop is N/2 (see "hop" above).
+template <int LOG_R1, int LOG_R2, int MODE, int HOPQ = 0>
 struct TileLane {
     using G = Geo<LOG_R1, LOG_R2>;
     static constexpr int R2 = G::R2;
+    // Rows by which frame B's column lies below frame A's (0: not known at compile time).
+    static constexpr int SHIFT = HOPQ == 1 ? G::R1 / 4 : HOPQ == 2 ? G::R1 / 2 : 0;
+    static constexpr int OWN_B = SHIFT ? G::R1 - SHIFT : 0;   // first row of frame B that is loaded for B itself
     const StftArgs &a;
     int lane;
-    float xa[R2], xb[R2];              // samples of frames A / B of job jj at [jj*R1 + n1]
+    float xa[R2], xb[R2];              // samples of frames A / B of job jj at [jj*R1 + n1] (B: rows >= OWN_B only)
     float run_max;                     // running maximum of |2X|^2 over every frame this lane has finished (MODE_U8)
 
     SONO_HD TileLane(const StftArgs &args, int lane_) : a(args), lane(lane_), run_max(0.0f) {}
@@ -271,8 +284,17 @@ struct TileLane {
     SONO_HD int col() const { return lane & (R2 - 1); }
     SONO_HD int hgroup() const { return lane >> LOG_R2; }
 
+    // Sample (row N1, this lane's column) of frame B of job JJ.
+    template <int JJ, int N1>
+    SONO_HD float b_at() const
+    {
+        if constexpr (N1 < OWN_B) return xa[JJ * G::R1 + N1 + SHIFT];
+        else return xb[JJ * G::R1 + N1];
+    }
+
     // Issues the loads of `tile` (pass-1 lane layout).  Frames past the end of a
-    // stream re-read the stream's frame 0; their results are never stored.
+    // stream re-read the stream's frame 0 (with SHIFT, a frame B past the end is
+    // made of A's rows and frame 0's last rows); their results are never stored.
     SONO_HD void load(const TileRef &tr)
     {
         const unsigned int j = tr.j;
@@ -288,7 +310,7 @@ struct TileLane {
             static_for<0, G::R1>([&](auto n_) {
                 constexpr int n1 = decltype(n_)::value;
                 xa[jj * G::R1 + n1] = pa[R2 * n1];
-                xb[jj * G::R1 + n1] = pb[R2 * n1];
+                if constexpr (n1 >= OWN_B) xb[jj * G::R1 + n1] = pb[R2 * n1];
             });
         });
     }
@@ -299,22 +321,37 @@ struct TileLane {
         static_for<0, G::JPL>([&](auto jj_) {
             constexpr int jj = decltype(jj_)::value;
             float va = 0.0f, vb = 0.0f;
-            static_for<0, G::R1 / 2>([&](auto n_) {
-                constexpr int n1 = 2 * decltype(n_)::value;
-                va = fmaxf(fmaxf(fabsf(xa[jj * G::R1 + n1]), fabsf(xa[jj * G::R1 + n1 + 1])), va);
-                vb = fmaxf(fmaxf(fabsf(xb[jj * G::R1 + n1]), fabsf(xb[jj * G::R1 + n1 + 1])), vb);
-            });
+            if constexpr (SHIFT != 0) {
+                float vs = 0.0f;          // the rows both frames hold
+                static_for<0, OWN_B / 2>([&](auto n_) {
+                    constexpr int n1 = SHIFT + 2 * decltype(n_)::value;
+                    vs = fmaxf(fmaxf(fabsf(xa[jj * G::R1 + n1]), fabsf(xa[jj * G::R1 + n1 + 1])), vs);
+                });
+                static_for<0, SHIFT / 2>([&](auto n_) {
+                    constexpr int n1 = 2 * decltype(n_)::value;
+                    va = fmaxf(fmaxf(fabsf(xa[jj * G::R1 + n1]), fabsf(xa[jj * G::R1 + n1 + 1])), va);
+                    vb = fmaxf(fmaxf(fabsf(xb[jj * G::R1 + OWN_B + n1]), fabsf(xb[jj * G::R1 + OWN_B + n1 + 1])), vb);
+                });
+                va = fmaxf(va, vs);
+                vb = fmaxf(vb, vs);
+            } else {
+                static_for<0, G::R1 / 2>([&](auto n_) {
+                    constexpr int n1 = 2 * decltype(n_)::value;
+                    va = fmaxf(fmaxf(fabsf(xa[jj * G::R1 + n1]), fabsf(xa[jj * G::R1 + n1 + 1])), va);
+                    vb = fmaxf(fmaxf(fabsf(xb[jj * G::R1 + n1]), fabsf(xb[jj * G::R1 + n1 + 1])), vb);
+                });
+            }
             ma[jj] = va;
             mb[jj] = vb;
         });
     }
 
     // Pass 1: scale B, window, DFT-R1 of A + iB, conjugate-symmetric separation,
-    // unscale B, twiddle.  ma / mb = largest |sample| of frames A / B of each pair
-    // over all R2 columns.  Leaves the R2 row values of the lane (rows rho of its JPL
-    // pairs, column n2) in rr / ri at [jj*R1 + rho].  win = the N window values;
-    // tw = the twiddle table described at Geo::TW_FOLD.  The lane of column 0
-    // records the pair's side information in `meta`.
+    // twiddle.  ma / mb = largest |sample| of frames A / B of each pair over all R2
+    // columns.  Leaves the R2 row values of the lane (rows rho of its JPL pairs,
+    // column n2) in rr / ri at [jj*R1 + rho]; frame B's rows stay scaled.  win = the N
+    // window values; tw = the twiddle table described at Geo::TW_FOLD.  The lane of
+    // column 0 records the pair's side information in `meta`.
     SONO_HD void pass1(const float *win, const float2 *tw, const float (&ma)[G::JPL], const float (&mb)[G::JPL],
                        float (&rr)[R2], float (&ri)[R2], float *meta) const
     {
@@ -322,29 +359,48 @@ struct TileLane {
         static_for<0, G::JPL>([&](auto jj_) {
             constexpr int jj = decltype(jj_)::value;
             int d = (ma[jj] > 0.0f && mb[jj] > 0.0f) ? float_exponent(ma[jj]) - float_exponent(mb[jj]) : 0;
-            d = d > 60 ? 60 : d < -60 ? -60 : d;
-            const float sb = pow2(d), gb = pow2(-d);
+            d = d > 40 ? 40 : d < -40 ? -40 : d;
+            const float sb = pow2(d);
             if (n2 == 0) {
                 const int q = h * G::JPL + jj;
-                meta[q] = gb * gb;
+                meta[kMetaGain + 2 * q] = 1.0f;
+                meta[kMetaGain + 2 * q + 1] = pow2(-d);
+                meta[kMetaShift + 2 * q] = 0.0f;
+                meta[kMetaShift + 2 * q + 1] = (float)(-2 * d);
                 meta[kMetaNonZero + 2 * q] = ma[jj] > 0.0f ? 1.0f : 0.0f;
                 meta[kMetaNonZero + 2 * q + 1] = mb[jj] > 0.0f ? 1.0f : 0.0f;
             }
+            // Window and the DFT's first stage in one go: a butterfly's two outputs are
+            // a +- b with a = x[n1]*w[n1] and b = x[n1 + R1/2]*w[n1 + R1/2] fused into the sum.
             float re[G::R1], im[G::R1];
-            static_for<0, G::R1>([&](auto i_) {
-                constexpr int i = decltype(i_)::value, n1 = bitrev(i, LOG_R1);
-                const float w = win[R2 * n1 + n2];
-                re[i] = xa[jj * G::R1 + n1] * w;
-                im[i] = (xb[jj * G::R1 + n1] * sb) * w;
+            static_for<0, G::HALF>([&](auto j_) {
+                constexpr int i = 2 * decltype(j_)::value, na = bitrev(i, LOG_R1), nb = na + G::HALF;
+                static_assert(bitrev(i + 1, LOG_R1) == nb, "stage-1 partner");
+                const float wa = win[R2 * na + n2], wb = win[R2 * nb + n2];
+#ifdef SONO_UNFUSED_WINDOW
+                const float a0 = xa[jj * G::R1 + na] * wa, a1 = xa[jj * G::R1 + nb] * wb;
+                re[i] = a0 + a1;
+                re[i + 1] = a0 - a1;
+                const float b0 = (b_at<jj, na>() * sb) * wa, b1 = (b_at<jj, nb>() * sb) * wb;
+                im[i] = b0 + b1;
+                im[i + 1] = b0 - b1;
+#else
+                const float a0 = xa[jj * G::R1 + na] * wa, a1 = xa[jj * G::R1 + nb];
+                re[i] = __builtin_fmaf(a1, wb, a0);
+                re[i + 1] = __builtin_fmaf(-a1, wb, a0);
+                const float b0 = (b_at<jj, na>() * sb) * wa, b1 = b_at<jj, nb>() * sb;
+                im[i] = __builtin_fmaf(b1, wb, b0);
+                im[i + 1] = __builtin_fmaf(-b1, wb, b0);
+#endif
             });
-            dft_bitrev_in<G::R1>(re, im);
+            dft_bitrev_in<G::R1, 2>(re, im);
             rr[jj * G::R1] = re[0];
             ri[jj * G::R1] = im[0];
             // rows k1 (frame A) and R1/2 + k1 (frame B), twiddled by t = W_N^(n2*k1)
             auto rows = [&](auto k_, const float2 t) {
                 constexpr int k1 = decltype(k_)::value;
                 const float ar = re[k1] + re[G::R1 - k1], ai = im[k1] - im[G::R1 - k1];   // 2 Y_A[k1]
-                const float br = (im[k1] + im[G::R1 - k1]) * gb, bi = (re[G::R1 - k1] - re[k1]) * gb;   // 2 Y_B[k1]
+                const float br = im[k1] + im[G::R1 - k1], bi = re[G::R1 - k1] - re[k1];   // 2 Y_B[k1], scaled
                 rr[jj * G::R1 + k1] = ar * t.x - ai * t.y;
                 ri[jj * G::R1 + k1] = ar * t.y + ai * t.x;
                 rr[jj * G::R1 + G::HALF + k1] = br * t.x - bi * t.y;
@@ -407,13 +463,8 @@ struct TileLane {
     //   |2X_A|^2 = |C[t] + conj C[p]|^2,  |2X_B|^2 = |C[t] - conj C[p]|^2,  p = (R2-t)%R2 or R2-1-t.
     // One instruction stream serves all three kinds: with b = conj C[p] and a
     // per-lane s (0 for frame rows, 1 for shared rows) the two stores are
-    // |C[t] + s b|^2 and g2 |s C[t] - b|^2 (g2 undoes frame B's scaling in a shared
-    // row and is 1 in a frame row).
-    SONO_HD float pass2_scale(const float *meta) const
-    {
-        return (lane & (G::HALF - 1)) == 0 ? meta[lane >> LOG_R1] : 1.0f;
-    }
-    SONO_HD void pass2_power(float (&re)[R2], float (&im)[R2], float g2, float *P) const
+    // |C[t] + s b|^2 and |s C[t] - b|^2.  (Frame B's values carry its scale.)
+    SONO_HD void pass2_power(float (&re)[R2], float (&im)[R2], float *P) const
     {
         dft_bitrev_in<R2>(re, im);
         const int q = lane >> LOG_R1, rho = lane & (G::R1 - 1), k1 = rho & (G::HALF - 1);
@@ -429,15 +480,16 @@ struct TileLane {
             const float er = re[t] + s * br, ei = im[t] - s * bi;
             const float dr = s * re[t] - br, di = s * im[t] + bi;
             row1[G::R1 * t] = er * er + ei * ei;
-            row2[G::R1 * t] = (dr * dr + di * di) * g2;
+            row2[G::R1 * t] = dr * dr + di * di;
         });
     }
 
     // Epilogue: lane (frame, l) owns bins 4l + 2*R1*m + r (m < R2/4, r < 4) of its frame.
     // zero_row = N/2 floats of 0.0, read in place of the power image for an all-zero
     // frame (only where Geo::ZERO_ROW).  `peak_slot` is the LDS word of the lane's
-    // frame (ordering key of its largest |2X|^2).
-    template <typename AtomicMax64>
+    // frame (ordering key of its largest |2X|^2).  FLOOR = false leaves out the
+    // clamp to q_floor (for q_floor = 0).
+    template <bool FLOOR, typename AtomicMax64>
     SONO_HD void epilogue(const TileRef &tr, const float *P, const float *meta,
                           const float *zero_row, unsigned long long *peak_slot, AtomicMax64 atomic_max64)
     {
@@ -446,6 +498,12 @@ struct TileLane {
         const bool valid = f < tr.frames;
         const unsigned long long g = tr.row0 + f;
         const float nz = meta[kMetaNonZero + frame];
+        // The frame's image holds |2X|^2 / gain^2: log2 of it is short by shift =
+        // 2 log2(gain), the magnitude by the factor gain, the floor moves the other way.
+        const float gain = meta[kMetaGain + frame], shift = meta[kMetaShift + frame];
+        const float q_c = a.q_a * shift + a.q_c;
+        const float q_floor = FLOOR ? a.q_floor / (gain * gain) : 0.0f;
+        const float inv_n = a.inv_n * gain;
         const float *row = ((!G::ZERO_ROW || nz != 0.0f) ? P + frame * G::PROW : zero_row) + 4 * l;
         // Peak search: per group of four bins only the group's maximum is compared
         // with the running one (strict >, so the lowest group wins a tie); which of
@@ -472,14 +530,14 @@ struct TileLane {
                 if (!G::ZERO_ROW) { p[0] *= nz; p[1] *= nz; p[2] *= nz; p[3] *= nz; }
                 if (MODE == MODE_MAG) {
                     float4 o;
-                    o.x = fast_sqrt(p[0]) * a.inv_n; o.y = fast_sqrt(p[1]) * a.inv_n;
-                    o.z = fast_sqrt(p[2]) * a.inv_n; o.w = fast_sqrt(p[3]) * a.inv_n;
+                    o.x = fast_sqrt(p[0]) * inv_n; o.y = fast_sqrt(p[1]) * inv_n;
+                    o.z = fast_sqrt(p[2]) * inv_n; o.w = fast_sqrt(p[3]) * inv_n;
                     *(float4 *)(a.out_mag + g * (unsigned long long)G::BINS + k0) = o;
                 } else {
                     unsigned int packed = 0;
                     static_for<0, 4>([&](auto r_) {
                         constexpr int r = decltype(r_)::value;
-                        packed |= quantise(p[r], a.q_a, a.q_c, a.q_floor) << (8 * r);
+                        packed |= quantise<FLOOR>(p[r], a.q_a, q_c, q_floor) << (8 * r);
                     });
                     const float top = max_of_4(p[0], p[1], p[2], p[3]);
                     if (top > best_p) { best_p = top; best_m = m0 + i; }        // false for a NaN
@@ -493,8 +551,9 @@ struct TileLane {
             if (!G::ZERO_ROW) { w[0] *= nz; w[1] *= nz; w[2] *= nz; w[3] *= nz; }
             const int r = w[0] == best_p ? 0 : w[1] == best_p ? 1 : w[2] == best_p ? 2 : 3;
             const unsigned int best_k = best_p > 0.0f ? (unsigned int)(4 * l + 2 * G::R1 * best_m + r) : 0u;
-            run_max = best_p > run_max ? best_p : run_max;
-            atomic_max64(peak_slot, peak_key(best_p, best_k));
+            const float best_true = best_p * (gain * gain);          // |2X|^2 itself
+            run_max = best_true > run_max ? best_true : run_max;
+            atomic_max64(peak_slot, peak_key(best_true, best_k));
         }
     }
 
@@ -506,6 +565,7 @@ struct TileLane {
     {
         const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
         const float nz = meta[kMetaNonZero + frame];
+        const float inv_n = a.inv_n * meta[kMetaGain + frame];
         const float *row = ((!G::ZERO_ROW || nz != 0.0f) ? P + frame * G::PROW : zero_row) + 4 * l;
         constexpr int NB = R2 / 4, B = LOG_R2 == 6 ? SONO_EPI_BATCH_WIDE : LOG_R1 == 5 ? SONO_EPI_BATCH : SONO_EPI_BATCH_512;
         double acc = 0.0;
@@ -523,7 +583,7 @@ struct TileLane {
                 if (!G::ZERO_ROW) { p[0] *= nz; p[1] *= nz; p[2] *= nz; p[3] *= nz; }
                 static_for<0, 4>([&](auto r_) {
                     constexpr int r = decltype(r_)::value;
-                    const double m = (double)(fast_sqrt(p[r]) * a.inv_n);
+                    const double m = (double)(fast_sqrt(p[r]) * inv_n);
                     const double t = m * m;
                     acc += (k0 + r >= a.band_lo && k0 + r <= a.band_hi) ? t : 0.0;
                 });

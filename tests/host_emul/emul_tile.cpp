@@ -13,7 +13,7 @@ using namespace sono;
 static int g_ragged = 0;      // 1 = walk the tiles through the ragged-batch tables
 extern "C" void emul_tile_set_ragged(int v) { g_ragged = v; }
 
-template <int LOG_R1, int LOG_R2, int MODE>
+template <int LOG_R1, int LOG_R2, int MODE, int HOPQ>
 static void run_tiles(const StftArgs &a)
 {
     using G = tile::Geo<LOG_R1, LOG_R2>;
@@ -41,9 +41,9 @@ static void run_tiles(const StftArgs &a)
     unsigned long long peak[16];
     for (auto &p : peak) p = peak_key(0.0f, 0u);
     auto max64 = [](unsigned long long *p, unsigned long long v) { if (v > *p) *p = v; };
-    std::vector<tile::TileLane<LOG_R1, LOG_R2, MODE>> lanes;
+    std::vector<tile::TileLane<LOG_R1, LOG_R2, MODE, HOPQ>> lanes;
     for (int l = 0; l < 64; ++l) lanes.emplace_back(a, l);
-    static float rr[64][R2], ri[64][R2], re[64][R2], im[64][R2], ma[64][G::JPL], mb[64][G::JPL], g2[64];
+    static float rr[64][R2], ri[64][R2], re[64][R2], im[64][R2], ma[64][G::JPL], mb[64][G::JPL];
     float meta[tile::kMetaFloats];
     const std::vector<float> zero_row(G::BINS, 0.0f);
     for (unsigned long long t = 0; t < it.n_tiles; ++t) {
@@ -61,8 +61,7 @@ static void run_tiles(const StftArgs &a)
         for (int l = 0; l < 64; ++l) lanes[l].exchange_load(img, re[l]);
         for (int l = 0; l < 64; ++l) lanes[l].exchange_store(ri[l], img);
         for (int l = 0; l < 64; ++l) lanes[l].exchange_load(img, im[l]);
-        for (int l = 0; l < 64; ++l) g2[l] = lanes[l].pass2_scale(meta);
-        for (int l = 0; l < 64; ++l) lanes[l].pass2_power(re[l], im[l], g2[l], img);
+        for (int l = 0; l < 64; ++l) lanes[l].pass2_power(re[l], im[l], img);
         if (MODE == MODE_BAND) {
             double e[64], e2[64];
             for (int l = 0; l < 64; ++l) e[l] = lanes[l].band_sum(img, meta, zero_row.data());
@@ -73,7 +72,10 @@ static void run_tiles(const StftArgs &a)
             for (int l = 0; l < 64; ++l) lanes[l].band_emit(tr, e[l]);
             continue;
         }
-        for (int l = 0; l < 64; ++l) lanes[l].epilogue(tr, img, meta, zero_row.data(), &peak[l >> (LOG_R1 - 1)], max64);
+        for (int l = 0; l < 64; ++l) {
+            if (MODE == MODE_U8 && a.q_floor > 0.0f) lanes[l].template epilogue<true>(tr, img, meta, zero_row.data(), &peak[l >> (LOG_R1 - 1)], max64);
+            else lanes[l].template epilogue<false>(tr, img, meta, zero_row.data(), &peak[l >> (LOG_R1 - 1)], max64);
+        }
         for (int l = 0; l < 64; ++l) lanes[l].features(tr, &peak[l >> (LOG_R1 - 1)]);
     }
     if (MODE == MODE_U8 && a.gmax_bits) {
@@ -88,6 +90,9 @@ static void run_tiles(const StftArgs &a)
 
 static int g_log_r2 = 0;      // 0 = the geometry the kernel launcher picks for N
 extern "C" void emul_tile_set_log_r2(int v) { g_log_r2 = v; }
+
+static int g_any_hop = 0;     // 1 = the any-hop form even where the launcher would pick the shared-load form
+extern "C" void emul_tile_set_any_hop(int v) { g_any_hop = v; }
 
 static unsigned int g_band_lo = 0, g_band_hi = 0;
 static double g_band_target = 0.0;
@@ -119,7 +124,11 @@ extern "C" int emul_tile(int mode, const float *x, unsigned long long n_streams,
     a.band_active = g_band_active; a.band_energy = g_band_energy;
     const Quant q = make_quant(N, gain_db, range_db);
     a.q_a = q.a; a.q_c = q.c; a.q_floor = q.floor;
-#define RUN(L1, L2) do { if (mode == MODE_MAG) run_tiles<L1, L2, MODE_MAG>(a); else if (mode == MODE_BAND) run_tiles<L1, L2, MODE_BAND>(a); else run_tiles<L1, L2, MODE_U8>(a); } while (0)
+    const bool quarter = !g_any_hop && hop * 4u == N, half = !g_any_hop && hop * 2u == N;
+#define RUN(L1, L2) do { \
+        if (mode == MODE_MAG) { if (quarter) run_tiles<L1, L2, MODE_MAG, 1>(a); else run_tiles<L1, L2, MODE_MAG, 0>(a); } \
+        else if (mode == MODE_BAND) { if (half) run_tiles<L1, L2, MODE_BAND, 2>(a); else run_tiles<L1, L2, MODE_BAND, 0>(a); } \
+        else { if (quarter) run_tiles<L1, L2, MODE_U8, 1>(a); else run_tiles<L1, L2, MODE_U8, 0>(a); } } while (0)
     if (g_log_r2 == 6 && N == 1024) RUN(4, 6);
     else if (g_log_r2 == 6 && N == 512) RUN(3, 6);
     else if (N == 4096) RUN(6, 6); else if (N == 2048) RUN(5, 6); else if (N == 1024) RUN(5, 5); else if (N == 512) RUN(4, 5); else RUN(3, 5);

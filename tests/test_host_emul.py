@@ -247,3 +247,34 @@ def _run_batch(emul, buf, N, V, window, per, stride):
                         C.c_uint(N), _p(window), C.c_float(20), C.c_float(80), None, _p(u8), _p(pb), None, None, None)
     assert rc == 0
     return u8, pb
+
+
+@pytest.mark.parametrize("N,V,mode", [(1024, 768, 1), (1024, 768, 0), (512, 384, 1), (256, 192, 1), (2048, 1536, 1), (4096, 3072, 0),
+                                      (1024, 512, 3), (2048, 1024, 3)])
+def test_tile_wave_shared_loads_change_nothing(emul, N, V, mode):
+    # hop = N/4 (N/2 in the band mode): frame B takes the rows it shares with frame A from A's registers
+    # instead of loading them again -- every output bit must equal the form that loads both frames whole
+    H = N - V
+    x = signal(N + 13 * H + 5, N + 9)
+    x[: N + H] = 0.0
+    x[N + 6 * H: N + 7 * H] *= 300.0                      # a burst that only some frames see (frame B's scaling)
+    e = so.OracleEngine(N, "hann")
+    res = []
+    for any_hop in (0, 1):
+        emul.emul_tile_set_any_hop(any_hop)
+        try:
+            if mode == 3:
+                F = so.num_frames(len(x), N, V)
+                active = np.full(F, 7, np.uint8)
+                energy = np.zeros(F, np.float64)
+                emul.emul_tile_set_band(C.c_uint(3), C.c_uint(N // 2 - 2), C.c_double(1e-3), _p(active), _p(energy))
+                run_emul(emul, "emul_tile", 3, x, N, V, e.window)
+                res.append((active, energy))
+            else:
+                r = run_emul(emul, "emul_tile", mode, x, N, V, e.window)
+                res.append((r["mag"], r["u8"], r["peak_bin"], r["peak_mag"], np.float32(r["gmax"])))
+        finally:
+            emul.emul_tile_set_any_hop(0)
+    for u, v in zip(res[0], res[1]):
+        assert np.array_equal(u, v)
+    assert any(np.any(u) for u in res[0])
