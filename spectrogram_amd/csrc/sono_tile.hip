@@ -5,10 +5,11 @@
 // the bin-major power image; the only data shared inside a workgroup are the
 // read-only window and inter-pass twiddle tables, a row of zeros and the tile
 // counter.  One workgroup per CU.  N <= 1024 (32 values per lane and pass): twelve
-// waves, i.e. three per SIMD and 168 VGPRs per lane, 8.25 KB regions.  N >= 2048
-// (64 values per lane and pass): eight waves, two per SIMD and up to 256 VGPRs,
-// 16 KB regions.  Enough waves to keep the vector ALU issuing while others sit
-// in LDS or memory waits, without register spills.
+// waves, i.e. three per SIMD (sixteen, four per SIMD and at most 128 VGPRs per lane,
+// at N = 1024), 8.25 KB regions.  N >= 2048 (64 values per lane and pass): eight
+// waves, two per SIMD and up to 256 VGPRs, 16 KB regions.  Enough waves to keep
+// the vector ALU issuing while others sit in LDS or memory waits, without
+// register spills.
 //
 // Tile walk: the tiles of a launch are cut into one contiguous range per XCD
 // (workgroups are dealt round-robin to the eight XCDs), and inside a range the
@@ -33,16 +34,25 @@ namespace {
 #ifndef SONO_WPS
 #define SONO_WPS 3
 #endif
+#ifndef SONO_WPB_1024
+#define SONO_WPB_1024 16
+#endif
+#ifndef SONO_WPS_1024
+#define SONO_WPS_1024 4
+#endif
 #ifndef SONO_WIDE_WPB
 #define SONO_WIDE_WPB 8
 #endif
 #ifndef SONO_WIDE_WPS
 #define SONO_WIDE_WPS 2
 #endif
-template <int LOG_R2>
+// fft 1024 fits 128 VGPRs without spills and gains from a fourth wave per SIMD
+// (3.32 -> 3.19 ms); fft 512 and 256 lose with it (1.89 -> 2.06 ms at 512).
+template <int LOG_R1, int LOG_R2>
 struct Occupancy {
-    static constexpr int kWavesPerBlock = LOG_R2 == 5 ? SONO_WPB : SONO_WIDE_WPB;
-    static constexpr int kWavesPerSimd = LOG_R2 == 5 ? SONO_WPS : SONO_WIDE_WPS;
+    static constexpr bool kFour = LOG_R1 == 5 && LOG_R2 == 5;
+    static constexpr int kWavesPerBlock = LOG_R2 == 6 ? SONO_WIDE_WPB : kFour ? SONO_WPB_1024 : SONO_WPB;
+    static constexpr int kWavesPerSimd = LOG_R2 == 6 ? SONO_WIDE_WPS : kFour ? SONO_WPS_1024 : SONO_WPS;
     static constexpr int kBlocksPerCU = 4 * kWavesPerSimd / kWavesPerBlock;
 };
 constexpr int kXcds = 8;
@@ -100,12 +110,12 @@ __device__ __forceinline__ float column_max(float v)
 // RAGGED: streams of different lengths, located through TileIter's tables.
 // HOPQ: 1 / 2 = the launch's hop is N/4 / N/2 (frame B reuses frame A's loads), 0 = any hop.
 template <int LOG_R1, int LOG_R2, int MODE, bool RAGGED, int HOPQ>
-__global__ __launch_bounds__(64 * Occupancy<LOG_R2>::kWavesPerBlock, Occupancy<LOG_R2>::kWavesPerSimd)
+__global__ __launch_bounds__((64 * Occupancy<LOG_R1, LOG_R2>::kWavesPerBlock), (Occupancy<LOG_R1, LOG_R2>::kWavesPerSimd))
 void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *tw_rows)
 {
     using G = tile::Geo<LOG_R1, LOG_R2>;
     constexpr int R2 = G::R2;
-    constexpr int kWavesPerBlock = Occupancy<LOG_R2>::kWavesPerBlock;
+    constexpr int kWavesPerBlock = Occupancy<LOG_R1, LOG_R2>::kWavesPerBlock;
     constexpr int kZeroFloats = G::ZERO_ROW ? G::BINS : 4;
     __shared__ __align__(16) float s_img[kWavesPerBlock * G::REGION];
     __shared__ __align__(16) float2 s_tw[G::TW_ROWS * R2];
@@ -224,8 +234,8 @@ template <int LOG_R1, int LOG_R2, int MODE>
 hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, hipStream_t stream)
 {
     using G = tile::Geo<LOG_R1, LOG_R2>;
-    constexpr int kWavesPerBlock = Occupancy<LOG_R2>::kWavesPerBlock;
-    constexpr int kBlocksPerCU = Occupancy<LOG_R2>::kBlocksPerCU;
+    constexpr int kWavesPerBlock = Occupancy<LOG_R1, LOG_R2>::kWavesPerBlock;
+    constexpr int kBlocksPerCU = Occupancy<LOG_R1, LOG_R2>::kBlocksPerCU;
     tile::TileIter it;
     if (plan) {
         it.tiles_per_stream = 0;
