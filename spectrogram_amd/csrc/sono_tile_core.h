@@ -174,7 +174,10 @@ struct Geo {
     static constexpr int PPW = 64 / R1;        // frame pairs per wave
     static constexpr int FPW = 2 * PPW;        // frames per wave
     static constexpr int JPL = R2 / R1;        // pass-1 jobs (pairs) per lane
-    static constexpr int PAD = R1 < 64 ? HALF : 0;
+#ifndef SONO_PAD_FROM
+#define SONO_PAD_FROM 32
+#endif
+    static constexpr int PAD = R1 < SONO_PAD_FROM ? HALF : 0;
     static constexpr int PROW = BINS + PAD;    // floats per frame in the power image: the pad puts the frames
                                                // of one 32-lane store group on disjoint banks
     // Inter-pass twiddles W_N^(n2*k1), one row of R2 entries per k1.  Unfolded: rows
