@@ -36,9 +36,13 @@ inline std::vector<float2> make_tile_twiddles(unsigned int N, unsigned int r2)
     std::vector<float2> t(ks.size() * r2);
     for (size_t r = 0; r < ks.size(); ++r)
         for (unsigned int n2 = 0; n2 < r2; ++n2) {
+            // Rows k1 < R1/2 carry a factor 2: pass 1 hands Y (not 2Y) of a frame's own rows to
+            // pass 2, which ends with |2X|^2 in every bin.  The row k1 = R1/2 is shared by the two
+            // frames of a pair and doubles in the separation after pass 2.
             const double a = -2.0 * 3.14159265358979323846 * (double)(ks[r] * n2) / (double)N;
-            t[r * r2 + n2].x = (float)std::cos(a);
-            t[r * r2 + n2].y = (float)std::sin(a);
+            const double g = ks[r] < half ? 2.0 : 1.0;
+            t[r * r2 + n2].x = (float)(g * std::cos(a));
+            t[r * r2 + n2].y = (float)(g * std::sin(a));
         }
     return t;
 }

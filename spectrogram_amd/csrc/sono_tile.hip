@@ -3,8 +3,7 @@
 // Persistent waves.  A workgroup is a set of independent waves, each owning a
 // private LDS region that is first the pass-1 -> pass-2 exchange image and then
 // the bin-major power image; the only data shared inside a workgroup are the
-// read-only window and inter-pass twiddle tables, a row of zeros and the tile
-// counter.  One workgroup per CU.  N <= 1024 (32 values per lane and pass): twelve
+// read-only window and inter-pass twiddle tables and the tile counter.  One workgroup per CU.  N <= 1024 (32 values per lane and pass): twelve
 // waves, i.e. three per SIMD (sixteen, four per SIMD and at most 128 VGPRs per lane,
 // at N = 1024), 8.25 KB regions.  N >= 2048 (64 values per lane and pass): eight
 // waves, two per SIMD and up to 256 VGPRs, 16 KB regions.  Enough waves to keep
@@ -116,14 +115,12 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
     using G = tile::Geo<LOG_R1, LOG_R2>;
     constexpr int R2 = G::R2;
     constexpr int kWavesPerBlock = Occupancy<LOG_R1, LOG_R2>::kWavesPerBlock;
-    constexpr int kZeroFloats = G::ZERO_ROW ? G::BINS : 4;
     __shared__ __align__(16) float s_img[kWavesPerBlock * G::REGION];
     __shared__ __align__(16) float2 s_tw[G::TW_ROWS * R2];
     __shared__ __align__(16) float s_win[G::N];
     __shared__ unsigned long long s_peak[kWavesPerBlock * 16];
     __shared__ unsigned int s_next;
     __shared__ float s_meta[kWavesPerBlock * tile::kMetaFloats];
-    __shared__ __align__(16) float s_zero[kZeroFloats];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -131,7 +128,6 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
     for (int i = threadIdx.x; i < G::N; i += blockDim.x) s_win[i] = a.window[i];
     if (threadIdx.x < kWavesPerBlock * 16) s_peak[threadIdx.x] = peak_key(0.0f, 0u);
     if (threadIdx.x == 0) s_next = 0u;
-    for (int i = threadIdx.x; i < kZeroFloats; i += blockDim.x) s_zero[i] = 0.0f;
     __syncthreads();
 
     float *img = s_img + wave * G::REGION;
@@ -174,10 +170,15 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
             float rr[R2], ri[R2];
             L.load(tr);
             STAMP(0);
-            float ma[G::JPL], mb[G::JPL];
-            L.scan(ma, mb);
-            for (int jj = 0; jj < G::JPL; ++jj) { ma[jj] = column_max<LOG_R2>(ma[jj]); mb[jj] = column_max<LOG_R2>(mb[jj]); }
-            L.pass1(s_win, s_tw, ma, mb, rr, ri, meta);
+            {
+                float ya[R2], yb[R2], pa[G::JPL], pb[G::JPL];
+                L.pass1_dft(s_win, ya, yb, pa, pb);
+#ifndef SONO_EXP_NO_SB1
+                __builtin_amdgcn_sched_barrier(0);     // keeps the twiddle reads (60 registers) below the transforms
+#endif
+                for (int jj = 0; jj < G::JPL; ++jj) { pa[jj] = column_max<LOG_R2>(pa[jj]); pb[jj] = column_max<LOG_R2>(pb[jj]); }
+                L.pass1_rows(s_tw, ya, yb, pa, pb, rr, ri, meta);
+            }
             __builtin_amdgcn_sched_barrier(0);
             STAMP(1);
             L.exchange_store(rr, img);
@@ -194,12 +195,12 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
         wave_lds_fence();
         STAMP(3);
         if constexpr (MODE == MODE_BAND) {
-            double e = L.band_sum(img, meta, s_zero);
+            double e = L.band_sum(img, meta);
             for (int o = G::HALF / 2; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
             L.band_emit(tr, e);
         } else {
-            if (MODE == MODE_U8 && a.q_floor > 0.0f) L.template epilogue<true>(tr, img, meta, s_zero, peak_slot, LdsMax64());
-            else L.template epilogue<false>(tr, img, meta, s_zero, peak_slot, LdsMax64());
+            if (MODE == MODE_U8 && a.q_floor > 0.0f) L.template epilogue<true>(tr, img, meta, peak_slot, LdsMax64());
+            else L.template epilogue<false>(tr, img, meta, peak_slot, LdsMax64());
         }
         if (MODE == MODE_U8) {
             wave_lds_fence();
@@ -277,11 +278,13 @@ template <int MODE>
 hipError_t launch_mode(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, hipStream_t stream)
 {
     switch (a.N) {
+#ifndef SONO_EXP_ONLY_1024      // tools/expbuild.sh: quicker experimental builds
     case 4096: return launch_one<6, 6, MODE>(a, tw_rows, plan, stream);
     case 2048: return launch_one<5, 6, MODE>(a, tw_rows, plan, stream);
-    case 1024: return launch_one<10 - tile_log_r2(1024), tile_log_r2(1024), MODE>(a, tw_rows, plan, stream);
     case 512: return launch_one<9 - tile_log_r2(512), tile_log_r2(512), MODE>(a, tw_rows, plan, stream);
     case 256: return launch_one<3, 5, MODE>(a, tw_rows, plan, stream);
+#endif
+    case 1024: return launch_one<10 - tile_log_r2(1024), tile_log_r2(1024), MODE>(a, tw_rows, plan, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -9,14 +9,13 @@
 //   X[k1 + R1*k2] = sum_{n2<32} W_32^(n2*k2) * W_N^(n2*k1) * Y[k1][n2],
 //   Y[k1][n2]     = sum_{n1<R1} xw[32*n1 + n2] * W_R1^(n1*k1)          (xw = x * window)
 //
-//   pass 1  lane = (h, n2), R1 register points n1: ONE complex DFT-R1 of
-//           (xwA + i*xwB) per pair gives Y_A and Y_B by conjugate symmetry:
-//             2*Y_A[k1] = C[k1] + conj C[R1-k1],  2*Y_B[k1] = -i*(C[k1] - conj C[R1-k1])
-//           for k1 = 1..R1/2-1; the two real rows k1 = 0 and k1 = R1/2 of both
-//           frames ride together as (Y_A, Y_B) = (Re C, Im C).  Each row is
-//           multiplied by W_N^(n2*k1) and written to the wave's LDS image
-//           [row][n2], real parts first, imaginary parts in a second round over
-//           the same 8 KB.
+//   pass 1  lane = (h, n2), R1 register points n1: one real-input DFT-R1 per
+//           frame (rdft_bitrev_in: half the work of a complex one) gives Y_A and
+//           Y_B for k1 = 0..R1/2.  Rows k1 = 1..R1/2-1 of each frame are multiplied
+//           by W_N^(n2*k1); the two real rows k1 = 0 and k1 = R1/2 of both frames
+//           ride together as Y_A + i*Y_B (times W_N^(n2*R1/2) for k1 = R1/2).  Each
+//           row is written to the wave's LDS image [row][n2], real parts first,
+//           imaginary parts in a second round over the same 8 KB.
 //   pass 2  lane = row (pair q, rho): rho = k1 in 1..R1/2-1 carries frame A,
 //           rho = R1/2 + k1 frame B, rho = 0 and rho = R1/2 the two shared real
 //           rows.  One complex DFT-32 over n2 leaves 2*X[k1 + R1*k2] in register
@@ -31,15 +30,15 @@
 //           log2 -> dB -> u8 -> one dword store, running arg-max for the
 //           per-frame peak.
 //
-//   scale   A + iB in one DFT leaks rounding noise of the louder frame into the
-//           quieter one (about 1e-7 of the LOUDER frame's level).  Frame B is
-//           therefore multiplied by the power of two that brings its largest
-//           sample to A's binade before pass 1 (exact) and stays scaled through
-//           both passes and in the power image; the epilogue undoes it where
-//           that is free: as a per-frame term in the dB constant, in the 1/N
-//           factor of the magnitude, and once on the frame's peak.  A frame of
-//           exact zeros must come out as exact zeros: the epilogue reads such a
-//           frame's bins from a row of zeros instead of the power image.
+//   scale   Y_A + i*Y_B in one DFT leaks rounding noise of the louder frame's
+//           rows into the quieter one's (about 1e-7 of the LOUDER level).  Only
+//           the two shared rows are affected -- every other row of pass 2 holds one
+//           frame alone.  Frame B's share of them is therefore multiplied by the
+//           power of two that brings its largest entry to the binade of frame
+//           A's (exact), and the epilogue multiplies |2X_B|^2 of the bins that came
+//           through those rows (the multiples of R1/2) by its inverse square.  A
+//           frame whose share is exactly zero gets the factor 0: its bins are
+//           exactly zero, as they are in every other row without any help.
 //
 //   hop     With hop = N/4 or N/2 (HOPQ = 1, 2) frame B's first samples ARE frame
 //           A's samples R1/4 (R1/2) rows further down the same column, so only
@@ -161,6 +160,62 @@ SONO_HD void dft_bitrev_in(float (&re)[N], float (&im)[N])
     });
 }
 
+// In-place DFT of N real values (N = 2..64), input in bit-reversed order, output
+// in half-complex order: Re X[k] in v[k] (k = 0..N/2), Im X[k] in v[N-k]
+// (k = 1..N/2-1).  Decimation in time on real data: a size-M block is combined
+// from the half-complex DFTs E (even samples, first half of the block) and O (odd
+// samples, second half):
+//   X[0] = E0 + O0,  X[M/2] = E0 - O0,  X[M/4] = E[M/4] - i O[M/4]  (all of E0, O0, E[M/4], O[M/4] real),
+//   X[k] = E[k] + W_M^k O[k],  X[M/2-k] = conj(E[k] - W_M^k O[k])   for 0 < k < M/4,
+// 164 operations at N = 32 where the complex transform of a frame pair takes 388
+// and the separation of the two spectra 60 more.  FIRST = 4: the size-2 blocks
+// (v[2j] + v[2j+1], v[2j] - v[2j+1]) have been formed by the caller.
+template <int M, int BASE, int N>
+SONO_HD void rdft_combine(float (&v)[N])
+{
+    constexpr int H = M / 2, Q = M / 4;
+    const float e0 = v[BASE], o0 = v[BASE + H];
+    v[BASE] = e0 + o0;
+    v[BASE + H] = e0 - o0;
+    if constexpr (M >= 4) v[BASE + H + Q] = -v[BASE + H + Q];
+    static_for<1, Q>([&](auto k_) {
+        constexpr int k = decltype(k_)::value;
+        constexpr float wr = w64_re(k * (64 / M)), wi = w64_im(k * (64 / M));
+        const float er = v[BASE + k], ei = v[BASE + H - k], orr = v[BASE + H + k], oi = v[BASE + M - k];
+        const float xr = er + (wr * orr - wi * oi);
+        const float xi = ei + (wr * oi + wi * orr);
+        v[BASE + k] = xr;
+        v[BASE + M - k] = xi;
+        v[BASE + H - k] = 2.0f * er - xr;
+        v[BASE + H + k] = xi - 2.0f * ei;
+    });
+}
+template <int N, int FIRST = 2>
+SONO_HD void rdft_bitrev_in(float (&v)[N])
+{
+    constexpr int L = ilog2(N), L0 = ilog2(FIRST);
+    static_for<L0, L + 1>([&](auto s_) {
+        constexpr int M = 1 << decltype(s_)::value;
+        static_for<0, N / M>([&](auto b_) { rdft_combine<M, decltype(b_)::value * M>(v); });
+    });
+}
+
+// Makes the compiler finish computing v[0..N) here: without it the part of a
+// transform that the next few instructions do not need is sunk below them, and its
+// inputs (twice as many registers) stay alive instead of its outputs.
+template <int G0 = 0, int N>
+SONO_HD void pin_registers(float (&v)[N])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(N % 8 == 0, "pinned in groups of eight");
+    asm volatile("" : "+v"(v[G0]), "+v"(v[G0 + 1]), "+v"(v[G0 + 2]), "+v"(v[G0 + 3]),
+                      "+v"(v[G0 + 4]), "+v"(v[G0 + 5]), "+v"(v[G0 + 6]), "+v"(v[G0 + 7]));
+    if constexpr (G0 + 8 < N) pin_registers<G0 + 8>(v);
+#else
+    (void)v;
+#endif
+}
+
 // ---- tile geometry -----------------------------------------------------------
 // N = R1 * R2: pass 1 transforms R1 register points per lane, pass 2 R2.  R2 = 32
 // serves N = 256..1024 (R1 = 8..32), R2 = 64 serves N = 2048 and 4096 (R1 = 32, 64).
@@ -189,9 +244,6 @@ struct Geo {
     // A wave's LDS region is first the exchange image (64 rows of R2 floats), then
     // the power image (FPW rows of PROW floats).
     static constexpr int REGION = 64 * R2 > FPW * PROW ? 64 * R2 : FPW * PROW;
-    // An all-zero frame must give exact zeros.  R2 = 32: the epilogue reads such a
-    // frame from a row of zeros in LDS; R2 = 64: it multiplies by the frame's 0/1 flag.
-    static constexpr bool ZERO_ROW = R2 == 32;
 };
 
 // Exchange image: row L (one per pass-2 lane) keeps its 16-byte chunks in the
@@ -205,14 +257,10 @@ template <int LOG_R2>
 SONO_HD constexpr int image_index(int row, int col) { return (row << LOG_R2) + (col ^ image_swizzle<LOG_R2>(row)); }
 
 // Per-wave, per-tile side information handed from pass 1 to the epilogue through
-// LDS, one entry per frame of the tile: [kMetaGain + frame] = the power of two
-// that undoes the frame's scaling in |2X| (1 for a frame A); [kMetaShift + frame]
-// = 2*log2 of it, as a float; [kMetaNonZero + frame] = 1 if the frame has a
-// non-zero sample, else 0.
-constexpr int kMetaGain = 0;
-constexpr int kMetaNonZero = 16;
-constexpr int kMetaShift = 32;
-constexpr int kMetaFloats = 48;
+// LDS: [kMetaFix + frame] = the factor for |2X|^2 of the frame's bins that came
+// through the rows it shares with the other frame of its pair (see pass1_rows).
+constexpr int kMetaFix = 0;
+constexpr int kMetaFloats = 16;
 
 #if defined(__HIP_DEVICE_COMPILE__)
 SONO_HD int float_exponent(float v) { return __builtin_amdgcn_frexp_expf(v); }
@@ -318,96 +366,82 @@ struct TileLane {
         });
     }
 
-    // Largest |sample| of this lane's column of frames A and B of each of its pairs.
-    SONO_HD void scan(float (&ma)[G::JPL], float (&mb)[G::JPL]) const
+    // Pass 1, first half: window and real-input DFT-R1 of this lane's column of
+    // frames A and B of each of its pairs.  Leaves Y_A / Y_B in half-complex order
+    // (Re Y[k1] at [jj*R1 + k1], Im Y[k1] at [jj*R1 + R1 - k1]) and, in pa / pb, the
+    // larger of |Y[0]| and |Y[R1/2]| -- the lane's share of the two rows that the
+    // frames of a pair send through pass 2 together.
+    SONO_HD void pass1_dft(const float *win, float (&ya)[R2], float (&yb)[R2], float (&pa)[G::JPL], float (&pb)[G::JPL]) const
     {
+        const int n2 = col();
         static_for<0, G::JPL>([&](auto jj_) {
             constexpr int jj = decltype(jj_)::value;
-            float va = 0.0f, vb = 0.0f;
-            if constexpr (SHIFT != 0) {
-                float vs = 0.0f;          // the rows both frames hold
-                static_for<0, OWN_B / 2>([&](auto n_) {
-                    constexpr int n1 = SHIFT + 2 * decltype(n_)::value;
-                    vs = fmaxf(fmaxf(fabsf(xa[jj * G::R1 + n1]), fabsf(xa[jj * G::R1 + n1 + 1])), vs);
-                });
-                static_for<0, SHIFT / 2>([&](auto n_) {
-                    constexpr int n1 = 2 * decltype(n_)::value;
-                    va = fmaxf(fmaxf(fabsf(xa[jj * G::R1 + n1]), fabsf(xa[jj * G::R1 + n1 + 1])), va);
-                    vb = fmaxf(fmaxf(fabsf(xb[jj * G::R1 + OWN_B + n1]), fabsf(xb[jj * G::R1 + OWN_B + n1 + 1])), vb);
-                });
-                va = fmaxf(va, vs);
-                vb = fmaxf(vb, vs);
-            } else {
-                static_for<0, G::R1 / 2>([&](auto n_) {
-                    constexpr int n1 = 2 * decltype(n_)::value;
-                    va = fmaxf(fmaxf(fabsf(xa[jj * G::R1 + n1]), fabsf(xa[jj * G::R1 + n1 + 1])), va);
-                    vb = fmaxf(fmaxf(fabsf(xb[jj * G::R1 + n1]), fabsf(xb[jj * G::R1 + n1 + 1])), vb);
-                });
-            }
-            ma[jj] = va;
-            mb[jj] = vb;
-        });
-    }
-
-    // Pass 1: scale B, window, DFT-R1 of A + iB, conjugate-symmetric separation,
-    // twiddle.  ma / mb = largest |sample| of frames A / B of each pair over all R2
-    // columns.  Leaves the R2 row values of the lane (rows rho of its JPL pairs,
-    // column n2) in rr / ri at [jj*R1 + rho]; frame B's rows stay scaled.  win = the N
-    // window values; tw = the twiddle table described at Geo::TW_FOLD.  The lane of
-    // column 0 records the pair's side information in `meta`.
-    SONO_HD void pass1(const float *win, const float2 *tw, const float (&ma)[G::JPL], const float (&mb)[G::JPL],
-                       float (&rr)[R2], float (&ri)[R2], float *meta) const
-    {
-        const int h = hgroup(), n2 = col();
-        static_for<0, G::JPL>([&](auto jj_) {
-            constexpr int jj = decltype(jj_)::value;
-            int d = (ma[jj] > 0.0f && mb[jj] > 0.0f) ? float_exponent(ma[jj]) - float_exponent(mb[jj]) : 0;
-            d = d > 40 ? 40 : d < -40 ? -40 : d;
-            const float sb = pow2(d);
-            if (n2 == 0) {
-                const int q = h * G::JPL + jj;
-                meta[kMetaGain + 2 * q] = 1.0f;
-                meta[kMetaGain + 2 * q + 1] = pow2(-d);
-                meta[kMetaShift + 2 * q] = 0.0f;
-                meta[kMetaShift + 2 * q + 1] = (float)(-2 * d);
-                meta[kMetaNonZero + 2 * q] = ma[jj] > 0.0f ? 1.0f : 0.0f;
-                meta[kMetaNonZero + 2 * q + 1] = mb[jj] > 0.0f ? 1.0f : 0.0f;
-            }
             // Window and the DFT's first stage in one go: a butterfly's two outputs are
             // a +- b with a = x[n1]*w[n1] and b = x[n1 + R1/2]*w[n1 + R1/2] fused into the sum.
-            float re[G::R1], im[G::R1];
+            float va[G::R1], vb[G::R1];
             static_for<0, G::HALF>([&](auto j_) {
                 constexpr int i = 2 * decltype(j_)::value, na = bitrev(i, LOG_R1), nb = na + G::HALF;
                 static_assert(bitrev(i + 1, LOG_R1) == nb, "stage-1 partner");
                 const float wa = win[R2 * na + n2], wb = win[R2 * nb + n2];
-#ifdef SONO_UNFUSED_WINDOW
-                const float a0 = xa[jj * G::R1 + na] * wa, a1 = xa[jj * G::R1 + nb] * wb;
-                re[i] = a0 + a1;
-                re[i + 1] = a0 - a1;
-                const float b0 = (b_at<jj, na>() * sb) * wa, b1 = (b_at<jj, nb>() * sb) * wb;
-                im[i] = b0 + b1;
-                im[i + 1] = b0 - b1;
-#else
                 const float a0 = xa[jj * G::R1 + na] * wa, a1 = xa[jj * G::R1 + nb];
-                re[i] = __builtin_fmaf(a1, wb, a0);
-                re[i + 1] = __builtin_fmaf(-a1, wb, a0);
-                const float b0 = (b_at<jj, na>() * sb) * wa, b1 = b_at<jj, nb>() * sb;
-                im[i] = __builtin_fmaf(b1, wb, b0);
-                im[i + 1] = __builtin_fmaf(-b1, wb, b0);
-#endif
+                va[i] = __builtin_fmaf(a1, wb, a0);
+                va[i + 1] = __builtin_fmaf(-a1, wb, a0);
+                const float b0 = b_at<jj, na>() * wa, b1 = b_at<jj, nb>();
+                vb[i] = __builtin_fmaf(b1, wb, b0);
+                vb[i + 1] = __builtin_fmaf(-b1, wb, b0);
             });
-            dft_bitrev_in<G::R1, 2>(re, im);
-            rr[jj * G::R1] = re[0];
-            ri[jj * G::R1] = im[0];
-            // rows k1 (frame A) and R1/2 + k1 (frame B), twiddled by t = W_N^(n2*k1)
+            rdft_bitrev_in<G::R1, 4>(va);
+            rdft_bitrev_in<G::R1, 4>(vb);
+            pin_registers(va);
+            pin_registers(vb);
+            static_for<0, G::R1>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                ya[jj * G::R1 + i] = va[i];
+                yb[jj * G::R1 + i] = vb[i];
+            });
+            pa[jj] = fmaxf(fabsf(va[0]), fabsf(va[G::HALF]));
+            pb[jj] = fmaxf(fabsf(vb[0]), fabsf(vb[G::HALF]));
+        });
+    }
+
+    // Pass 1, second half: the inter-pass twiddles.  pa / pb = the maxima of
+    // pass1_dft's values over all R2 columns.  Leaves the R2 row values of the lane
+    // (rows rho of its JPL pairs, column n2) in rr / ri at [jj*R1 + rho]: rows
+    // 1..R1/2-1 = frame A's Y[k1] * 2 W_N^(n2*k1), rows R1/2+1..R1-1 frame B's; row 0 =
+    // Y_A[0] + i s Y_B[0] and row R1/2 = (Y_A[R1/2] + i s Y_B[R1/2]) * W_N^(n2*R1/2), where the
+    // power of two s brings frame B's share of these two rows to the binade of
+    // frame A's (see "scale" above).  win = the N window values; tw = the twiddle
+    // table described at Geo::TW_FOLD.  The lane of column 0 records the pair's side
+    // information in `meta`.
+    SONO_HD void pass1_rows(const float2 *tw, const float (&ya)[R2], const float (&yb)[R2], const float (&pa)[G::JPL],
+                            const float (&pb)[G::JPL], float (&rr)[R2], float (&ri)[R2], float *meta) const
+    {
+        const int h = hgroup(), n2 = col();
+        static_for<0, G::JPL>([&](auto jj_) {
+            constexpr int jj = decltype(jj_)::value, o = jj * G::R1;
+            int d = (pa[jj] > 0.0f && pb[jj] > 0.0f) ? float_exponent(pa[jj]) - float_exponent(pb[jj]) : 0;
+            d = d > 40 ? 40 : d < -40 ? -40 : d;
+            const float sb = pow2(d);
+            if (n2 == 0) {
+                // What the epilogue multiplies |2X|^2 of the shared rows' bins by: 0 for a
+                // frame whose share of them is exactly zero (its bins are then exactly zero,
+                // and what the separation leaves of the other frame must not show), else 1
+                // for a frame A and s^-2 for a frame B.
+                const int q = h * G::JPL + jj;
+                const float gb = pow2(-d);
+                meta[kMetaFix + 2 * q] = pa[jj] > 0.0f ? 1.0f : 0.0f;
+                meta[kMetaFix + 2 * q + 1] = pb[jj] > 0.0f ? gb * gb : 0.0f;
+            }
+            rr[o] = ya[o];
+            ri[o] = yb[o] * sb;
+            // rows k1 (frame A) and R1/2 + k1 (frame B), twiddled by t = 2 W_N^(n2*k1)
             auto rows = [&](auto k_, const float2 t) {
                 constexpr int k1 = decltype(k_)::value;
-                const float ar = re[k1] + re[G::R1 - k1], ai = im[k1] - im[G::R1 - k1];   // 2 Y_A[k1]
-                const float br = im[k1] + im[G::R1 - k1], bi = re[G::R1 - k1] - re[k1];   // 2 Y_B[k1], scaled
-                rr[jj * G::R1 + k1] = ar * t.x - ai * t.y;
-                ri[jj * G::R1 + k1] = ar * t.y + ai * t.x;
-                rr[jj * G::R1 + G::HALF + k1] = br * t.x - bi * t.y;
-                ri[jj * G::R1 + G::HALF + k1] = br * t.y + bi * t.x;
+                const float ar = ya[o + k1], ai = ya[o + G::R1 - k1], br = yb[o + k1], bi = yb[o + G::R1 - k1];
+                rr[o + k1] = ar * t.x - ai * t.y;
+                ri[o + k1] = ar * t.y + ai * t.x;
+                rr[o + G::HALF + k1] = br * t.x - bi * t.y;
+                ri[o + G::HALF + k1] = br * t.y + bi * t.x;
             };
             float2 tn;                                                                       // W_N^(n2*R1/2)
             if constexpr (G::TW_FOLD) {
@@ -427,8 +461,9 @@ struct TileLane {
                 tn = tw[(G::HALF - 1) * R2 + n2];
                 static_for<1, G::HALF>([&](auto k_) { rows(k_, tw[(decltype(k_)::value - 1) * R2 + n2]); });
             }
-            rr[jj * G::R1 + G::HALF] = re[G::HALF] * tn.x - im[G::HALF] * tn.y;
-            ri[jj * G::R1 + G::HALF] = re[G::HALF] * tn.y + im[G::HALF] * tn.x;
+            const float cr = ya[o + G::HALF], ci = yb[o + G::HALF] * sb;
+            rr[o + G::HALF] = cr * tn.x - ci * tn.y;
+            ri[o + G::HALF] = cr * tn.y + ci * tn.x;
         });
     }
 
@@ -488,26 +523,25 @@ struct TileLane {
     }
 
     // Epilogue: lane (frame, l) owns bins 4l + 2*R1*m + r (m < R2/4, r < 4) of its frame.
-    // zero_row = N/2 floats of 0.0, read in place of the power image for an all-zero
-    // frame (only where Geo::ZERO_ROW).  `peak_slot` is the LDS word of the lane's
-    // frame (ordering key of its largest |2X|^2).  FLOOR = false leaves out the
-    // clamp to q_floor (for q_floor = 0).
+    // `peak_slot` is the LDS word of the lane's frame (ordering key of its largest
+    // |2X|^2).  FLOOR = false leaves out the clamp to q_floor (for q_floor = 0).
+    // The bins that came through the pair's shared rows are the multiples of R1/2:
+    // the first of a lane's four wherever 4l is one.
+    SONO_HD float shared_fix(const float *meta) const
+    {
+        const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
+        return ((4 * l) & (G::HALF - 1)) == 0 ? meta[kMetaFix + frame] : 1.0f;
+    }
     template <bool FLOOR, typename AtomicMax64>
     SONO_HD void epilogue(const TileRef &tr, const float *P, const float *meta,
-                          const float *zero_row, unsigned long long *peak_slot, AtomicMax64 atomic_max64)
+                          unsigned long long *peak_slot, AtomicMax64 atomic_max64)
     {
         const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
         const unsigned long long f = (unsigned long long)tr.j * G::FPW + (unsigned int)frame;
         const bool valid = f < tr.frames;
         const unsigned long long g = tr.row0 + f;
-        const float nz = meta[kMetaNonZero + frame];
-        // The frame's image holds |2X|^2 / gain^2: log2 of it is short by shift =
-        // 2 log2(gain), the magnitude by the factor gain, the floor moves the other way.
-        const float gain = meta[kMetaGain + frame], shift = meta[kMetaShift + frame];
-        const float q_c = a.q_a * shift + a.q_c;
-        const float q_floor = FLOOR ? a.q_floor / (gain * gain) : 0.0f;
-        const float inv_n = a.inv_n * gain;
-        const float *row = ((!G::ZERO_ROW || nz != 0.0f) ? P + frame * G::PROW : zero_row) + 4 * l;
+        const float fix = shared_fix(meta);
+        const float *row = P + frame * G::PROW + 4 * l;
         // Peak search: per group of four bins only the group's maximum is compared
         // with the running one (strict >, so the lowest group wins a tie); which of
         // the four it was is settled once, after the loop.
@@ -529,18 +563,17 @@ struct TileLane {
             static_for<0, B>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
                 const int k0 = 4 * l + 2 * G::R1 * (m0 + i);
-                float p[4] = {p4[i].x, p4[i].y, p4[i].z, p4[i].w};
-                if (!G::ZERO_ROW) { p[0] *= nz; p[1] *= nz; p[2] *= nz; p[3] *= nz; }
+                float p[4] = {p4[i].x * fix, p4[i].y, p4[i].z, p4[i].w};
                 if (MODE == MODE_MAG) {
                     float4 o;
-                    o.x = fast_sqrt(p[0]) * inv_n; o.y = fast_sqrt(p[1]) * inv_n;
-                    o.z = fast_sqrt(p[2]) * inv_n; o.w = fast_sqrt(p[3]) * inv_n;
+                    o.x = fast_sqrt(p[0]) * a.inv_n; o.y = fast_sqrt(p[1]) * a.inv_n;
+                    o.z = fast_sqrt(p[2]) * a.inv_n; o.w = fast_sqrt(p[3]) * a.inv_n;
                     *(float4 *)(a.out_mag + g * (unsigned long long)G::BINS + k0) = o;
                 } else {
                     unsigned int packed = 0;
                     static_for<0, 4>([&](auto r_) {
                         constexpr int r = decltype(r_)::value;
-                        packed |= quantise<FLOOR>(p[r], a.q_a, q_c, q_floor) << (8 * r);
+                        packed |= quantise<FLOOR>(p[r], a.q_a, a.q_c, a.q_floor) << (8 * r);
                     });
                     const float top = max_of_4(p[0], p[1], p[2], p[3]);
                     if (top > best_p) { best_p = top; best_m = m0 + i; }        // false for a NaN
@@ -550,13 +583,11 @@ struct TileLane {
         }
         if (MODE == MODE_U8) {
             const float4 w4 = *(const float4 *)(row + 2 * G::R1 * best_m);
-            float w[4] = {w4.x, w4.y, w4.z, w4.w};
-            if (!G::ZERO_ROW) { w[0] *= nz; w[1] *= nz; w[2] *= nz; w[3] *= nz; }
+            const float w[4] = {w4.x * fix, w4.y, w4.z, w4.w};
             const int r = w[0] == best_p ? 0 : w[1] == best_p ? 1 : w[2] == best_p ? 2 : 3;
             const unsigned int best_k = best_p > 0.0f ? (unsigned int)(4 * l + 2 * G::R1 * best_m + r) : 0u;
-            const float best_true = best_p * (gain * gain);          // |2X|^2 itself
-            run_max = best_true > run_max ? best_true : run_max;
-            atomic_max64(peak_slot, peak_key(best_true, best_k));
+            run_max = best_p > run_max ? best_p : run_max;
+            atomic_max64(peak_slot, peak_key(best_p, best_k));
         }
     }
 
@@ -564,12 +595,11 @@ struct TileLane {
     // the sum over its bins k in [band_lo, band_hi] of (double)mag * mag, where mag is
     // the f32 magnitude MODE_MAG would store, in increasing k.  Step 2 (the caller's):
     // add up the R1/2 lanes of the frame, pairing lanes l and l ^ o for o = R1/4 ... 1.
-    SONO_HD double band_sum(const float *P, const float *meta, const float *zero_row) const
+    SONO_HD double band_sum(const float *P, const float *meta) const
     {
         const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
-        const float nz = meta[kMetaNonZero + frame];
-        const float inv_n = a.inv_n * meta[kMetaGain + frame];
-        const float *row = ((!G::ZERO_ROW || nz != 0.0f) ? P + frame * G::PROW : zero_row) + 4 * l;
+        const float fix = shared_fix(meta);
+        const float *row = P + frame * G::PROW + 4 * l;
         constexpr int NB = R2 / 4, B = LOG_R2 == 6 ? SONO_EPI_BATCH_WIDE : LOG_R1 == 5 ? SONO_EPI_BATCH : SONO_EPI_BATCH_512;
         double acc = 0.0;
         SONO_EPILOGUE_UNROLL
@@ -582,11 +612,10 @@ struct TileLane {
             static_for<0, B>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
                 const unsigned int k0 = (unsigned int)(4 * l + 2 * G::R1 * (m0 + i));
-                float p[4] = {p4[i].x, p4[i].y, p4[i].z, p4[i].w};
-                if (!G::ZERO_ROW) { p[0] *= nz; p[1] *= nz; p[2] *= nz; p[3] *= nz; }
+                const float p[4] = {p4[i].x * fix, p4[i].y, p4[i].z, p4[i].w};
                 static_for<0, 4>([&](auto r_) {
                     constexpr int r = decltype(r_)::value;
-                    const double m = (double)(fast_sqrt(p[r]) * inv_n);
+                    const double m = (double)(fast_sqrt(p[r]) * a.inv_n);
                     const double t = m * m;
                     acc += (k0 + r >= a.band_lo && k0 + r <= a.band_hi) ? t : 0.0;
                 });

@@ -43,20 +43,19 @@ static void run_tiles(const StftArgs &a)
     auto max64 = [](unsigned long long *p, unsigned long long v) { if (v > *p) *p = v; };
     std::vector<tile::TileLane<LOG_R1, LOG_R2, MODE, HOPQ>> lanes;
     for (int l = 0; l < 64; ++l) lanes.emplace_back(a, l);
-    static float rr[64][R2], ri[64][R2], re[64][R2], im[64][R2], ma[64][G::JPL], mb[64][G::JPL];
+    static float rr[64][R2], ri[64][R2], re[64][R2], im[64][R2], ya[64][R2], yb[64][R2], ma[64][G::JPL], mb[64][G::JPL];
     float meta[tile::kMetaFloats];
-    const std::vector<float> zero_row(G::BINS, 0.0f);
     for (unsigned long long t = 0; t < it.n_tiles; ++t) {
         const tile::TileRef tr = g_ragged ? tile::locate<true>(a, it, t) : tile::locate<false>(a, it, t);
         for (int l = 0; l < 64; ++l) lanes[l].load(tr);
-        for (int l = 0; l < 64; ++l) lanes[l].scan(ma[l], mb[l]);
+        for (int l = 0; l < 64; ++l) lanes[l].pass1_dft(a.window, ya[l], yb[l], ma[l], mb[l]);
         for (int h = 0; h < HW; ++h)
             for (int jj = 0; jj < G::JPL; ++jj) {
                 float va = 0.0f, vb = 0.0f;
                 for (int l = R2 * h; l < R2 * h + R2; ++l) { va = std::fmax(va, ma[l][jj]); vb = std::fmax(vb, mb[l][jj]); }
                 for (int l = R2 * h; l < R2 * h + R2; ++l) { ma[l][jj] = va; mb[l][jj] = vb; }
             }
-        for (int l = 0; l < 64; ++l) lanes[l].pass1(a.window, tw.data(), ma[l], mb[l], rr[l], ri[l], meta);
+        for (int l = 0; l < 64; ++l) lanes[l].pass1_rows(tw.data(), ya[l], yb[l], ma[l], mb[l], rr[l], ri[l], meta);
         for (int l = 0; l < 64; ++l) lanes[l].exchange_store(rr[l], img);
         for (int l = 0; l < 64; ++l) lanes[l].exchange_load(img, re[l]);
         for (int l = 0; l < 64; ++l) lanes[l].exchange_store(ri[l], img);
@@ -64,7 +63,7 @@ static void run_tiles(const StftArgs &a)
         for (int l = 0; l < 64; ++l) lanes[l].pass2_power(re[l], im[l], img);
         if (MODE == MODE_BAND) {
             double e[64], e2[64];
-            for (int l = 0; l < 64; ++l) e[l] = lanes[l].band_sum(img, meta, zero_row.data());
+            for (int l = 0; l < 64; ++l) e[l] = lanes[l].band_sum(img, meta);
             for (int o = G::HALF / 2; o > 0; o >>= 1) {
                 for (int l = 0; l < 64; ++l) e2[l] = e[l] + e[l ^ o];
                 std::memcpy(e, e2, sizeof(e));
@@ -73,8 +72,8 @@ static void run_tiles(const StftArgs &a)
             continue;
         }
         for (int l = 0; l < 64; ++l) {
-            if (MODE == MODE_U8 && a.q_floor > 0.0f) lanes[l].template epilogue<true>(tr, img, meta, zero_row.data(), &peak[l >> (LOG_R1 - 1)], max64);
-            else lanes[l].template epilogue<false>(tr, img, meta, zero_row.data(), &peak[l >> (LOG_R1 - 1)], max64);
+            if (MODE == MODE_U8 && a.q_floor > 0.0f) lanes[l].template epilogue<true>(tr, img, meta, &peak[l >> (LOG_R1 - 1)], max64);
+            else lanes[l].template epilogue<false>(tr, img, meta, &peak[l >> (LOG_R1 - 1)], max64);
         }
         for (int l = 0; l < 64; ++l) lanes[l].features(tr, &peak[l >> (LOG_R1 - 1)]);
     }
