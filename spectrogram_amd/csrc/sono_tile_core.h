@@ -112,7 +112,9 @@ constexpr int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 
 // Decimation-in-time butterfly (a, b) -> (a + w b, a - w b), w = W_64^K64.
 // The second output is formed as 2a - (a + w b), which keeps a general butterfly
-// at six fused multiply-adds.
+// at eight operations, six of them fused multiply-adds.  (Written as
+// fma(-w.im, b.im, fma(w.re, b.re, a.re)) it would be six, and the kernel no faster:
+// measured; the form below rounds like the sum of products it stands for.)
 template <int K64>
 SONO_HD void bfly(float &ar, float &ai, float &br, float &bi)
 {
@@ -167,8 +169,9 @@ SONO_HD void dft_bitrev_in(float (&re)[N], float (&im)[N])
 // samples, second half):
 //   X[0] = E0 + O0,  X[M/2] = E0 - O0,  X[M/4] = E[M/4] - i O[M/4]  (all of E0, O0, E[M/4], O[M/4] real),
 //   X[k] = E[k] + W_M^k O[k],  X[M/2-k] = conj(E[k] - W_M^k O[k])   for 0 < k < M/4,
-// 164 operations at N = 32 where the complex transform of a frame pair takes 388
-// and the separation of the two spectra 60 more.  FIRST = 4: the size-2 blocks
+// about 200 operations at N = 32, 400 for the two frames of a pair, where one
+// complex transform of the pair takes 430 and the separation of the two spectra
+// 60 more.  FIRST = 4: the size-2 blocks
 // (v[2j] + v[2j+1], v[2j] - v[2j+1]) have been formed by the caller.
 template <int M, int BASE, int N>
 SONO_HD void rdft_combine(float (&v)[N])
@@ -360,8 +363,13 @@ struct TileLane {
             const float *pa = xs + fa * a.hop, *pb = xs + fb * a.hop;
             static_for<0, G::R1>([&](auto n_) {
                 constexpr int n1 = decltype(n_)::value;
+#ifdef SONO_EXP_NOLOAD      // diagnostic build: what the kernel costs without its sample loads
+                xa[jj * G::R1 + n1] = (float)(lane + n1) * 1e-3f + (float)fa * 1e-9f;
+                if constexpr (n1 >= OWN_B) xb[jj * G::R1 + n1] = (float)(lane - n1) * 1e-3f + (float)fb * 1e-9f;
+#else
                 xa[jj * G::R1 + n1] = pa[R2 * n1];
                 if constexpr (n1 >= OWN_B) xb[jj * G::R1 + n1] = pb[R2 * n1];
+#endif
             });
         });
     }
