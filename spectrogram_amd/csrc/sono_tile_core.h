@@ -232,12 +232,14 @@ struct Geo {
     static constexpr int PPW = 64 / R1;        // frame pairs per wave
     static constexpr int FPW = 2 * PPW;        // frames per wave
     static constexpr int JPL = R2 / R1;        // pass-1 jobs (pairs) per lane
-#ifndef SONO_PAD_FROM
-#define SONO_PAD_FROM 32
-#endif
-    static constexpr int PAD = R1 < SONO_PAD_FROM ? HALF : 0;
-    static constexpr int PROW = BINS + PAD;    // floats per frame in the power image: the pad puts the frames
-                                               // of one 32-lane store group on disjoint banks
+    // Floats per frame in the power image.  The pad puts the frames that one 32-lane
+    // group of pass 2 stores to on disjoint banks (ds_write_b32: 32 banks).  The
+    // epilogue's 16-byte reads go by 64 banks in 16-lane groups that take lanes from
+    // two frames; at R1 = 32 they are conflict-free as well if frame f's lanes take
+    // their bins ROT*f places further round the frame (bin_lane below).
+    static constexpr int PAD = R1 < 64 ? HALF : 0;
+    static constexpr int PROW = BINS + PAD;
+    static constexpr int ROT = R1 == 32 ? PAD / 4 : 0;
     // Inter-pass twiddles W_N^(n2*k1), one row of R2 entries per k1.  Unfolded: rows
     // k1 = 1..R1/2.  Folded (R1 = 64, where the full table would not fit beside
     // eight wave regions): rows k1 = 1..R1/4, then one row of W_N^(n2*R1/2); the
@@ -535,16 +537,21 @@ struct TileLane {
     // |2X|^2).  FLOOR = false leaves out the clamp to q_floor (for q_floor = 0).
     // The bins that came through the pair's shared rows are the multiples of R1/2:
     // the first of a lane's four wherever 4l is one.
-    SONO_HD float shared_fix(const float *meta) const
+    SONO_HD int bin_lane() const       // which quarter-row of four bins per 2*R1 this lane takes (see Geo::ROT)
     {
         const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
+        return (l - G::ROT * frame) & (G::HALF - 1);
+    }
+    SONO_HD float shared_fix(const float *meta) const
+    {
+        const int frame = lane >> (LOG_R1 - 1), l = bin_lane();
         return ((4 * l) & (G::HALF - 1)) == 0 ? meta[kMetaFix + frame] : 1.0f;
     }
     template <bool FLOOR, typename AtomicMax64>
     SONO_HD void epilogue(const TileRef &tr, const float *P, const float *meta,
                           unsigned long long *peak_slot, AtomicMax64 atomic_max64)
     {
-        const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
+        const int frame = lane >> (LOG_R1 - 1), l = bin_lane();
         const unsigned long long f = (unsigned long long)tr.j * G::FPW + (unsigned int)frame;
         const bool valid = f < tr.frames;
         const unsigned long long g = tr.row0 + f;
@@ -605,7 +612,7 @@ struct TileLane {
     // add up the R1/2 lanes of the frame, pairing lanes l and l ^ o for o = R1/4 ... 1.
     SONO_HD double band_sum(const float *P, const float *meta) const
     {
-        const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
+        const int frame = lane >> (LOG_R1 - 1), l = bin_lane();
         const float fix = shared_fix(meta);
         const float *row = P + frame * G::PROW + 4 * l;
         constexpr int NB = R2 / 4, B = LOG_R2 == 6 ? SONO_EPI_BATCH_WIDE : LOG_R1 == 5 ? SONO_EPI_BATCH : SONO_EPI_BATCH_512;
