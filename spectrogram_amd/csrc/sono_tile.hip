@@ -71,9 +71,33 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP(i) do { } while (0)
 #endif
 
-struct LdsMax64 {
-    __device__ void operator()(unsigned long long *p, unsigned long long v) const { atomicMax(p, v); }
-};
+// Maximum of a 64-bit key over each group of 2^LOG_LANES consecutive lanes (4 ... 32), in every
+// lane of the group, by data-parallel-primitive moves: no LDS round trip.
+template <int CTRL>
+__device__ __forceinline__ unsigned long long max_with_dpp(unsigned long long v)
+{
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_mov_dpp((int)(unsigned int)v, CTRL, 0xf, 0xf, true);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_mov_dpp((int)(unsigned int)(v >> 32), CTRL, 0xf, 0xf, true);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    return o > v ? o : v;
+}
+template <int LOG_LANES>
+__device__ __forceinline__ unsigned long long group_max(unsigned long long v)
+{
+    static_assert(LOG_LANES >= 2 && LOG_LANES <= 5, "groups of 4 to 32 lanes");
+    if constexpr (LOG_LANES >= 4) v = max_with_dpp<0x140>(v);     // row_mirror: lane i <-> 15 - i
+    if constexpr (LOG_LANES >= 3) v = max_with_dpp<0x141>(v);     // row_half_mirror: i <-> 7 - i inside each half row
+    v = max_with_dpp<0x4E>(v);                                    // quad_perm [2,3,0,1]
+    v = max_with_dpp<0xB1>(v);                                    // quad_perm [1,0,3,2]
+    if constexpr (LOG_LANES == 5) {
+        // rows 0/1 and 2/3 trade places
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned int)v, (unsigned int)v, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned int)(v >> 32), (unsigned int)(v >> 32), false, false);
+        const unsigned long long x = ((unsigned long long)hi[0] << 32) | lo[0], y = ((unsigned long long)hi[1] << 32) | lo[1];
+        v = x > y ? x : y;
+    }
+    return v;
+}
 
 // Orders this wave's LDS writes before its later LDS reads of other lanes' data.
 // LDS operations of one wave execute in issue order, so no instruction is
@@ -118,7 +142,6 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
     __shared__ __align__(16) float s_img[kWavesPerBlock * G::REGION];
     __shared__ __align__(16) float2 s_tw[G::TW_ROWS * R2];
     __shared__ __align__(16) float s_win[G::N];
-    __shared__ unsigned long long s_peak[kWavesPerBlock * 16];
     __shared__ unsigned int s_next;
     __shared__ float s_meta[kWavesPerBlock * tile::kMetaFloats];
 
@@ -126,13 +149,11 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = threadIdx.x; i < G::TW_ROWS * R2; i += blockDim.x) s_tw[i] = tw_rows[i];
     for (int i = threadIdx.x; i < G::N; i += blockDim.x) s_win[i] = a.window[i];
-    if (threadIdx.x < kWavesPerBlock * 16) s_peak[threadIdx.x] = peak_key(0.0f, 0u);
     if (threadIdx.x == 0) s_next = 0u;
     __syncthreads();
 
     float *img = s_img + wave * G::REGION;
     float *meta = s_meta + wave * tile::kMetaFloats;
-    unsigned long long *peak_slot = s_peak + wave * 16 + (lane >> (LOG_R1 - 1));
 
     // This workgroup's share of the tiles.  The launch is cut into one contiguous
     // range per XCD; inside a range, groups of kWavesPerBlock consecutive tiles are
@@ -199,12 +220,10 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
             for (int o = G::HALF / 2; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
             L.band_emit(tr, e);
         } else {
-            if (MODE == MODE_U8 && a.q_floor > 0.0f) L.template epilogue<true>(tr, img, meta, peak_slot, LdsMax64());
-            else L.template epilogue<false>(tr, img, meta, peak_slot, LdsMax64());
-        }
-        if (MODE == MODE_U8) {
-            wave_lds_fence();
-            L.features(tr, peak_slot);
+            unsigned long long key;
+            if (MODE == MODE_U8 && a.q_floor > 0.0f) key = L.template epilogue<true>(tr, img, meta);
+            else key = L.template epilogue<false>(tr, img, meta);
+            if (MODE == MODE_U8) L.features(tr, group_max<LOG_R1 - 1>(key));
         }
         wave_lds_fence();
         STAMP(4);

@@ -533,8 +533,8 @@ struct TileLane {
     }
 
     // Epilogue: lane (frame, l) owns bins 4l + 2*R1*m + r (m < R2/4, r < 4) of its frame.
-    // `peak_slot` is the LDS word of the lane's frame (ordering key of its largest
-    // |2X|^2).  FLOOR = false leaves out the clamp to q_floor (for q_floor = 0).
+    // Returns the ordering key (peak_key) of the largest |2X|^2 among this lane's bins;
+    // the caller takes the maximum over the frame's R1/2 lanes (MODE_U8).  FLOOR = false leaves out the clamp to q_floor (for q_floor = 0).
     // The bins that came through the pair's shared rows are the multiples of R1/2:
     // the first of a lane's four wherever 4l is one.
     SONO_HD int bin_lane() const       // which quarter-row of four bins per 2*R1 this lane takes (see Geo::ROT)
@@ -547,9 +547,8 @@ struct TileLane {
         const int frame = lane >> (LOG_R1 - 1), l = bin_lane();
         return ((4 * l) & (G::HALF - 1)) == 0 ? meta[kMetaFix + frame] : 1.0f;
     }
-    template <bool FLOOR, typename AtomicMax64>
-    SONO_HD void epilogue(const TileRef &tr, const float *P, const float *meta,
-                          unsigned long long *peak_slot, AtomicMax64 atomic_max64)
+    template <bool FLOOR>
+    SONO_HD unsigned long long epilogue(const TileRef &tr, const float *P, const float *meta)
     {
         const int frame = lane >> (LOG_R1 - 1), l = bin_lane();
         const unsigned long long f = (unsigned long long)tr.j * G::FPW + (unsigned int)frame;
@@ -567,7 +566,7 @@ struct TileLane {
         // behind whatever bursts the other waves have queued.
         constexpr int NB = R2 / 4, B = LOG_R2 == 6 ? SONO_EPI_BATCH_WIDE : LOG_R1 == 5 ? SONO_EPI_BATCH : SONO_EPI_BATCH_512;
         static_assert(NB % B == 0, "the epilogue batch must divide the reads per lane");
-        if (!valid) return;          // lanes of frames past the end of the stream have nothing to store
+        if (!valid) return peak_key(0.0f, 0u);          // lanes of frames past the end of the stream have nothing to store
         SONO_EPILOGUE_UNROLL
         for (int m0 = 0; m0 < NB; m0 += B) {
             float4 p4[B];
@@ -602,8 +601,9 @@ struct TileLane {
             const int r = w[0] == best_p ? 0 : w[1] == best_p ? 1 : w[2] == best_p ? 2 : 3;
             const unsigned int best_k = best_p > 0.0f ? (unsigned int)(4 * l + 2 * G::R1 * best_m + r) : 0u;
             run_max = best_p > run_max ? best_p : run_max;
-            atomic_max64(peak_slot, peak_key(best_p, best_k));
+            return peak_key(best_p, best_k);
         }
+        return peak_key(0.0f, 0u);
     }
 
     // MODE_BAND epilogue, step 1: this lane's share of its frame's band energy --
@@ -650,15 +650,13 @@ struct TileLane {
         if (a.band_energy) a.band_energy[g] = total;
     }
 
-    // After every lane of the frame has contributed: the frame's first lane emits
-    // the features and clears the slot for the next tile.
-    SONO_HD void features(const TileRef &tr, unsigned long long *peak_slot) const
+    // `key` = the largest of the epilogue's keys over the frame's lanes: the frame's
+    // first lane emits the features.
+    SONO_HD void features(const TileRef &tr, unsigned long long key) const
     {
         const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
         if (MODE != MODE_U8 || l != 0) return;
         const unsigned long long f = (unsigned long long)tr.j * G::FPW + (unsigned int)frame;
-        const unsigned long long key = *peak_slot;
-        *peak_slot = peak_key(0.0f, 0u);
         if (f >= tr.frames) return;
         const unsigned long long g = tr.row0 + f;
         unsigned int bits = (unsigned int)(key >> 32);

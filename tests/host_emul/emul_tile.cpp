@@ -38,9 +38,6 @@ static void run_tiles(const StftArgs &a)
     }
     const std::vector<float2> tw = make_tile_twiddles(a.N, R2);
     alignas(16) static float img[G::REGION];
-    unsigned long long peak[16];
-    for (auto &p : peak) p = peak_key(0.0f, 0u);
-    auto max64 = [](unsigned long long *p, unsigned long long v) { if (v > *p) *p = v; };
     std::vector<tile::TileLane<LOG_R1, LOG_R2, MODE, HOPQ>> lanes;
     for (int l = 0; l < 64; ++l) lanes.emplace_back(a, l);
     static float rr[64][R2], ri[64][R2], re[64][R2], im[64][R2], ya[64][R2], yb[64][R2], ma[64][G::JPL], mb[64][G::JPL];
@@ -71,11 +68,17 @@ static void run_tiles(const StftArgs &a)
             for (int l = 0; l < 64; ++l) lanes[l].band_emit(tr, e[l]);
             continue;
         }
+        unsigned long long key[64], best[64];
         for (int l = 0; l < 64; ++l) {
-            if (MODE == MODE_U8 && a.q_floor > 0.0f) lanes[l].template epilogue<true>(tr, img, meta, &peak[l >> (LOG_R1 - 1)], max64);
-            else lanes[l].template epilogue<false>(tr, img, meta, &peak[l >> (LOG_R1 - 1)], max64);
+            if (MODE == MODE_U8 && a.q_floor > 0.0f) key[l] = lanes[l].template epilogue<true>(tr, img, meta);
+            else key[l] = lanes[l].template epilogue<false>(tr, img, meta);
         }
-        for (int l = 0; l < 64; ++l) lanes[l].features(tr, &peak[l >> (LOG_R1 - 1)]);
+        for (int l = 0; l < 64; ++l) {                      // maximum over the lanes of each frame
+            const int f0 = l & ~(G::HALF - 1);
+            best[l] = key[f0];
+            for (int m = f0; m < f0 + G::HALF; ++m) best[l] = key[m] > best[l] ? key[m] : best[l];
+        }
+        for (int l = 0; l < 64; ++l) lanes[l].features(tr, best[l]);
     }
     if (MODE == MODE_U8 && a.gmax_bits) {
         float m = 0.0f;
