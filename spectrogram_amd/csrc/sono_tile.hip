@@ -194,9 +194,7 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
             {
                 float ya[R2], yb[R2], pa[G::JPL], pb[G::JPL];
                 L.pass1_dft(s_win, ya, yb, pa, pb);
-#ifndef SONO_EXP_NO_SB1
                 __builtin_amdgcn_sched_barrier(0);     // keeps the twiddle reads (60 registers) below the transforms
-#endif
                 for (int jj = 0; jj < G::JPL; ++jj) { pa[jj] = column_max<LOG_R2>(pa[jj]); pb[jj] = column_max<LOG_R2>(pb[jj]); }
                 L.pass1_rows(s_tw, ya, yb, pa, pb, rr, ri, meta);
             }
