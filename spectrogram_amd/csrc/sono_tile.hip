@@ -17,6 +17,7 @@
 // from HBM once per XCD.
 #include "sono_tile.h"
 
+#include <cstdlib>
 #include <vector>
 
 #include "sono_tables.h"
@@ -279,8 +280,10 @@ hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, const RaggedPlan
     const dim3 grid((unsigned int)blocks), block(64 * kWavesPerBlock);
     // The hops that let frame B reuse frame A's loads: a quarter frame (75 % overlap) for
     // the row and magnitude modes, half a frame (the fast scan's 50 %) for the band mode.
+    // SONO_FORCE_ANY_HOP=1 (read per launch) takes the any-hop form regardless: the tests compare the two.
     constexpr int kHopQ = MODE == MODE_BAND ? 2 : 1;
-    const bool q = a.hop * (kHopQ == 2 ? 2u : 4u) == (unsigned int)G::N;
+    const char *any_hop = std::getenv("SONO_FORCE_ANY_HOP");
+    const bool q = a.hop * (kHopQ == 2 ? 2u : 4u) == (unsigned int)G::N && !(any_hop && any_hop[0] && any_hop[0] != '0');
     if (plan) {
         if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, true, kHopQ>), grid, block, 0, stream, a, it, tw_rows);
         else hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, true, 0>), grid, block, 0, stream, a, it, tw_rows);

@@ -445,3 +445,27 @@ def test_ragged_launches_back_to_back_keep_their_own_tables():
     for order, out in zip(orders, outs):
         assert np.array_equal(out.cpu().numpy(), np.concatenate([single[i] for i in order]))
     e.free()
+
+
+@pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096])
+def test_shared_loads_change_nothing(monkeypatch, N):
+    # hop = N/4: frame B takes the rows it shares with frame A from A's registers instead of loading them again;
+    # SONO_FORCE_ANY_HOP=1 (read per launch) selects the form that loads both frames whole -- identical bits
+    V, H = N - N // 4, N // 4
+    x = signal(N + 41 * H + 5, N + 1)
+    x[: N + H] = 0.0
+    x[N + 6 * H: N + 7 * H] *= 300.0                      # a burst that only some frames see
+    res = []
+    for any_hop in (False, True):
+        if any_hop:
+            monkeypatch.setenv("SONO_FORCE_ANY_HOP", "1")
+        else:
+            monkeypatch.delenv("SONO_FORCE_ANY_HOP", raising=False)
+        e = sa.SpectrogramEngine(N, "hann")
+        u8 = e.compute_spectrogram_u8(x, V, 20.0, 80.0)
+        res.append((e.compute_spectrogram(x, V), u8, e.get_peaks(0.0), e.get_peak_magnitudes(0.0), np.float32(e.get_global_max())))
+        e.free()
+    monkeypatch.delenv("SONO_FORCE_ANY_HOP", raising=False)
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    assert res[0][1].any()
