@@ -108,6 +108,8 @@ WORKLOADS = {
     "cfg3": dict(fft=1024, window="hann", alpha=None, noverlap=768, sr=500000),
     "cfg4": dict(fft=4096, window="blackman", alpha=0.16, noverlap=3891, sr=384000),
     "cfg5": dict(fft=1024, window="hann", alpha=None, noverlap=768, sr=384000),
+    # cfg2 on the recording as a WAV file holds it: 16-bit PCM in HBM, converted in the STFT kernel's loads
+    "cfg2_pcm16": dict(fft=1024, window="hann", alpha=None, noverlap=768, sr=384000),
 }
 FILE_SAMPLES = 2500000          # cfg3: 5 s at 500 kHz
 
@@ -154,7 +156,7 @@ def main():
         n_streams, per = len(my_files), FILE_SAMPLES
         seconds = per / sr
     else:
-        seconds = args.seconds or {"cfg2": SECONDS, "cfg4": 600, "cfg5": 12 * 3600}[args.workload]
+        seconds = args.seconds or {"cfg2": SECONDS, "cfg2_pcm16": SECONDS, "cfg4": 600, "cfg5": 12 * 3600}[args.workload]
         n_streams, per = 1, int(seconds * sr)
     n = n_streams * per
     frames_per_stream = sa.frames_for(per, n_fft, noverlap)
@@ -166,7 +168,10 @@ def main():
     peak_mag = torch.empty(frames, dtype=torch.float32, device="cuda")
     gmax = torch.zeros(1, dtype=torch.int32, device="cuda")
     features_only = args.workload == "cfg5"
-    bytes_per_frame = 4 * hop + (0 if features_only else bins) + 6
+    pcm16 = args.workload == "cfg2_pcm16"
+    if pcm16:
+        x = torch.clamp(torch.round(x * 32768.0), -32768, 32767).to(torch.int16)
+    bytes_per_frame = (2 if pcm16 else 4) * hop + (0 if features_only else bins) + 6
     if not features_only:
         out = torch.empty(frames * bins, dtype=torch.uint8, device="cuda")
     else:
@@ -185,6 +190,10 @@ def main():
     def step():
         with torch.cuda.stream(stream):
             gmax.zero_()
+        if pcm16:
+            engine.stft_u8_pcm16_dev(x.data_ptr(), n_streams, per, per, 1, 0, noverlap, GAIN_DB, RANGE_DB, out.data_ptr(),
+                                     peak_bin.data_ptr(), peak_mag.data_ptr(), gmax.data_ptr(), stream.cuda_stream)
+            return
         if not features_only:
             engine.stft_u8_dev(x.data_ptr(), n_streams, per, per, noverlap, GAIN_DB, RANGE_DB, out.data_ptr(),
                                peak_bin.data_ptr(), peak_mag.data_ptr(), gmax.data_ptr(), stream.cuda_stream)
@@ -241,6 +250,8 @@ def main():
         what = {
             "cfg2": f"{seconds:g} s synthetic {sr} Hz mono FM-chirp recording per GPU, FFT {n_fft} Hann, 75% overlap (hop {hop}), "
                     f"uint8 dB frames + per-frame peak bin/magnitude + global max, {frames} frames per GPU, samples resident in HBM",
+            "cfg2_pcm16": f"{seconds:g} s synthetic {sr} Hz mono recording per GPU as 16-bit PCM in HBM (converted in the STFT kernel's "
+                          f"loads), FFT {n_fft} Hann, 75% overlap (hop {hop}), uint8 dB frames + peaks, {frames} frames per GPU",
             "cfg3": f"{args.files} synthetic 5 s {sr} Hz files ({frames_per_stream} frames each) dealt round-robin to {world} GPU(s), "
                     f"one launch per GPU over its files, FFT {n_fft} Hann, 75% overlap, uint8 dB frames + peaks",
             "cfg4": f"{seconds:g} s synthetic {sr} Hz recording per GPU, FFT {n_fft} Blackman(0.16), 95% overlap (hop {hop}), "
@@ -259,7 +270,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.workload == "cfg3" else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32",                      # the arithmetic type; cfg2_pcm16 reads int16 and computes in f32
             "data": "synthetic",
             "audio_s_per_s": total_frames * hop / sr * args.steps / wall_max,
             "config": {

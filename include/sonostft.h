@@ -149,6 +149,18 @@ int sono_stft_u8_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap,
                      uint8_t *d_out, uint16_t *d_peak_bin, float *d_peak_mag,
                      uint32_t *d_gmax_bits, void *hip_stream);
 
+/* sono_stft_u8_dev on 16-bit PCM as it lies in a WAV data chunk (fileLoader.js:7-63 walks the
+ * chunks; the browser's decoder then turns the integers into value / 32768): d_pcm holds interleaved
+ * sample frames of `channels` int16 values; stream s starts at sample frame s*stream_stride and has
+ * samples_per_stream sample frames; `channel` is transformed.  The conversion happens in the STFT
+ * kernel's loads, so no f32 copy of the recording exists (2 B instead of 4 B read per sample, half
+ * the HBM footprint); every output equals, bit for bit, sono_pcm_to_f32_dev followed by
+ * sono_stft_u8_dev.  d_out may be NULL (features only).  No wasm counterpart. */
+int sono_stft_u8_pcm16_dev(sono_engine *e, const int16_t *d_pcm, size_t n_streams, size_t stream_stride,
+                           size_t samples_per_stream, uint32_t channels, uint32_t channel, uint32_t noverlap,
+                           float gain_db, float range_db, uint8_t *d_out, uint16_t *d_peak_bin,
+                           float *d_peak_mag, uint32_t *d_gmax_bits, void *hip_stream);
+
 /* The per-frame features of sono_stft_u8_dev without the u8 rows: peak bin
  * (lib.rs:370-378: first maximum), peak magnitude and the running global maximum
  * (lib.rs:261-266) of every frame of a batch.  For survey-scale passes (a whole

@@ -183,6 +183,9 @@ _SIGNATURES = {
                                          C.c_float, C.c_float, _u8p, C.c_size_t]),
     "sono_stft_u8_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_float, C.c_float,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sono_stft_u8_pcm16_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
     "sono_stft_mag_f32_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_void_p, C.c_void_p]),
     "sono_stft_features_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),
@@ -461,6 +464,16 @@ class SpectrogramEngine:
         _check(lib().sono_stft_u8_dev(self._handle(), C.byref(b), int(noverlap), float(gain_db), float(range_db),
                                       d_out, d_peak_bin or None, d_peak_mag or None, d_gmax_bits or None,
                                       stream or None))
+
+    def stft_u8_pcm16_dev(self, d_pcm, n_streams, stream_stride, samples_per_stream, channels, channel, noverlap,
+                          gain_db, range_db, d_out=0, d_peak_bin=0, d_peak_mag=0, d_gmax_bits=0, stream=0):
+        """stft_u8_dev on interleaved 16-bit PCM sample frames in HBM (a WAV data chunk as it is): the
+        conversion to value / 32768 happens in the kernel's loads.  Strides and lengths count sample frames.
+        d_out = 0: features only."""
+        _check(lib().sono_stft_u8_pcm16_dev(self._handle(), d_pcm, int(n_streams), int(stream_stride),
+                                            int(samples_per_stream), int(channels), int(channel), int(noverlap),
+                                            float(gain_db), float(range_db), d_out or None, d_peak_bin or None,
+                                            d_peak_mag or None, d_gmax_bits or None, stream or None))
 
     def stft_features_dev(self, d_samples, n_streams, stream_stride, samples_per_stream, noverlap,
                           d_peak_bin=0, d_peak_mag=0, d_gmax_bits=0, stream=0):

@@ -283,6 +283,37 @@ int sono_stft_u8_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap, fl
     return SONO_OK;
 }
 
+int sono_stft_u8_pcm16_dev(sono_engine *e, const int16_t *d_pcm, size_t n_streams, size_t stream_stride,
+                           size_t samples_per_stream, uint32_t channels, uint32_t channel, uint32_t noverlap,
+                           float gain_db, float range_db, uint8_t *d_out, uint16_t *d_peak_bin,
+                           float *d_peak_mag, uint32_t *d_gmax_bits, void *hip_stream)
+{
+    const char *who = "sono_stft_u8_pcm16_dev";
+    if (!e) return fail(SONO_EINVAL, std::string(who) + ": NULL argument");
+    if (noverlap >= e->N) return fail(SONO_EINVAL, std::string(who) + ": noverlap must be < fft_size");
+    if (channels == 0 || channel >= channels) return fail(SONO_EINVAL, std::string(who) + ": channel out of range");
+    if (n_streams && samples_per_stream && !d_pcm) return fail(SONO_EINVAL, std::string(who) + ": d_pcm is NULL");
+    if (n_streams > 1 && stream_stride < samples_per_stream)
+        return fail(SONO_EINVAL, std::string(who) + ": stream_stride < samples_per_stream");
+    if (!d_out && !d_peak_bin && !d_peak_mag && !d_gmax_bits)
+        return fail(SONO_EINVAL, std::string(who) + ": every output is NULL");
+    sono_batch in;
+    in.d_samples = nullptr; in.n_streams = n_streams; in.stream_stride = stream_stride; in.samples_per_stream = samples_per_stream;
+    sono::StftArgs a;
+    fill_args(e, in, noverlap, a);
+    if (a.n_streams * a.frames_per_stream == 0) return SONO_OK;
+    a.x16 = d_pcm; a.x16_channels = channels; a.x16_channel = channel;
+    const sono::Quant q = sono::make_quant(e->N, gain_db, range_db);
+    a.out_u8 = d_out; a.peak_bin = d_peak_bin; a.peak_mag = d_peak_mag; a.gmax_bits = d_gmax_bits;
+    a.q_a = q.a; a.q_c = q.c; a.q_floor = q.floor;
+    if (!sono::tile_supports(sono::MODE_U8, a, e->tables.tile))
+        return fail(SONO_EINVAL, std::string(who) + ": needs fft_size 256, 512, 1024, 2048 or 4096 and a 4-byte aligned d_out");
+    DeviceGuard guard(e->device);
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    HIP_TRY(sono::launch_stft_tile(sono::MODE_U8, a, e->tables.tile, s));
+    return SONO_OK;
+}
+
 int sono_stft_features_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap, uint16_t *d_peak_bin,
                            float *d_peak_mag, uint32_t *d_gmax_bits, void *hip_stream)
 {

@@ -133,7 +133,8 @@ __device__ __forceinline__ float column_max(float v)
 
 // RAGGED: streams of different lengths, located through TileIter's tables.
 // HOPQ: 1 / 2 = the launch's hop is N/4 / N/2 (frame B reuses frame A's loads), 0 = any hop.
-template <int LOG_R1, int LOG_R2, int MODE, bool RAGGED, int HOPQ>
+// PCM: 16-bit integer samples (StftArgs::x16) instead of f32.
+template <int LOG_R1, int LOG_R2, int MODE, bool RAGGED, int HOPQ, bool PCM = false>
 __global__ __launch_bounds__((64 * Occupancy<LOG_R1, LOG_R2>::kWavesPerBlock), (Occupancy<LOG_R1, LOG_R2>::kWavesPerSimd))
 void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *tw_rows)
 {
@@ -149,7 +150,7 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = threadIdx.x; i < G::TW_ROWS * R2; i += blockDim.x) s_tw[i] = tw_rows[i];
-    for (int i = threadIdx.x; i < G::N; i += blockDim.x) s_win[i] = a.window[i];
+    for (int i = threadIdx.x; i < G::N; i += blockDim.x) s_win[i] = PCM ? a.window[i] * (1.0f / 32768.0f) : a.window[i];
     if (threadIdx.x == 0) s_next = 0u;
     __syncthreads();
 
@@ -168,7 +169,7 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
     const unsigned int blocks_in_part = (gridDim.x - part + parts - 1) / parts;
     const unsigned long long t_first = it.n_tiles * part / parts;
     const unsigned long long t_count = it.n_tiles * (part + 1) / parts - t_first;
-    tile::TileLane<LOG_R1, LOG_R2, MODE, HOPQ> L(a, lane);
+    tile::TileLane<LOG_R1, LOG_R2, MODE, HOPQ, PCM> L(a, lane);
     auto claim = [&]() -> unsigned long long {          // -> index of the claimed tile inside the range
         unsigned int c = 0;
         if (lane == 0) c = atomicAdd(&s_next, 1u);
@@ -284,6 +285,14 @@ hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, const RaggedPlan
     constexpr int kHopQ = MODE == MODE_BAND ? 2 : 1;
     const char *any_hop = std::getenv("SONO_FORCE_ANY_HOP");
     const bool q = a.hop * (kHopQ == 2 ? 2u : 4u) == (unsigned int)G::N && !(any_hop && any_hop[0] && any_hop[0] != '0');
+    if (a.x16 && (plan || MODE != MODE_U8)) return hipErrorInvalidValue;
+    if constexpr (MODE == MODE_U8) {
+        if (a.x16) {        // 16-bit PCM input: uniform batches of the row mode only (tile_supports)
+            if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, kHopQ, true>), grid, block, 0, stream, a, it, tw_rows);
+            else hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, 0, true>), grid, block, 0, stream, a, it, tw_rows);
+            return hipGetLastError();
+        }
+    }
     if (plan) {
         if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, true, kHopQ>), grid, block, 0, stream, a, it, tw_rows);
         else hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, true, 0>), grid, block, 0, stream, a, it, tw_rows);
@@ -345,6 +354,7 @@ void tile_tables_release(TileTables &t) { if (t.d_blob) (void)hipFree(t.d_blob);
 bool tile_supports(int mode, const StftArgs &a, const TileTables &t)
 {
     if (mode != MODE_MAG && mode != MODE_U8 && mode != MODE_BAND) return false;
+    if (a.x16 && (mode != MODE_U8 || a.x16_channels == 0 || a.x16_channel >= a.x16_channels)) return false;
     if (mode == MODE_BAND && (!a.band_active || a.band_hi >= a.N / 2 || a.band_lo > a.band_hi)) return false;
     if (a.N != 4096 && a.N != 2048 && a.N != 1024 && a.N != 512 && a.N != 256) return false;
     if (!t.d_blob || t.N != a.N) return false;

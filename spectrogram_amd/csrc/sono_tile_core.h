@@ -295,7 +295,8 @@ struct TileIter {
 };
 // Where one tile reads and writes.
 struct TileRef {
-    const float *xs;                   // sample 0 of the tile's stream
+    const float *xs;                   // sample 0 of the tile's stream (f32 input)
+    unsigned long long xs_off;         // the same as an offset from the start of the input, in samples (sample frames)
     unsigned long long frames;         // frames of that stream
     unsigned long long row0;           // output row of the stream's frame 0
     unsigned int j;                    // the tile's index inside the stream
@@ -307,12 +308,14 @@ SONO_HD TileRef locate(const StftArgs &a, const TileIter &it, unsigned long long
     if (RAGGED) {
         const RaggedStream st = it.streams[it.tile_stream[tile]];
         r.xs = a.x + st.sample_offset;
+        r.xs_off = st.sample_offset;
         r.frames = st.frames;
         r.row0 = st.row0;
         r.j = (unsigned int)(tile - st.tile0);
     } else {
         const unsigned long long s = tile / it.tiles_per_stream;
         r.xs = a.x + s * a.stream_stride;
+        r.xs_off = s * a.stream_stride;
         r.frames = a.frames_per_stream;
         r.row0 = s * a.frames_per_stream;
         r.j = (unsigned int)(tile - s * it.tiles_per_stream);
@@ -322,7 +325,10 @@ SONO_HD TileRef locate(const StftArgs &a, const TileIter &it, unsigned long long
 
 // ---- one lane of one wave ------------------------------------------------------
 // HOPQ: 0 = any hop; 1 = the hop is N/4; 2 = the hop is N/2 (see "hop" above).
-template <int LOG_R1, int LOG_R2, int MODE, int HOPQ = 0>
+// PCM: the samples are 16-bit integers (StftArgs::x16), loaded and converted in
+// place of the f32 loads; their factor 1/32768 rides in the window table the
+// caller passes, which gives the same bits as f32 samples value/32768 would.
+template <int LOG_R1, int LOG_R2, int MODE, int HOPQ = 0, bool PCM = false>
 struct TileLane {
     using G = Geo<LOG_R1, LOG_R2>;
     static constexpr int R2 = G::R2;
@@ -362,6 +368,17 @@ struct TileLane {
             unsigned long long fb = fa + 1;
             if (fa >= tr.frames) fa = 0;
             if (fb >= tr.frames) fb = 0;
+            if constexpr (PCM) {
+                const unsigned long long c = a.x16_channels, row = (unsigned long long)R2 * c;
+                const int16_t *qa = a.x16 + (tr.xs_off + (unsigned int)n2 + fa * a.hop) * c + a.x16_channel;
+                const int16_t *qb = a.x16 + (tr.xs_off + (unsigned int)n2 + fb * a.hop) * c + a.x16_channel;
+                static_for<0, G::R1>([&](auto n_) {
+                    constexpr int n1 = decltype(n_)::value;
+                    xa[jj * G::R1 + n1] = (float)qa[row * n1];
+                    if constexpr (n1 >= OWN_B) xb[jj * G::R1 + n1] = (float)qb[row * n1];
+                });
+                return;
+            }
             const float *pa = xs + fa * a.hop, *pb = xs + fb * a.hop;
             static_for<0, G::R1>([&](auto n_) {
                 constexpr int n1 = decltype(n_)::value;

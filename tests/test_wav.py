@@ -89,3 +89,59 @@ def test_wav_to_u8_frames_equals_float_input():
     assert np.array_equal(e.compute_spectrogram_u8(x, 256, 20.0, 80.0),
                           e.compute_spectrogram_u8(x16.astype(np.float32) / 32768, 256, 20.0, 80.0))
     e.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,V,channels,channel", [(1024, 768, 1, 0), (1024, 700, 2, 1), (256, 192, 2, 0), (512, 256, 1, 0),
+                                                  (2048, 1536, 3, 2), (4096, 3891, 1, 0)])
+def test_pcm16_frames_in_hbm_equal_convert_then_stft(N, V, channels, channel):
+    # the STFT kernel reading the WAV data chunk's int16 sample frames itself (no f32 copy of the recording)
+    # against sono_pcm_to_f32_dev followed by sono_stft_u8_dev: every output bit for bit
+    import torch
+    H, B, S = N - V, N // 2, 3
+    per = N + 29 * H + 3                                     # sample frames per stream; the last tile is partial
+    stride = per + 7
+    rng = np.random.default_rng(N + channels)
+    t = np.arange(S * stride)
+    pcm = np.zeros((S * stride, channels), np.int16)
+    for c in range(channels):
+        pcm[:, c] = np.round(9000 * np.sin((0.2 + 0.05 * c) * t + 1e-5 * t * t) + 30 * rng.standard_normal(t.size)).astype(np.int16)
+    pcm[: N + H, channel] = 0                                # all-zero frames
+    pcm[N + 6 * H: N + 7 * H, channel] = 32767               # a burst only some frames see; full scale
+    pcm[N + 9 * H, channel] = -32768
+    d_pcm = torch.from_numpy(pcm.reshape(-1)).cuda()
+    e = sa.SpectrogramEngine(N, "hann")
+    F = sa.frames_for(per, N, V)
+    T = S * F
+
+    def outputs():
+        return (torch.full((T * B,), 77, dtype=torch.uint8, device="cuda"), torch.zeros(T, dtype=torch.int16, device="cuda"),
+                torch.zeros(T, dtype=torch.float32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda"))
+
+    # reference composition: convert the whole buffer's channel, then the f32 kernel
+    d_x = torch.zeros(S * stride, dtype=torch.float32, device="cuda")
+    sa._check(sa.lib().sono_pcm_to_f32_dev(e._handle(), d_pcm.data_ptr(), S * stride, channels, channel, 16, 0, d_x.data_ptr(), None))
+    want = outputs()
+    e.stft_u8_dev(d_x.data_ptr(), S, stride, per, V, 20.0, 80.0, want[0].data_ptr(), want[1].data_ptr(), want[2].data_ptr(),
+                  want[3].data_ptr())
+    got = outputs()
+    e.stft_u8_pcm16_dev(d_pcm.data_ptr(), S, stride, per, channels, channel, V, 20.0, 80.0, got[0].data_ptr(), got[1].data_ptr(),
+                        got[2].data_ptr(), got[3].data_ptr())
+    e.synchronize()
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    assert int(want[0].max()) > 0 and not bool(want[0][: 2 * B].any())
+    # features only, and argument checks
+    feat = outputs()
+    e.stft_u8_pcm16_dev(d_pcm.data_ptr(), S, stride, per, channels, channel, V, 20.0, 80.0, 0, feat[1].data_ptr(), feat[2].data_ptr(),
+                        feat[3].data_ptr())
+    e.synchronize()
+    assert torch.equal(feat[1], want[1]) and torch.equal(feat[2], want[2]) and torch.equal(feat[3], want[3])
+    with pytest.raises(sa.SonoError):
+        e.stft_u8_pcm16_dev(d_pcm.data_ptr(), S, stride, per, channels, channels, V, 20.0, 80.0, got[0].data_ptr())
+    with pytest.raises(sa.SonoError):
+        e.stft_u8_pcm16_dev(d_pcm.data_ptr(), S, stride, per, channels, channel, N, 20.0, 80.0, got[0].data_ptr())
+    with pytest.raises(sa.SonoError):
+        e.stft_u8_pcm16_dev(d_pcm.data_ptr(), S, stride, per, channels, channel, V, 20.0, 80.0)
+    e.free()
