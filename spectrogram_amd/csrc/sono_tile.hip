@@ -1,23 +1,7 @@
-// sono_tile.hip -- register-tiled fused STFT kernel for fft sizes 256 ... 4096.
-//
-// Persistent waves.  A workgroup is a set of independent waves, each owning a
-// private LDS region that is first the pass-1 -> pass-2 exchange image and then
-// the bin-major power image; the only data shared inside a workgroup are the
-// read-only window and inter-pass twiddle tables and the tile counter.  One workgroup per CU.  N <= 1024 (32 values per lane and pass): twelve
-// waves, i.e. three per SIMD (sixteen, four per SIMD and at most 128 VGPRs per lane,
-// at N = 1024), 8.25 KB regions.  N >= 2048 (64 values per lane and pass): eight
-// waves, two per SIMD and up to 256 VGPRs, 16 KB regions.  Enough waves to keep
-// the vector ALU issuing while others sit in LDS or memory waits, without
-// register spills.
-//
-// Tile walk: the tiles of a launch are cut into one contiguous range per XCD
-// (workgroups are dealt round-robin to the eight XCDs), and inside a range the
-// resident waves sweep forward together, so the 75 % of a tile's samples that it
-// shares with its neighbours is served by that XCD's L2 instead of being fetched
-// from HBM once per XCD.
+// sono_tile.hip -- host side of the register-tiled STFT kernel: twiddle tables, which launches it
+// serves, dispatch to the per-mode translation units.
 #include "sono_tile.h"
 
-#include <cstdlib>
 #include <vector>
 
 #include "sono_tables.h"
@@ -25,318 +9,26 @@
 
 namespace sono {
 
+hipError_t launch_tile_u8(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, hipStream_t stream);
+hipError_t launch_tile_mag(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, hipStream_t stream);
+hipError_t launch_tile_band(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, hipStream_t stream);
+
 namespace {
 
-// Overridable so that tools/expbuild.sh can sweep occupancy.
-#ifndef SONO_WPB
-#define SONO_WPB 12
-#endif
-#ifndef SONO_WPS
-#define SONO_WPS 3
-#endif
-#ifndef SONO_WPB_1024
-#define SONO_WPB_1024 16
-#endif
-#ifndef SONO_WPS_1024
-#define SONO_WPS_1024 4
-#endif
-#ifndef SONO_WIDE_WPB
-#define SONO_WIDE_WPB 8
-#endif
-#ifndef SONO_WIDE_WPS
-#define SONO_WIDE_WPS 2
-#endif
-// fft 1024 fits 128 VGPRs without spills and gains from a fourth wave per SIMD
-// (3.32 -> 3.19 ms); fft 512 and 256 lose with it (1.89 -> 2.06 ms at 512).
-template <int LOG_R1, int LOG_R2>
-struct Occupancy {
-    static constexpr bool kFour = LOG_R1 == 5 && LOG_R2 == 5;
-    static constexpr int kWavesPerBlock = LOG_R2 == 6 ? SONO_WIDE_WPB : kFour ? SONO_WPB_1024 : SONO_WPB;
-    static constexpr int kWavesPerSimd = LOG_R2 == 6 ? SONO_WIDE_WPS : kFour ? SONO_WPS_1024 : SONO_WPS;
-    static constexpr int kBlocksPerCU = 4 * kWavesPerSimd / kWavesPerBlock;
-};
-constexpr int kXcds = 8;
-
-// Values per lane and pass (log2) of the geometry that serves fft size N.
 #ifndef SONO_WIDE_FROM
 #define SONO_WIDE_FROM 2048
 #endif
 constexpr int tile_log_r2(unsigned int N) { return N >= SONO_WIDE_FROM ? 6 : 5; }
 
-// Diagnostic build (-DSONO_EXP_STAMPS, tools/expbuild.sh): every wave sums the
-// shader-clock cycles it spends in each phase; tools/kbench prints the totals.
-#ifdef SONO_EXP_STAMPS
-__device__ unsigned long long g_stamps[16];
-#define STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc[i] += now_ - last; last = now_; } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
-
-// Maximum of a 64-bit key over each group of 2^LOG_LANES consecutive lanes (4 ... 32), in every
-// lane of the group, by data-parallel-primitive moves: no LDS round trip.
-template <int CTRL>
-__device__ __forceinline__ unsigned long long max_with_dpp(unsigned long long v)
-{
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_mov_dpp((int)(unsigned int)v, CTRL, 0xf, 0xf, true);
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_mov_dpp((int)(unsigned int)(v >> 32), CTRL, 0xf, 0xf, true);
-    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-    return o > v ? o : v;
-}
-template <int LOG_LANES>
-__device__ __forceinline__ unsigned long long group_max(unsigned long long v)
-{
-    static_assert(LOG_LANES >= 2 && LOG_LANES <= 5, "groups of 4 to 32 lanes");
-    if constexpr (LOG_LANES >= 4) v = max_with_dpp<0x140>(v);     // row_mirror: lane i <-> 15 - i
-    if constexpr (LOG_LANES >= 3) v = max_with_dpp<0x141>(v);     // row_half_mirror: i <-> 7 - i inside each half row
-    v = max_with_dpp<0x4E>(v);                                    // quad_perm [2,3,0,1]
-    v = max_with_dpp<0xB1>(v);                                    // quad_perm [1,0,3,2]
-    if constexpr (LOG_LANES == 5) {
-        // rows 0/1 and 2/3 trade places
-        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned int)v, (unsigned int)v, false, false);
-        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned int)(v >> 32), (unsigned int)(v >> 32), false, false);
-        const unsigned long long x = ((unsigned long long)hi[0] << 32) | lo[0], y = ((unsigned long long)hi[1] << 32) | lo[1];
-        v = x > y ? x : y;
-    }
-    return v;
-}
-
-// Orders this wave's LDS writes before its later LDS reads of other lanes' data.
-// LDS operations of one wave execute in issue order, so no instruction is
-// needed; this only stops the compiler from moving accesses across the point.
-__device__ __forceinline__ void wave_lds_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_sched_barrier(0);      // and keeps one phase's arithmetic (and registers) out of the next
-}
-
-// Maximum over the 32 lanes of this lane's half of the wave (R2 = 32) or over the
-// whole wave (R2 = 64), in every lane.
-template <int LOG_R2>
-__device__ __forceinline__ float column_max(float v)
-{
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xf, 0xf, true)));   // row_ror:8
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x124, 0xf, 0xf, true)));   // row_ror:4
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x122, 0xf, 0xf, true)));   // row_ror:2
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x121, 0xf, 0xf, true)));   // row_ror:1
-    // rows 0/1 and 2/3 trade places: every lane then holds both rows' maxima of its half
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    if constexpr (LOG_R2 == 6) {
-        // the two halves trade places
-        const auto w = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-        v = fmaxf(__uint_as_float(w[0]), __uint_as_float(w[1]));
-    }
-    return v;
-}
-
-// RAGGED: streams of different lengths, located through TileIter's tables.
-// HOPQ: 1 / 2 = the launch's hop is N/4 / N/2 (frame B reuses frame A's loads), 0 = any hop.
-// PCM: 16-bit integer samples (StftArgs::x16) instead of f32.
-template <int LOG_R1, int LOG_R2, int MODE, bool RAGGED, int HOPQ, bool PCM = false>
-__global__ __launch_bounds__((64 * Occupancy<LOG_R1, LOG_R2>::kWavesPerBlock), (Occupancy<LOG_R1, LOG_R2>::kWavesPerSimd))
-void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *tw_rows)
-{
-    using G = tile::Geo<LOG_R1, LOG_R2>;
-    constexpr int R2 = G::R2;
-    constexpr int kWavesPerBlock = Occupancy<LOG_R1, LOG_R2>::kWavesPerBlock;
-    __shared__ __align__(16) float s_img[kWavesPerBlock * G::REGION];
-    __shared__ __align__(16) float2 s_tw[G::TW_ROWS * R2];
-    __shared__ __align__(16) float s_win[G::N];
-    __shared__ unsigned int s_next;
-    __shared__ float s_meta[kWavesPerBlock * tile::kMetaFloats];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = threadIdx.x; i < G::TW_ROWS * R2; i += blockDim.x) s_tw[i] = tw_rows[i];
-    for (int i = threadIdx.x; i < G::N; i += blockDim.x) s_win[i] = PCM ? a.window[i] * (1.0f / 32768.0f) : a.window[i];
-    if (threadIdx.x == 0) s_next = 0u;
-    __syncthreads();
-
-    float *img = s_img + wave * G::REGION;
-    float *meta = s_meta + wave * tile::kMetaFloats;
-
-    // This workgroup's share of the tiles.  The launch is cut into one contiguous
-    // range per XCD; inside a range, groups of kWavesPerBlock consecutive tiles are
-    // dealt round-robin to the range's workgroups, so the resident workgroups sweep
-    // forward together.  Inside a workgroup (= all the waves of one CU) every wave
-    // claims the next unclaimed tile from an LDS counter: the SIMD favours its
-    // oldest wave, and with a fixed split the youngest waves would still be
-    // working long after the oldest had left.
-    const unsigned int parts = gridDim.x < (unsigned int)kXcds ? gridDim.x : (unsigned int)kXcds;
-    const unsigned int part = blockIdx.x % parts, lb = blockIdx.x / parts;
-    const unsigned int blocks_in_part = (gridDim.x - part + parts - 1) / parts;
-    const unsigned long long t_first = it.n_tiles * part / parts;
-    const unsigned long long t_count = it.n_tiles * (part + 1) / parts - t_first;
-    tile::TileLane<LOG_R1, LOG_R2, MODE, HOPQ, PCM> L(a, lane);
-    auto claim = [&]() -> unsigned long long {          // -> index of the claimed tile inside the range
-        unsigned int c = 0;
-        if (lane == 0) c = atomicAdd(&s_next, 1u);
-        c = __builtin_amdgcn_readfirstlane(c);
-        const unsigned long long group = (unsigned long long)(c / kWavesPerBlock) * blocks_in_part + lb;
-        return group * kWavesPerBlock + c % kWavesPerBlock;
-    };
-    unsigned long long cur = claim();
-
-#ifdef SONO_EXP_STAMPS
-    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long t_begin = __builtin_amdgcn_s_memtime(), rt_begin = __builtin_amdgcn_s_memrealtime();
-    unsigned long long last = t_begin;
-#endif
-    while (cur < t_count) {
-        const unsigned long long t = t_first + cur;
-        const unsigned long long nxt = claim();           // returns while this tile is being worked on
-        const tile::TileRef tr = tile::locate<RAGGED>(a, it, t);
-        float re[R2], im[R2];
-        {
-            float rr[R2], ri[R2];
-            L.load(tr);
-            STAMP(0);
-            {
-                float ya[R2], yb[R2], pa[G::JPL], pb[G::JPL];
-                L.pass1_dft(s_win, ya, yb, pa, pb);
-                __builtin_amdgcn_sched_barrier(0);     // keeps the twiddle reads (60 registers) below the transforms
-                for (int jj = 0; jj < G::JPL; ++jj) { pa[jj] = column_max<LOG_R2>(pa[jj]); pb[jj] = column_max<LOG_R2>(pb[jj]); }
-                L.pass1_rows(s_tw, ya, yb, pa, pb, rr, ri, meta);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            STAMP(1);
-            L.exchange_store(rr, img);
-            wave_lds_fence();
-            L.exchange_load(img, re);
-            wave_lds_fence();
-            L.exchange_store(ri, img);
-            wave_lds_fence();
-            L.exchange_load(img, im);
-            wave_lds_fence();
-            STAMP(2);
-        }
-        L.pass2_power(re, im, img);
-        wave_lds_fence();
-        STAMP(3);
-        if constexpr (MODE == MODE_BAND) {
-            double e = L.band_sum(img, meta);
-            for (int o = G::HALF / 2; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
-            L.band_emit(tr, e);
-        } else {
-            unsigned long long key;
-            if (MODE == MODE_U8 && a.q_floor > 0.0f) key = L.template epilogue<true>(tr, img, meta);
-            else key = L.template epilogue<false>(tr, img, meta);
-            if (MODE == MODE_U8) L.features(tr, group_max<LOG_R1 - 1>(key));
-        }
-        wave_lds_fence();
-        STAMP(4);
-        cur = nxt;
-    }
-#ifdef SONO_EXP_STAMPS
-    if (lane == 0) {
-        for (int i = 0; i < 5; ++i) atomicAdd(&g_stamps[i], acc[i]);
-        atomicAdd(&g_stamps[8], __builtin_amdgcn_s_memtime() - t_begin);
-        atomicAdd(&g_stamps[9], __builtin_amdgcn_s_memrealtime() - rt_begin);
-        atomicAdd(&g_stamps[10], 1ull);
-        atomicMax(&g_stamps[11], __builtin_amdgcn_s_memtime() - t_begin);
-        atomicMax(&g_stamps[12], __builtin_amdgcn_s_memrealtime());
-        atomicMin(&g_stamps[13], rt_begin);
-        atomicMax(&g_stamps[14], rt_begin);
-        atomicMin(&g_stamps[15], __builtin_amdgcn_s_memrealtime());
-    }
-#endif
-    if (MODE == MODE_U8 && a.gmax_bits) {
-        // wave-wide maximum of |2X|^2, then one atomic per wave on the magnitude's bit pattern
-        float m = L.run_max;
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        if (lane == 0 && m > 0.0f) atomicMax(a.gmax_bits, __float_as_uint(fast_sqrt(m) * a.inv_n));
-    }
-}
-
-template <int LOG_R1, int LOG_R2, int MODE>
-hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, hipStream_t stream)
-{
-    using G = tile::Geo<LOG_R1, LOG_R2>;
-    constexpr int kWavesPerBlock = Occupancy<LOG_R1, LOG_R2>::kWavesPerBlock;
-    constexpr int kBlocksPerCU = Occupancy<LOG_R1, LOG_R2>::kBlocksPerCU;
-    tile::TileIter it;
-    if (plan) {
-        it.tiles_per_stream = 0;
-        it.n_tiles = plan->n_tiles;
-        it.streams = (const tile::RaggedStream *)plan->d_streams;
-        it.tile_stream = plan->d_tile_stream;
-    } else {
-        const unsigned long long tps = (a.frames_per_stream + G::FPW - 1) / G::FPW;
-        it.tiles_per_stream = (unsigned int)tps;
-        it.n_tiles = a.n_streams * tps;
-        it.streams = nullptr;
-        it.tile_stream = nullptr;
-    }
-    if (it.n_tiles == 0) return hipSuccess;
-    int dev = 0, cus = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return e;
-    unsigned long long blocks = (it.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    const unsigned long long resident = (unsigned long long)cus * kBlocksPerCU;
-    if (blocks > resident) blocks = resident;
-    const dim3 grid((unsigned int)blocks), block(64 * kWavesPerBlock);
-    // The hops that let frame B reuse frame A's loads: a quarter frame (75 % overlap) for
-    // the row and magnitude modes, half a frame (the fast scan's 50 %) for the band mode.
-    // SONO_FORCE_ANY_HOP=1 (read per launch) takes the any-hop form regardless: the tests compare the two.
-    constexpr int kHopQ = MODE == MODE_BAND ? 2 : 1;
-    const char *any_hop = std::getenv("SONO_FORCE_ANY_HOP");
-    const bool q = a.hop * (kHopQ == 2 ? 2u : 4u) == (unsigned int)G::N && !(any_hop && any_hop[0] && any_hop[0] != '0');
-    if (a.x16 && (plan || MODE != MODE_U8)) return hipErrorInvalidValue;
-    if constexpr (MODE == MODE_U8) {
-        if (a.x16) {        // 16-bit PCM input: uniform batches of the row mode only (tile_supports)
-            if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, kHopQ, true>), grid, block, 0, stream, a, it, tw_rows);
-            else hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, 0, true>), grid, block, 0, stream, a, it, tw_rows);
-            return hipGetLastError();
-        }
-    }
-    if (plan) {
-        if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, true, kHopQ>), grid, block, 0, stream, a, it, tw_rows);
-        else hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, true, 0>), grid, block, 0, stream, a, it, tw_rows);
-    } else {
-        if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, kHopQ>), grid, block, 0, stream, a, it, tw_rows);
-        else hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, 0>), grid, block, 0, stream, a, it, tw_rows);
-    }
-    return hipGetLastError();
-}
-
-template <int MODE>
-hipError_t launch_mode(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, hipStream_t stream)
-{
-    switch (a.N) {
-#ifndef SONO_EXP_ONLY_1024      // tools/expbuild.sh: quicker experimental builds
-    case 4096: return launch_one<6, 6, MODE>(a, tw_rows, plan, stream);
-    case 2048: return launch_one<5, 6, MODE>(a, tw_rows, plan, stream);
-    case 512: return launch_one<9 - tile_log_r2(512), tile_log_r2(512), MODE>(a, tw_rows, plan, stream);
-    case 256: return launch_one<3, 5, MODE>(a, tw_rows, plan, stream);
-#endif
-    case 1024: return launch_one<10 - tile_log_r2(1024), tile_log_r2(1024), MODE>(a, tw_rows, plan, stream);
-    default: return hipErrorInvalidValue;
-    }
-}
-
 hipError_t launch_any(int mode, const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream)
 {
     const float2 *tw_rows = (const float2 *)t.d_blob;
-    return mode == MODE_MAG ? launch_mode<MODE_MAG>(a, tw_rows, plan, stream)
-         : mode == MODE_BAND ? launch_mode<MODE_BAND>(a, tw_rows, plan, stream)
-                             : launch_mode<MODE_U8>(a, tw_rows, plan, stream);
+    return mode == MODE_MAG ? launch_tile_mag(a, tw_rows, plan, stream)
+         : mode == MODE_BAND ? launch_tile_band(a, tw_rows, plan, stream)
+                             : launch_tile_u8(a, tw_rows, plan, stream);
 }
 
 }  // namespace
-
-#ifdef SONO_EXP_STAMPS
-extern "C" void sono_debug_stamps(unsigned long long *out)
-{
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
-    unsigned long long z[16] = {0};
-    z[13] = z[15] = ~0ull;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
-}
-#endif
 
 hipError_t tile_tables_build(unsigned int N, TileTables &t)
 {

@@ -1,0 +1,11 @@
+// sono_tile_mag.hip -- the MODE_MAG instantiations of the tiled STFT kernel (sono_tile_kernel.h).
+#include "sono_tile_kernel.h"
+
+namespace sono {
+
+hipError_t launch_tile_mag(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, hipStream_t stream)
+{
+    return launch_mode<MODE_MAG>(a, tw_rows, plan, stream);
+}
+
+}  // namespace sono
