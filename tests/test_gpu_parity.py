@@ -12,17 +12,21 @@ from tests import parity
 
 pytestmark = pytest.mark.gpu
 
-PATHS = ["default", "generic"]
+PATHS = ["default", "generic", "any_hop"]
 
 
 @pytest.fixture(params=PATHS)
 def kernel_path(request, monkeypatch):
-    """Runs a test once through the normal kernel dispatch and once with the
-    generic LDS-staged kernel forced (SONO_FORCE_GENERIC is read per launch)."""
+    """Runs a test once through the normal kernel dispatch, once with the generic
+    LDS-staged kernel forced and once with the tiled kernel's any-hop form forced
+    where the dispatch would pick the shared-load form (SONO_FORCE_GENERIC and
+    SONO_FORCE_ANY_HOP are read per launch)."""
+    monkeypatch.delenv("SONO_FORCE_GENERIC", raising=False)
+    monkeypatch.delenv("SONO_FORCE_ANY_HOP", raising=False)
     if request.param == "generic":
         monkeypatch.setenv("SONO_FORCE_GENERIC", "1")
-    else:
-        monkeypatch.delenv("SONO_FORCE_GENERIC", raising=False)
+    elif request.param == "any_hop":
+        monkeypatch.setenv("SONO_FORCE_ANY_HOP", "1")
     return request.param
 
 
