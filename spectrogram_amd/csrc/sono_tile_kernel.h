@@ -5,12 +5,11 @@
 // Persistent waves.  A workgroup is a set of independent waves, each owning a
 // private LDS region that is first the pass-1 -> pass-2 exchange image and then
 // the bin-major power image; the only data shared inside a workgroup are the
-// read-only window and inter-pass twiddle tables and the tile counter.  One workgroup per CU.  N <= 1024 (32 values per lane and pass): twelve
-// waves, i.e. three per SIMD (sixteen, four per SIMD and at most 128 VGPRs per lane,
-// at N = 1024), 8.25 KB regions.  N >= 2048 (64 values per lane and pass): eight
-// waves, two per SIMD and up to 256 VGPRs, 16 KB regions.  Enough waves to keep
-// the vector ALU issuing while others sit in LDS or memory waits, without
-// register spills.
+// read-only window and inter-pass twiddle tables and the tile counter.  One
+// workgroup per CU.  N <= 1024 (32 values per lane and pass): sixteen waves, four
+// per SIMD and at most 128 VGPRs per lane, 8.25 KB regions.  N >= 2048 (64 values
+// per lane and pass): eight waves, two per SIMD and up to 256 VGPRs, 16 KB regions.
+// Enough waves to keep the vector ALU issuing while others sit in LDS or memory waits.
 //
 // Tile walk: the tiles of a launch are cut into one contiguous range per XCD
 // (workgroups are dealt round-robin to the eight XCDs), and inside a range the
@@ -29,16 +28,10 @@ namespace {
 
 // Overridable so that tools/expbuild.sh can sweep occupancy.
 #ifndef SONO_WPB
-#define SONO_WPB 12
+#define SONO_WPB 16
 #endif
 #ifndef SONO_WPS
-#define SONO_WPS 3
-#endif
-#ifndef SONO_WPB_1024
-#define SONO_WPB_1024 16
-#endif
-#ifndef SONO_WPS_1024
-#define SONO_WPS_1024 4
+#define SONO_WPS 4
 #endif
 #ifndef SONO_WIDE_WPB
 #define SONO_WIDE_WPB 8
@@ -46,13 +39,12 @@ namespace {
 #ifndef SONO_WIDE_WPS
 #define SONO_WIDE_WPS 2
 #endif
-// fft 1024 fits 128 VGPRs without spills and gains from a fourth wave per SIMD
-// (3.32 -> 3.19 ms); fft 512 and 256 lose with it (1.89 -> 2.06 ms at 512).
+// The 32-column geometries fit 128 VGPRs (the any-hop forms with a handful of spilled
+// dwords) and gain 2-4 % from a fourth wave per SIMD over three.
 template <int LOG_R1, int LOG_R2>
 struct Occupancy {
-    static constexpr bool kFour = LOG_R1 == 5 && LOG_R2 == 5;
-    static constexpr int kWavesPerBlock = LOG_R2 == 6 ? SONO_WIDE_WPB : kFour ? SONO_WPB_1024 : SONO_WPB;
-    static constexpr int kWavesPerSimd = LOG_R2 == 6 ? SONO_WIDE_WPS : kFour ? SONO_WPS_1024 : SONO_WPS;
+    static constexpr int kWavesPerBlock = LOG_R2 == 6 ? SONO_WIDE_WPB : SONO_WPB;
+    static constexpr int kWavesPerSimd = LOG_R2 == 6 ? SONO_WIDE_WPS : SONO_WPS;
     static constexpr int kBlocksPerCU = 4 * kWavesPerSimd / kWavesPerBlock;
 };
 constexpr int kXcds = 8;
