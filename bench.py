@@ -110,6 +110,7 @@ WORKLOADS = {
     "cfg5": dict(fft=1024, window="hann", alpha=None, noverlap=768, sr=384000),
     # cfg2 on the recording as a WAV file holds it: 16-bit PCM in HBM, converted in the STFT kernel's loads
     "cfg2_pcm16": dict(fft=1024, window="hann", alpha=None, noverlap=768, sr=384000),
+    "cfg5_pcm16": dict(fft=1024, window="hann", alpha=None, noverlap=768, sr=384000),
 }
 FILE_SAMPLES = 2500000          # cfg3: 5 s at 500 kHz
 
@@ -156,7 +157,7 @@ def main():
         n_streams, per = len(my_files), FILE_SAMPLES
         seconds = per / sr
     else:
-        seconds = args.seconds or {"cfg2": SECONDS, "cfg2_pcm16": SECONDS, "cfg4": 600, "cfg5": 12 * 3600}[args.workload]
+        seconds = args.seconds or {"cfg2": SECONDS, "cfg2_pcm16": SECONDS, "cfg4": 600, "cfg5": 12 * 3600, "cfg5_pcm16": 12 * 3600}[args.workload]
         n_streams, per = 1, int(seconds * sr)
     n = n_streams * per
     frames_per_stream = sa.frames_for(per, n_fft, noverlap)
@@ -167,8 +168,8 @@ def main():
     peak_bin = torch.empty(frames, dtype=torch.int16, device="cuda")
     peak_mag = torch.empty(frames, dtype=torch.float32, device="cuda")
     gmax = torch.zeros(1, dtype=torch.int32, device="cuda")
-    features_only = args.workload == "cfg5"
-    pcm16 = args.workload == "cfg2_pcm16"
+    features_only = args.workload in ("cfg5", "cfg5_pcm16")
+    pcm16 = args.workload in ("cfg2_pcm16", "cfg5_pcm16")
     if pcm16:
         x = torch.clamp(torch.round(x * 32768.0), -32768, 32767).to(torch.int16)
     bytes_per_frame = (2 if pcm16 else 4) * hop + (0 if features_only else bins) + 6
@@ -190,9 +191,17 @@ def main():
     def step():
         with torch.cuda.stream(stream):
             gmax.zero_()
-        if pcm16:
+        if pcm16 and not features_only:
             engine.stft_u8_pcm16_dev(x.data_ptr(), n_streams, per, per, 1, 0, noverlap, GAIN_DB, RANGE_DB, out.data_ptr(),
                                      peak_bin.data_ptr(), peak_mag.data_ptr(), gmax.data_ptr(), stream.cuda_stream)
+            return
+        if pcm16:
+            engine.stft_u8_pcm16_dev(x.data_ptr(), 1, per, per, 1, 0, noverlap, GAIN_DB, RANGE_DB, 0, peak_bin.data_ptr(),
+                                     peak_mag.data_ptr(), gmax.data_ptr(), stream.cuda_stream)
+            engine.stft_band_active_pcm16_dev(x.data_ptr(), 1, per, per, 1, 0, scan_v, min_bin, max_bin, target,
+                                              active.data_ptr(), 0, stream.cuda_stream)
+            sa._check(sa.lib().sono_detect_runs_dev(engine._handle(), active.data_ptr(), scan_frames, run_first.data_ptr(),
+                                                    run_last.data_ptr(), run_count.data_ptr(), stream.cuda_stream))
             return
         if not features_only:
             engine.stft_u8_dev(x.data_ptr(), n_streams, per, per, noverlap, GAIN_DB, RANGE_DB, out.data_ptr(),
@@ -256,6 +265,8 @@ def main():
                     f"one launch per GPU over its files, FFT {n_fft} Hann, 75% overlap, uint8 dB frames + peaks",
             "cfg4": f"{seconds:g} s synthetic {sr} Hz recording per GPU, FFT {n_fft} Blackman(0.16), 95% overlap (hop {hop}), "
                     f"uint8 dB frames + peaks, {frames} frames per GPU",
+            "cfg5_pcm16": f"{seconds / 3600:g} h synthetic {sr} Hz channel per GPU as 16-bit PCM in HBM: per-frame peak features at FFT "
+                          f"{n_fft} 75% overlap ({frames} frames, no u8 rows) + fused fast scan at 50% overlap + run extraction",
             "cfg5": f"{seconds / 3600:g} h synthetic {sr} Hz channel per GPU: per-frame peak features at FFT {n_fft} 75% overlap "
                     f"({frames} frames, no u8 rows) + fused fast scan at 50% overlap (band energy test in the STFT kernel, run extraction)",
         }[args.workload]

@@ -256,6 +256,14 @@ int sono_stft_mag_f32_ragged_dev(sono_engine *e, const sono_ragged_batch *in, ui
 int sono_stft_band_active_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap, uint32_t min_bin,
                               uint32_t max_bin, double target_energy_sum, uint8_t *d_active,
                               double *d_band_energy /* may be NULL */, void *hip_stream);
+
+/* sono_stft_band_active_dev on 16-bit PCM sample frames in HBM (layout and conversion as in
+ * sono_stft_u8_pcm16_dev): the fast scan of batCallDetector.js:878-949 over a WAV data chunk as it
+ * lies, flags and sums bit-identical to converting first.  No wasm counterpart. */
+int sono_stft_band_active_pcm16_dev(sono_engine *e, const int16_t *d_pcm, size_t n_streams, size_t stream_stride,
+                                    size_t samples_per_stream, uint32_t channels, uint32_t channel, uint32_t noverlap,
+                                    uint32_t min_bin, uint32_t max_bin, double target_energy_sum, uint8_t *d_active,
+                                    double *d_band_energy, void *hip_stream);
 int sono_detect_band_active_dev(sono_engine *e, const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin,
                                 uint32_t max_bin, double target_energy_sum, uint8_t *d_active,
                                 double *d_band_energy /* may be NULL */, void *hip_stream);

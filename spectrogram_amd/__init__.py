@@ -186,6 +186,9 @@ _SIGNATURES = {
     "sono_stft_u8_pcm16_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),
+    "sono_stft_band_active_pcm16_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32,
+                                                  C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p]),
     "sono_stft_mag_f32_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_void_p, C.c_void_p]),
     "sono_stft_features_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),
@@ -474,6 +477,14 @@ class SpectrogramEngine:
                                             int(samples_per_stream), int(channels), int(channel), int(noverlap),
                                             float(gain_db), float(range_db), d_out or None, d_peak_bin or None,
                                             d_peak_mag or None, d_gmax_bits or None, stream or None))
+
+    def stft_band_active_pcm16_dev(self, d_pcm, n_streams, stream_stride, samples_per_stream, channels, channel, noverlap,
+                                   min_bin, max_bin, target_energy_sum, d_active, d_band_energy=0, stream=0):
+        """stft_band_active_dev (the fused fast scan) on interleaved 16-bit PCM sample frames in HBM."""
+        _check(lib().sono_stft_band_active_pcm16_dev(self._handle(), d_pcm, int(n_streams), int(stream_stride),
+                                                     int(samples_per_stream), int(channels), int(channel), int(noverlap),
+                                                     int(min_bin), int(max_bin), float(target_energy_sum), d_active,
+                                                     d_band_energy or None, stream or None))
 
     def stft_features_dev(self, d_samples, n_streams, stream_stride, samples_per_stream, noverlap,
                           d_peak_bin=0, d_peak_mag=0, d_gmax_bits=0, stream=0):

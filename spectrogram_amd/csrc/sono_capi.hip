@@ -478,6 +478,37 @@ int sono_stft_band_active_dev(sono_engine *e, const sono_batch *in, uint32_t nov
     return SONO_OK;
 }
 
+int sono_stft_band_active_pcm16_dev(sono_engine *e, const int16_t *d_pcm, size_t n_streams, size_t stream_stride,
+                                    size_t samples_per_stream, uint32_t channels, uint32_t channel, uint32_t noverlap,
+                                    uint32_t min_bin, uint32_t max_bin, double target_energy_sum, uint8_t *d_active,
+                                    double *d_band_energy, void *hip_stream)
+{
+    const char *who = "sono_stft_band_active_pcm16_dev";
+    if (!e) return fail(SONO_EINVAL, std::string(who) + ": NULL argument");
+    if (noverlap >= e->N) return fail(SONO_EINVAL, std::string(who) + ": noverlap must be < fft_size");
+    if (channels == 0 || channel >= channels) return fail(SONO_EINVAL, std::string(who) + ": channel out of range");
+    if (n_streams && samples_per_stream && !d_pcm) return fail(SONO_EINVAL, std::string(who) + ": d_pcm is NULL");
+    if (n_streams > 1 && stream_stride < samples_per_stream)
+        return fail(SONO_EINVAL, std::string(who) + ": stream_stride < samples_per_stream");
+    sono_batch in;
+    in.d_samples = nullptr; in.n_streams = n_streams; in.stream_stride = stream_stride; in.samples_per_stream = samples_per_stream;
+    sono::StftArgs a;
+    fill_args(e, in, noverlap, a);
+    if (a.n_streams * a.frames_per_stream == 0) return SONO_OK;
+    if (!d_active) return fail(SONO_EINVAL, std::string(who) + ": d_active is NULL");
+    if (max_bin >= e->N / 2 || min_bin > max_bin)
+        return fail(SONO_EINVAL, std::string(who) + ": need min_bin <= max_bin < fft_size/2");
+    a.x16 = d_pcm; a.x16_channels = channels; a.x16_channel = channel;
+    a.band_lo = min_bin; a.band_hi = max_bin; a.band_target = target_energy_sum;
+    a.band_active = d_active; a.band_energy = d_band_energy;
+    if (!sono::tile_supports(sono::MODE_BAND, a, e->tables.tile))
+        return fail(SONO_EINVAL, std::string(who) + ": needs fft_size 256, 512, 1024, 2048 or 4096");
+    DeviceGuard guard(e->device);
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    HIP_TRY(sono::launch_stft_tile(sono::MODE_BAND, a, e->tables.tile, s));
+    return SONO_OK;
+}
+
 int sono_stft_mag_f32(sono_engine *e, const float *x, size_t n, uint32_t noverlap, float *out,
                       size_t cap, size_t *frames)
 {

@@ -35,7 +35,7 @@ enum Mode : int {
 // s * stream_stride + f * hop.  Output row g is contiguous after row g-1.
 struct StftArgs {
     const float *x;               // f32 samples; NULL when the samples are 16-bit PCM (x16)
-    const int16_t *x16;           // tiled kernel, MODE_U8 only: interleaved 16-bit PCM sample frames, sample = value / 32768;
+    const int16_t *x16;           // tiled kernel, MODE_U8 / MODE_BAND: interleaved 16-bit PCM sample frames, sample = value / 32768;
     unsigned int x16_channels;    //   stream offsets, strides and hops count sample frames of x16_channels values,
     unsigned int x16_channel;     //   of which this channel is transformed
     unsigned long long n_streams;

@@ -46,7 +46,7 @@ void tile_tables_release(TileTables &t) { if (t.d_blob) (void)hipFree(t.d_blob);
 bool tile_supports(int mode, const StftArgs &a, const TileTables &t)
 {
     if (mode != MODE_MAG && mode != MODE_U8 && mode != MODE_BAND) return false;
-    if (a.x16 && (mode != MODE_U8 || a.x16_channels == 0 || a.x16_channel >= a.x16_channels)) return false;
+    if (a.x16 && (mode == MODE_MAG || a.x16_channels == 0 || a.x16_channel >= a.x16_channels)) return false;
     if (mode == MODE_BAND && (!a.band_active || a.band_hi >= a.N / 2 || a.band_lo > a.band_hi)) return false;
     if (a.N != 4096 && a.N != 2048 && a.N != 1024 && a.N != 512 && a.N != 256) return false;
     if (!t.d_blob || t.N != a.N) return false;

@@ -277,9 +277,9 @@ hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, const RaggedPlan
     constexpr int kHopQ = MODE == MODE_BAND ? 2 : 1;
     const char *any_hop = std::getenv("SONO_FORCE_ANY_HOP");
     const bool q = a.hop * (kHopQ == 2 ? 2u : 4u) == (unsigned int)G::N && !(any_hop && any_hop[0] && any_hop[0] != '0');
-    if (a.x16 && (plan || MODE != MODE_U8)) return hipErrorInvalidValue;
-    if constexpr (MODE == MODE_U8) {
-        if (a.x16) {        // 16-bit PCM input: uniform batches of the row mode only (tile_supports)
+    if (a.x16 && (plan || MODE == MODE_MAG)) return hipErrorInvalidValue;
+    if constexpr (MODE != MODE_MAG) {
+        if (a.x16) {        // 16-bit PCM input: uniform batches of the row and band modes only (tile_supports)
             if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, kHopQ, true>), grid, block, 0, stream, a, it, tw_rows);
             else hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, 0, true>), grid, block, 0, stream, a, it, tw_rows);
             return hipGetLastError();

@@ -145,3 +145,42 @@ def test_pcm16_frames_in_hbm_equal_convert_then_stft(N, V, channels, channel):
     with pytest.raises(sa.SonoError):
         e.stft_u8_pcm16_dev(d_pcm.data_ptr(), S, stride, per, channels, channel, V, 20.0, 80.0)
     e.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,V,channels,channel", [(1024, 512, 1, 0), (1024, 600, 2, 1), (512, 256, 2, 0), (4096, 2048, 1, 0)])
+def test_pcm16_fast_scan_equals_convert_then_scan(N, V, channels, channel):
+    # the fused fast scan reading int16 sample frames against sono_pcm_to_f32_dev + sono_stft_band_active_dev
+    import torch
+    H, S = N - V, 2
+    per = N + 37 * H + 5
+    stride = per + 3
+    rng = np.random.default_rng(7 * N + channels)
+    t = np.arange(S * stride)
+    pcm = np.zeros((S * stride, channels), np.int16)
+    for c in range(channels):
+        gate = (rng.random(t.size) > 0.4)
+        pcm[:, c] = np.round(6000 * np.sin((0.3 + 0.04 * c) * t + 2e-5 * t * t) * gate + 40 * rng.standard_normal(t.size)).astype(np.int16)
+    pcm[: N + 2 * H, channel] = 0
+    d_pcm = torch.from_numpy(pcm.reshape(-1)).cuda()
+    e = sa.SpectrogramEngine(N, "hann")
+    F = sa.frames_for(per, N, V)
+    T = S * F
+    lo, hi = 5, N // 2 - 3
+    d_x = torch.zeros(S * stride, dtype=torch.float32, device="cuda")
+    sa._check(sa.lib().sono_pcm_to_f32_dev(e._handle(), d_pcm.data_ptr(), S * stride, channels, channel, 16, 0, d_x.data_ptr(), None))
+    act = [torch.full((T,), 9, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    en = [torch.zeros(T, dtype=torch.float64, device="cuda") for _ in range(2)]
+    e.stft_band_active_dev(d_x.data_ptr(), S, stride, per, V, lo, hi, 1.0, act[0].data_ptr(), en[0].data_ptr(), 0)
+    e.synchronize()
+    target = float(en[0].median().item())
+    e.stft_band_active_dev(d_x.data_ptr(), S, stride, per, V, lo, hi, target, act[0].data_ptr(), en[0].data_ptr(), 0)
+    e.stft_band_active_pcm16_dev(d_pcm.data_ptr(), S, stride, per, channels, channel, V, lo, hi, target, act[1].data_ptr(),
+                                 en[1].data_ptr(), 0)
+    e.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(en[0], en[1]) and torch.equal(act[0], act[1])
+    assert 0 < int(act[1].sum()) < T and float(en[1][0]) == 0.0
+    with pytest.raises(sa.SonoError):
+        e.stft_band_active_pcm16_dev(d_pcm.data_ptr(), S, stride, per, channels, channel, V, lo, N // 2, target, act[1].data_ptr())
+    e.free()
