@@ -39,6 +39,9 @@ namespace {
 #ifndef SONO_WIDE_WPS
 #define SONO_WIDE_WPS 2
 #endif
+#ifndef SONO_EPI_PRIO
+#define SONO_EPI_PRIO 2
+#endif
 // The 32-column geometries fit 128 VGPRs (the any-hop forms with a handful of spilled
 // dwords) and gain 2-4 % from a fourth wave per SIMD over three.
 template <int LOG_R1, int LOG_R2>
@@ -206,6 +209,10 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
         }
         L.pass2_power(re, im, img);
         wave_lds_fence();
+        // The epilogue is a few instructions between LDS reads and stores: with issue
+        // priority over the waves that are in their transforms it gets through sooner
+        // and is back to arithmetic itself (2 % of the launch).
+        __builtin_amdgcn_s_setprio(SONO_EPI_PRIO);
         STAMP(3);
         if constexpr (MODE == MODE_BAND) {
             double e = L.band_sum(img, meta);
@@ -218,6 +225,7 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
             if (MODE == MODE_U8) L.features(tr, group_max<LOG_R1 - 1>(key));
         }
         wave_lds_fence();
+        __builtin_amdgcn_s_setprio(0);
         STAMP(4);
         cur = nxt;
     }
