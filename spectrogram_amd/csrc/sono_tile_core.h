@@ -372,16 +372,20 @@ struct TileLane {
                 const unsigned long long c = a.x16_channels, row = (unsigned long long)R2 * c;
                 const int16_t *qa = a.x16 + (tr.xs_off + (unsigned int)n2 + fa * a.hop) * c + a.x16_channel;
                 const int16_t *qb = a.x16 + (tr.xs_off + (unsigned int)n2 + fb * a.hop) * c + a.x16_channel;
-                if (c == 1) {
-                    // one channel: the rows lie at constant distances, which the loads carry as
-                    // immediate offsets (a run-time stride costs an address pair per load and
-                    // halves the band mode's rate)
+                // One or two channels: the rows lie at distances known here, which the loads carry
+                // as immediate offsets (a run-time stride costs an address pair per load and halves
+                // the band mode's rate).
+                auto rows_at = [&](auto stride_) {
+                    constexpr int stride = decltype(stride_)::value;
                     static_for<0, G::R1>([&](auto n_) {
                         constexpr int n1 = decltype(n_)::value;
-                        xa[jj * G::R1 + n1] = (float)qa[R2 * n1];
-                        if constexpr (n1 >= OWN_B) xb[jj * G::R1 + n1] = (float)qb[R2 * n1];
+                        xa[jj * G::R1 + n1] = (float)qa[stride * n1];
+                        if constexpr (n1 >= OWN_B) xb[jj * G::R1 + n1] = (float)qb[stride * n1];
                     });
-                } else {
+                };
+                if (c == 1) rows_at(ic<R2>{});
+                else if (c == 2) rows_at(ic<2 * R2>{});
+                else {
                     static_for<0, G::R1>([&](auto n_) {
                         constexpr int n1 = decltype(n_)::value;
                         xa[jj * G::R1 + n1] = (float)qa[row * n1];
