@@ -62,7 +62,10 @@
 #define SONO_EPI_BATCH_512 8      // the same, fft 512 and 256 (4: 1.70 ms, 8: 1.66 ms per hour of audio at 512)
 #endif
 #ifndef SONO_EPI_BATCH_WIDE
-#define SONO_EPI_BATCH_WIDE 8     // the same, 64-column geometry (fft 2048, 4096)
+#define SONO_EPI_BATCH_WIDE 8     // the same, fft 2048 (16: 3.46 against 3.42 ms per hour of audio)
+#endif
+#ifndef SONO_EPI_BATCH_4096
+#define SONO_EPI_BATCH_4096 16    // the same, fft 4096 (8: 2.88, 16: 2.82 ms per 10 min at 95 % overlap)
 #endif
 #define SONO_PRAGMA_(x) _Pragma(#x)
 #define SONO_PRAGMA(x) SONO_PRAGMA_(x)
@@ -596,7 +599,7 @@ struct TileLane {
         // The reads of a batch are issued together: the LDS serves every wave of the
         // workgroup from one queue, and a read that is waited for on its own sits
         // behind whatever bursts the other waves have queued.
-        constexpr int NB = R2 / 4, B = LOG_R2 == 6 ? SONO_EPI_BATCH_WIDE : LOG_R1 == 5 ? SONO_EPI_BATCH : SONO_EPI_BATCH_512;
+        constexpr int NB = R2 / 4, B = LOG_R2 == 6 ? (LOG_R1 == 6 ? SONO_EPI_BATCH_4096 : SONO_EPI_BATCH_WIDE) : LOG_R1 == 5 ? SONO_EPI_BATCH : SONO_EPI_BATCH_512;
         static_assert(NB % B == 0, "the epilogue batch must divide the reads per lane");
         if (!valid) return peak_key(0.0f, 0u);          // lanes of frames past the end of the stream have nothing to store
         SONO_EPILOGUE_UNROLL
@@ -647,7 +650,7 @@ struct TileLane {
         const int frame = lane >> (LOG_R1 - 1), l = bin_lane();
         const float fix = shared_fix(meta);
         const float *row = P + frame * G::PROW + 4 * l;
-        constexpr int NB = R2 / 4, B = LOG_R2 == 6 ? SONO_EPI_BATCH_WIDE : LOG_R1 == 5 ? SONO_EPI_BATCH : SONO_EPI_BATCH_512;
+        constexpr int NB = R2 / 4, B = LOG_R2 == 6 ? (LOG_R1 == 6 ? SONO_EPI_BATCH_4096 : SONO_EPI_BATCH_WIDE) : LOG_R1 == 5 ? SONO_EPI_BATCH : SONO_EPI_BATCH_512;
         double acc = 0.0;
         SONO_EPILOGUE_UNROLL
         for (int m0 = 0; m0 < NB; m0 += B) {
