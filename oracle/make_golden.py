@@ -1,26 +1,24 @@
 #!/usr/bin/env python3
-"""Capture golden vectors from the reference's own wasm binary.
+"""Case definitions (seeded inputs) of tests/golden/golden.npz.
 
-TEST INFRASTRUCTURE ONLY.  Runs in the build container, where /root/reference
-and Node are present; the GPU box only ever sees the committed output,
-tests/golden/golden.npz (inputs + the reference's outputs; no reference code).
-
-  python oracle/make_golden.py            # rewrites tests/golden/golden.npz
-
-Every case feeds seeded synthetic PCM through the wasm exports the hot path
-consists of (spectrogram_wasm.d.ts:60-139,226-271) and stores what came back.
+TEST INFRASTRUCTURE ONLY.  The fixture holds these inputs together with the
+outputs the reference's exports gave for them (windows, compute_spectrogram,
+compute_spectrogram_u8, get_peaks, get_peak_magnitudes, get_global_max,
+compute_power_spectrum, find_peak_frequency_from_spectrum, compute_wave_peaks:
+spectrogram_wasm.d.ts:60-139,226-271).  The outputs were recorded once, in the
+build container; the fixture is frozen data and is never regenerated -- nothing
+in this repository loads or executes anything that ships inside the reference.
+What remains here is the record of how every input was made (build_cases) and the
+signal generators the tests import (chirp, tone, white).
 """
 import json
 import os
-import subprocess
 import sys
-import tempfile
 
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-WASM = os.environ.get("SONO_REF_WASM", "/root/reference/modules/spectrogram_wasm_bg.wasm")
 OUT = os.path.join(ROOT, "tests", "golden", "golden.npz")
 
 WINDOWS = ["bartlett", "bartlettHann", "blackman", "cosine", "gauss", "hamming", "hann",
@@ -147,37 +145,13 @@ def build_cases():
 
 
 def main():
-    cases, inputs = build_cases()
-    with tempfile.TemporaryDirectory() as work:
-        with open(os.path.join(work, "cases.json"), "w") as f:
-            json.dump(cases, f)
-        inputs.tofile(os.path.join(work, "inputs.bin"))
-        node = ["node"]
-        ver = subprocess.check_output(["node", "--version"]).decode().strip()
-        if int(ver.lstrip("v").split(".")[0]) < 16:
-            node += ["--experimental-wasm-mv", "--experimental-wasm-anyref"]
-        subprocess.check_call(node + [os.path.join(HERE, "golden_driver.js"), WASM, work])
-        man = json.load(open(os.path.join(work, "outputs.json")))
-        blob = open(os.path.join(work, "outputs.bin"), "rb").read()
-    dt = {"f32": np.float32, "u16": np.uint16, "u8": np.uint8}
-    arrays = {}
-    for m in man:
-        t = np.dtype(dt[m["dtype"]])
-        arrays[f"{m['case']}/{m['key']}"] = np.frombuffer(blob, t, m["count"], m["offset"]).copy()
-    meta = []
-    for c in cases:
-        c = dict(c)
-        if "x_len" in c:
-            arrays[f"{c['name']}/x"] = inputs[c["x_off"]:c["x_off"] + c["x_len"]].copy()
-        if c.get("bank_len"):
-            arrays[f"{c['name']}/bank"] = inputs[c["bank_off"]:c["bank_off"] + c["bank_len"]].copy()
-        for k in ("x_off", "x_len", "bank_off", "bank_len"):
-            c.pop(k, None)
-        meta.append(c)
-    arrays["__meta__"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    np.savez_compressed(OUT, **arrays)
-    print(f"wrote {OUT}: {len(cases)} cases, {os.path.getsize(OUT)} bytes")
+    """The fixture is frozen data: nothing here executes anything that ships inside the
+    reference.  build_cases() remains as the record of the inputs the fixture was made from."""
+    cases = build_cases()
+    n = len(cases[0]) if isinstance(cases, tuple) else len(cases)
+    print(f"{n} case definitions; tests/golden/golden.npz is frozen and is not regenerated "
+          "(its expected outputs were recorded once from the reference's own code paths; see the module docstring)")
+    return 1
 
 
 if __name__ == "__main__":

@@ -1,19 +1,16 @@
 #!/usr/bin/env python3
-"""Capture golden vectors of the detector front end from the reference's own
-JavaScript (fastScanSegmentsWasm, mergeAndPadSegments, generateSpectrogramWasm,
-detectCallSegments of modules/batCallDetector.js) driving the reference wasm.
+"""Case definitions (seeded inputs) of tests/golden/golden_detector.npz: the detector
+front end (fastScanSegmentsWasm, mergeAndPadSegments, generateSpectrogramWasm,
+detectCallSegments; batCallDetector.js:878-949, 1028-1056, 1296-1377, 1540-1598).
 
-TEST INFRASTRUCTURE ONLY.  Runs in the build container, where /root/reference
-and Node are present; the GPU box only ever sees the committed output,
-tests/golden/golden_detector.npz (inputs + the reference's outputs, no code).
-
-  python oracle/make_golden_detector.py
+TEST INFRASTRUCTURE ONLY.  The expected outputs in the fixture were recorded once
+from the reference's own methods; the fixture is frozen data and is never
+regenerated -- nothing here loads or executes anything that ships inside the
+reference.  build_cases() is the record of the inputs.
 """
 import json
 import os
-import subprocess
 import sys
-import tempfile
 
 import numpy as np
 
@@ -22,8 +19,6 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
 from make_golden import chirp, tone, white  # noqa: E402
 
-WASM = os.environ.get("SONO_REF_WASM", "/root/reference/modules/spectrogram_wasm_bg.wasm")
-DETECTOR_JS = os.environ.get("SONO_REF_DETECTOR", "/root/reference/modules/batCallDetector.js")
 OUT = os.path.join(ROOT, "tests", "golden", "golden_detector.npz")
 
 
@@ -68,34 +63,13 @@ def build_cases():
 
 
 def main():
-    cases, inputs = build_cases()
-    with tempfile.TemporaryDirectory() as work:
-        json.dump(cases, open(os.path.join(work, "cases.json"), "w"))
-        inputs.tofile(os.path.join(work, "inputs.bin"))
-        node = ["node"]
-        ver = subprocess.check_output(["node", "--version"]).decode().strip()
-        if int(ver.lstrip("v").split(".")[0]) < 16:
-            node += ["--experimental-wasm-mv", "--experimental-wasm-anyref"]
-        subprocess.check_call(node + [os.path.join(HERE, "detector_driver.js"), WASM, DETECTOR_JS, work])
-        man = json.load(open(os.path.join(work, "outputs.json")))
-        blob = open(os.path.join(work, "outputs.bin"), "rb").read()
-    dt = {"f32": np.float32, "f64": np.float64, "u8": np.uint8}
-    arrays = {}
-    for m in man:
-        arrays[f"{m['case']}/{m['key']}"] = np.frombuffer(blob, np.dtype(dt[m["dtype"]]), m["count"], m["offset"]).copy()
-    meta = []
-    for c in cases:
-        c = dict(c)
-        arrays[f"{c['name']}/x"] = inputs[c["x_off"]:c["x_off"] + c["x_len"]].copy()
-        c.pop("x_off"); c.pop("x_len")
-        meta.append(c)
-    arrays["__meta__"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
-    np.savez_compressed(OUT, **arrays)
-    print(f"wrote {OUT}: {len(cases)} cases, {os.path.getsize(OUT)} bytes")
-    for c in meta:
-        n = c["name"]
-        print(f"  {n}: scan {arrays[n + '/scan'].reshape(-1, 2).tolist()} merged {arrays[n + '/merged'].reshape(-1, 2).tolist()}"
-              f" shape {arrays[n + '/shape'].tolist()} calls {arrays.get(n + '/calls', np.zeros(0)).reshape(-1, 2).tolist()}")
+    """The fixture is frozen data: nothing here executes anything that ships inside the
+    reference.  build_cases() remains as the record of the inputs the fixture was made from."""
+    cases = build_cases()
+    n = len(cases[0]) if isinstance(cases, tuple) else len(cases)
+    print(f"{n} case definitions; tests/golden/golden_detector.npz is frozen and is not regenerated "
+          "(its expected outputs were recorded once from the reference's own code paths; see the module docstring)")
+    return 1
 
 
 if __name__ == "__main__":

@@ -1,21 +1,18 @@
 #!/usr/bin/env python3
-"""Capture golden vectors of the detector's call-framing stage from the
-reference's own JavaScript (detectCalls up to the measurement stage,
+"""Case definitions (seeded inputs) of tests/golden/golden_framing.npz: the detector's
+call-framing and measurement stages (detectCalls, processFullFile,
 refineEndUsingOscillogram, calculateZonalNoiseFloors, _scanSpectrumForFrequency,
-applyHighpassFilter, savitzkyGolay of modules/batCallDetector.js) driving the
-reference wasm.
+applyHighpassFilter, savitzkyGolay, measureFrequencyParameters and its threshold
+searches; batCallDetector.js:584-840, 1070-1289, 1610-2909, 2994-3894, 4028-4140).
 
-TEST INFRASTRUCTURE ONLY.  Runs in the build container, where /root/reference
-and Node are present; the GPU box only ever sees the committed output,
-tests/golden/golden_framing.npz (inputs + the reference's outputs, no code).
-
-  python oracle/make_golden_framing.py
+TEST INFRASTRUCTURE ONLY.  The expected outputs in the fixture were recorded once
+from the reference's own methods; the fixture is frozen data and is never
+regenerated -- nothing here loads or executes anything that ships inside the
+reference.  build_cases() is the record of the inputs.
 """
 import json
 import os
-import subprocess
 import sys
-import tempfile
 
 import numpy as np
 
@@ -24,8 +21,6 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
 from make_golden import chirp, tone, white  # noqa: E402
 
-WASM = os.environ.get("SONO_REF_WASM", "/root/reference/modules/spectrogram_wasm_bg.wasm")
-DETECTOR_JS = os.environ.get("SONO_REF_DETECTOR", "/root/reference/modules/batCallDetector.js")
 OUT = os.path.join(ROOT, "tests", "golden", "golden_framing.npz")
 
 
@@ -162,56 +157,13 @@ def build_cases():
 
 
 def main():
-    cases, inputs = build_cases()
-    with tempfile.TemporaryDirectory() as work:
-        json.dump(cases, open(os.path.join(work, "cases.json"), "w"))
-        inputs.tofile(os.path.join(work, "inputs.bin"))
-        node = ["node"]
-        ver = subprocess.check_output(["node", "--version"]).decode().strip()
-        if int(ver.lstrip("v").split(".")[0]) < 16:
-            node += ["--experimental-wasm-mv", "--experimental-wasm-anyref"]
-        subprocess.check_call(node + [os.path.join(HERE, "framing_driver.js"), WASM, DETECTOR_JS, work])
-        man = json.load(open(os.path.join(work, "outputs.json")))
-        blob = open(os.path.join(work, "outputs.bin"), "rb").read()
-    dt = {"f32": np.float32, "f64": np.float64, "u8": np.uint8}
-    arrays = {}
-    for m in man:
-        arrays[f"{m['case']}/{m['key']}"] = np.frombuffer(blob, np.dtype(dt[m["dtype"]]), m["count"], m["offset"]).copy()
-    meta = []
-    for c in cases:
-        c = dict(c)
-        arrays[f"{c['name']}/x"] = inputs[c["x_off"]:c["x_off"] + c["x_len"]].copy()
-        if c["noise_len"]:
-            arrays[f"{c['name']}/noise"] = inputs[c["noise_off"]:c["noise_off"] + c["noise_len"]].copy()
-        for k in ("x_off", "x_len", "noise_off", "noise_len"):
-            c.pop(k)
-        meta.append(c)
-    arrays["__meta__"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
-    np.savez_compressed(OUT, **arrays)
-    print(f"wrote {OUT}: {len(cases)} cases, {os.path.getsize(OUT)} bytes")
-    for c in meta:
-        n = c["name"]
-        if c["kind"] in ("fullfile", "fullfile_measured"):
-            print(f"  {n}: calls {arrays[n + '/calls'].reshape(-1, 5).round(5).tolist()} threw {arrays[n + '/measure_threw'].tolist()}")
-        elif c["kind"] == "calls_measured":
-            for key in ("measured", "measured_skip_snr"):
-                print(f"  {n}: {key} {arrays[n + '/' + key].reshape(-1, 37)[:, [2, 3, 6, 15, 25, 28, 31, 32, 33, 34]].round(2).tolist()}")
-        elif c["kind"] == "calls":
-            print(f"  {n}: calls {arrays[n + '/calls'].reshape(-1, 6).round(5).tolist()} zonal {arrays[n + '/zonal'].tolist()}")
-        elif c["kind"] == "measure":
-            for key in ("measured", "measured_debug"):
-                print(f"  {n}: {key} {arrays[n + '/' + key].reshape(-1, 33)[:, [2, 3, 6, 9, 12, 15, 17, 19, 22, 31, 32]].round(2).tolist()}")
-        elif c["kind"] == "thresholds":
-            print(f"  {n}: low {arrays[n + '/low'].reshape(-1, 8)[:, [0, 1, 3, 6, 7]].round(2).tolist()}")
-            print(f"  {n}: high {arrays[n + '/high'].reshape(-1, 9)[:, [0, 1, 3, 7, 8]].round(2).tolist()}")
-        elif c["kind"] == "snr":
-            print(f"  {n}: snr rows {arrays[n + '/snr'].reshape(-1, 9)[:, [0, 3, 4, 8]].round(4).tolist()}")
-        elif c["kind"] == "refine":
-            print(f"  {n}: refined {arrays[n + '/refined'].tolist()}")
-        elif c["kind"] == "zonal":
-            print(f"  {n}: p25 {arrays[n + '/p25'].tolist()} " + " ".join(f"{k.split('/')[1]}={arrays[k].tolist()}" for k in arrays if k.startswith(n + "/zonal_")))
-        else:
-            print(f"  {n}: auto {arrays[n + '/auto'].tolist()} sg_short {arrays[n + '/sg_short'].tolist()}")
+    """The fixture is frozen data: nothing here executes anything that ships inside the
+    reference.  build_cases() remains as the record of the inputs the fixture was made from."""
+    cases = build_cases()
+    n = len(cases[0]) if isinstance(cases, tuple) else len(cases)
+    print(f"{n} case definitions; tests/golden/golden_framing.npz is frozen and is not regenerated "
+          "(its expected outputs were recorded once from the reference's own code paths; see the module docstring)")
+    return 1
 
 
 if __name__ == "__main__":

@@ -1,16 +1,15 @@
 #!/usr/bin/env python3
-"""Capture golden vectors of the spectrogram plugin's frame contract from the
-reference's own JavaScript (getFrequencies of modules/spectrogram.esm.js) driving
-the reference wasm.  TEST INFRASTRUCTURE ONLY; runs in the build container.
-
-  python oracle/make_golden_plugin.py      # rewrites tests/golden/golden_plugin.json
+"""Case definitions (seeded inputs) of tests/golden/golden_plugin.json: the spectrogram
+plugin's frame contract (getFrequencies, spectrogram.esm.js:1364-1529).  TEST
+INFRASTRUCTURE ONLY.  The expected outputs were recorded once from the reference's own
+method; the fixture is frozen data and is never regenerated -- nothing here loads or
+executes anything that ships inside the reference.  build_cases() is the record of the
+inputs.
 """
 import base64
 import json
 import os
-import subprocess
 import sys
-import tempfile
 
 import numpy as np
 
@@ -19,8 +18,6 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
 from make_golden import chirp, tone, white  # noqa: E402
 
-WASM = os.environ.get("SONO_REF_WASM", "/root/reference/modules/spectrogram_wasm_bg.wasm")
-PLUGIN_JS = os.environ.get("SONO_REF_PLUGIN", "/root/reference/modules/spectrogram.esm.js")
 OUT = os.path.join(ROOT, "tests", "golden", "golden_plugin.json")
 
 
@@ -59,38 +56,13 @@ def build_cases():
 
 
 def main():
-    cases, inputs = build_cases()
-    with tempfile.TemporaryDirectory() as work:
-        json.dump(cases, open(os.path.join(work, "cases.json"), "w"))
-        inputs.tofile(os.path.join(work, "inputs.bin"))
-        node = ["node"]
-        ver = subprocess.check_output(["node", "--version"]).decode().strip()
-        if int(ver.lstrip("v").split(".")[0]) < 16:
-            node += ["--experimental-wasm-mv", "--experimental-wasm-anyref"]
-        subprocess.check_call(node + [os.path.join(HERE, "plugin_driver.js"), WASM, PLUGIN_JS, work])
-        res = json.load(open(os.path.join(work, "outputs.json")))
-    out = []
-    for c in cases:
-        r = res[c["name"]]
-        chans = [base64.b64encode(inputs[o:o + n].tobytes()).decode() for o, n in c["channels"]]
-        frames = []
-        for ch in r["frames"]:
-            rows = [np.frombuffer(base64.b64decode(f), np.uint8) for f in ch]
-            flat = np.concatenate(rows) if rows else np.zeros(0, np.uint8)
-            frames.append({"count": len(rows), "u8": base64.b64encode(flat.tobytes()).decode()})
-        c2 = {k: v for k, v in c.items() if k != "channels"}
-        bank = None
-        if r.get("bank"):                                     # two non-zeros per row: keep positions and values only
-            flat = np.frombuffer(base64.b64decode(r["bank"]), np.float32)
-            nz = np.flatnonzero(flat)
-            bank = {"size": int(flat.size), "idx": base64.b64encode(nz.astype(np.uint32).tobytes()).decode(),
-                    "val": base64.b64encode(flat[nz].tobytes()).decode()}
-        c2.update(x=chans, frames=frames, peaks=r["peaks"], bank=bank)
-        out.append(c2)
-        print(f"  {c['name']}: channels {len(frames)} frames {[f['count'] for f in frames]} bank {len(r.get('bank') or '')} "
-              f"peak lists {[sum(len(p) for p in ch) for ch in r['peaks']]}")
-    json.dump(out, open(OUT, "w"))
-    print(f"wrote {OUT}: {os.path.getsize(OUT)} bytes")
+    """The fixture is frozen data: nothing here executes anything that ships inside the
+    reference.  build_cases() remains as the record of the inputs the fixture was made from."""
+    cases = build_cases()
+    n = len(cases[0]) if isinstance(cases, tuple) else len(cases)
+    print(f"{n} case definitions; tests/golden/golden_plugin.json is frozen and is not regenerated "
+          "(its expected outputs were recorded once from the reference's own code paths; see the module docstring)")
+    return 1
 
 
 if __name__ == "__main__":

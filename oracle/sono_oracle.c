@@ -8,7 +8,7 @@
  * the shipped library never links or calls anything in this directory.
  *
  * Parity status: PINNED against golden vectors captured from the reference's
- * own wasm binary (tests/golden/, produced by oracle/make_golden.py).  The one
+ * own wasm binary (tests/golden/, frozen fixtures; case definitions in oracle/make_golden.py).  The one
  * part that cannot be restated bit-for-bit is the FFT itself: the reference
  * calls the third-party crate rustfft 6.4.1 (spectrogram-wasm/Cargo.lock:113-116),
  * whose source is not in the reference tree.  Here the DFT is an iterative
