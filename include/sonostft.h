@@ -283,6 +283,18 @@ int sono_detect_frame_features_dev(sono_engine *e, const float *d_db, size_t fra
 int sono_detect_runs_dev(sono_engine *e, const uint8_t *d_active, size_t frames, uint64_t *d_first,
                          uint64_t *d_last, uint64_t *d_count, void *hip_stream);
 
+/* sono_detect_runs_dev for callers that cannot allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same outputs as
+ * sono_detect_runs_dev, bit for bit; calls no hipMalloc / hipFree and no allocating library routine,
+ * and does not synchronise (the three kernels are queued on the stream).  Its only device memory
+ * beside the caller's buffers is a fixed 128 KiB array that every GPU the library runs on holds until
+ * the process ends; that bounds the input: frames <= SONO_RUNS_STATIC_MAX_FRAMES, else SONO_EINVAL.
+ * All calls on one GPU share that array: calls that overlap on one GPU (different streams or
+ * threads) race; calls queued one after another on one stream are fine. */
+#define SONO_RUNS_STATIC_MAX_FRAMES 67108864ull
+int sono_detect_runs_static_dev(sono_engine *e, const uint8_t *d_active, size_t frames, uint64_t *d_first,
+                                uint64_t *d_last, uint64_t *d_count, void *hip_stream);
+
 /* ---- call framing: what detectCalls (batCallDetector.js:1070-1289) does between
  * detectCallSegments and measureFrequencyParameters -------------------------- */
 

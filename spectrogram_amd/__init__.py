@@ -219,6 +219,8 @@ _SIGNATURES = {
                                                  C.c_uint32, C.c_double, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p]),
     "sono_detect_runs_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
+    "sono_detect_runs_static_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]),
     "sono_zonal_noise_floors": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_uint32, _f32p, C.c_size_t, C.c_size_t,
                                           C.POINTER(C.c_double), C.c_size_t, _szp]),
     "sono_zonal_noise_floors_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, _f32p, C.c_size_t, C.c_size_t,

@@ -22,6 +22,8 @@
 
 namespace sono {
 
+int noalloc_init_device(int device);      // sono_capi_noalloc.hip
+
 thread_local std::string g_err;
 
 int fail(int code, const std::string &msg)
@@ -128,6 +130,7 @@ int sono_engine_create(uint32_t fft_size, const char *window, int has_alpha, flo
     int rc = build_tables(fft_size, e->window.data(), e->tables);
     if (rc == SONO_OK && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
         rc = hip_fail(hipGetLastError(), "hipStreamCreate");
+    if (rc == SONO_OK) rc = sono::noalloc_init_device(dev);      // this GPU's fixed scratch of sono_detect_runs_static_dev
     if (rc != SONO_OK) { sono_engine_destroy(e); return rc; }
     *out = e;
     return SONO_OK;
