@@ -9,6 +9,9 @@ plus per-frame peak bin / peak magnitude / global max (5 399 997 frames, one
 kernel launch), with the samples already resident in HBM.  With --gpus N every
 rank holds one such recording of its own (independent recordings, no data-path
 collective: weak scaling); only a per-rank summary row is gathered at the end.
+Started under torch.distributed.run the script is one rank of WORLD_SIZE (which
+must equal N); started plainly with --gpus N > 1 it launches the N ranks itself
+(one per GPU, rendezvous on 127.0.0.1) and fails if fewer than N GPUs are visible.
 
 --workload selects another configuration of the same path (cfg3: a batch of 5 s
 500 kHz files spread over the ranks, strong scaling; cfg4: FFT 4096 Blackman 95 %
@@ -102,6 +105,30 @@ def measured_traffic():
     return None
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: starts N ranks of this script (one per GPU,
+    torch.distributed.run on 127.0.0.1) as child processes and returns their exit code.  Nothing in this
+    process has touched a GPU at this point, and nothing does: it only waits for the children."""
+    import subprocess
+    backend = os.environ.get("SONO_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        import torch
+        have = torch.cuda.device_count()          # counts devices without initialising them
+        if have < n:
+            sys.exit(f"bench.py: --gpus {n} needs {n} visible GPUs, this machine shows {have} "
+                     f"(SONO_BENCH_BACKEND=gloo rehearses the multi-rank path on fewer cards)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 WORKLOADS = {
     # name: fft, window, alpha, noverlap, sample rate
     "cfg2": dict(fft=1024, window="hann", alpha=None, noverlap=768, sr=384000),
@@ -127,6 +154,11 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=600.0,
                     help="seconds of audio in the CPU baseline's sample, processed repeatedly for >= 10 s (0 disables it)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: start as many ranks as GPUs")
 
     import torch
     import spectrogram_amd as sa
@@ -320,4 +352,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
