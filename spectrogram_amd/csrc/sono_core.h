@@ -53,7 +53,7 @@ struct StftArgs {
     unsigned int *gmax_bits;      // MODE_U8, optional: f32 bits, only ever raised
     float *out_power;             // MODE_POWER
     float inv_n;                  // 1/N: |2X| * inv_n = |X| * 2/N (lib.rs:150)
-    float q_a, q_c;               // code = trunc(q_a * log2(max(|2X|^2, q_floor)) + q_c), saturated to [0,255]
+    float q_a, q_c;               // code = round(q_a * log2(max(|2X|^2, q_floor)) + q_c), saturated to [0,255] (make_quant)
     float q_floor;                // 0 = no floor (it would not change any code, see make_quant)
     unsigned int band_lo, band_hi;   // MODE_BAND: bins band_lo..band_hi (inclusive, band_hi < N/2)
     double band_target;              // MODE_BAND: a frame is active iff its band energy > band_target
@@ -80,8 +80,13 @@ SONO_HD float2 real_split2(float2 zk, float2 zp, float2 w)
 
 // Quantiser constants for the dB -> u8 law of lib.rs:277-293, restated on
 // p = |2X|^2 = (mag * N)^2:   db = 20 log10(mag) = 10 log10(p) - 20 log10(N)
-//   code = (db - (-gain - range)) * 255/range = q_a * log2(p) + q_c
+//   code = trunc((db - (-gain - range)) * 255/range) = trunc(a * log2(p) + c0), saturated to [0, 255],
 // with the reference's floor mag >= 1e-10 carried over as p >= (1e-10 * N)^2.
+// The kernels form the code with v_cvt_pk_u8_f32, which saturates and rounds to the
+// nearest integer (ties to even): trunc(v) for v >= 0 is round(v - 1/2) except where
+// v is an integer exactly, so the constant they add is c = c0 - 1/2.  (An exactly
+// integral v with an odd value comes out one code lower; v has 16 fractional bits
+// at most, and the 1-LSB tolerance of the u8 rows covers it.)
 struct Quant { float a, c, floor; };
 inline Quant make_quant(unsigned int N, float gain_db, float range_db)
 {
@@ -89,13 +94,14 @@ inline Quant make_quant(unsigned int N, float gain_db, float range_db)
     const double ten_log10_2 = 3.010299956639812;       // 10*log10(2)
     Quant q;
     q.a = (float)(ten_log10_2 * k);
-    q.c = (float)((-20.0 * std::log10((double)N) + (double)gain_db + (double)range_db) * k);
+    const double c0 = (-20.0 * std::log10((double)N) + (double)gain_db + (double)range_db) * k;
+    q.c = (float)(c0 - 0.5);
     const double fl = 1e-10 * (double)N;
     q.floor = (float)(fl * fl);
     // Where the floor's own code is 0 (the defaults: the floor lies 100 dB below the lowest
     // coded level) the clamp cannot change a code: log2 of anything below the floor, down to
     // log2(0) = -inf, saturates to 0 as well.  floor = 0 tells the kernels to leave it out.
-    const double floor_code = (double)q.a * std::log2((double)q.floor) + (double)q.c;
+    const double floor_code = (double)q.a * std::log2((double)q.floor) + c0;
     if (q.a > 0.0f && floor_code < -1.0) q.floor = 0.0f;
     return q;
 }
@@ -130,20 +136,38 @@ SONO_HD float max_of_4(float a, float b, float c, float d)
     return max_nonneg(max_nonneg(a, b), max_nonneg(c, d));
 }
 
-// u8 code of one bin from p = |2X|^2.  Float -> int conversion truncates toward
-// zero like Rust's `as u8`; the clamps make the saturation explicit.
-template <bool FLOOR = true>
-SONO_HD unsigned int quantise(float p, float q_a, float q_c, float q_floor)
+// Saturating float -> u8 conversion, round to nearest even, NaN -> 0, placed in byte
+// BYTE of `word` (v_cvt_pk_u8_f32: conversion, clamp and byte insert in one instruction).
+template <int BYTE>
+SONO_HD unsigned int cvt_pk_u8(float v, unsigned int word)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_cvt_pk_u8_f32(v, (unsigned int)BYTE, word);
+#else
+    unsigned int code = 0;
+    if (v >= 255.0f) code = 255;
+    else if (v > 0.0f) code = (unsigned int)std::nearbyint(v);      // default rounding mode: ties to even
+    return (word & ~(0xFFu << (8 * BYTE))) | (code << (8 * BYTE));
+#endif
+}
+
+// Keeps a wave-uniform value in a vector register: a vector instruction with a
+// scalar-register operand issues in 3.2 cycles instead of 1.96 on gfx950, so a constant
+// that 32 instructions per tile multiply by is worth the register.
+SONO_HD float in_vgpr(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+
+// u8 code of one bin from p = |2X|^2 (see make_quant), in byte BYTE of `word`.
+template <bool FLOOR = true, int BYTE = 0>
+SONO_HD unsigned int quantise(float p, float q_a, float q_c, float q_floor, unsigned int word = 0u)
 {
     const float pf = FLOOR ? max_nonneg(p, q_floor) : p;
-    float v = q_a * fast_log2(pf) + q_c;
-#if defined(__HIP_DEVICE_COMPILE__)
-    v = __builtin_amdgcn_fmed3f(v, 0.0f, 255.0f);   // one v_med3_f32; a NaN comes out as 0
-#else
-    v = v > 0.0f ? v : 0.0f;          // also NaN -> 0
-    v = v < 255.0f ? v : 255.0f;
-#endif
-    return (unsigned int)v;
+    return cvt_pk_u8<BYTE>(__builtin_fmaf(q_a, fast_log2(pf), q_c), word);
 }
 
 // Ordering key for "largest magnitude, lowest bin on ties" (lib.rs:370-378):
@@ -314,8 +338,11 @@ struct GenericBlock {
                 // bin); the winner's magnitude is formed once per frame in phase_features.
                 unsigned int packed = 0;
                 unsigned long long best = peak_key(0.0f, 0u);
+                packed = quantise<true, 0>(p[0], a.q_a, a.q_c, a.q_floor, packed);
+                packed = quantise<true, 1>(p[1], a.q_a, a.q_c, a.q_floor, packed);
+                packed = quantise<true, 2>(p[2], a.q_a, a.q_c, a.q_floor, packed);
+                packed = quantise<true, 3>(p[3], a.q_a, a.q_c, a.q_floor, packed);
                 for (int r = 0; r < 4; ++r) {
-                    packed |= quantise(p[r], a.q_a, a.q_c, a.q_floor) << (8 * r);
                     if (p[r] > 0.0f) {                      // false for NaN, like `val > acc`
                         const unsigned long long key = peak_key(p[r], (unsigned int)(k0 + r));
                         best = key > best ? key : best;

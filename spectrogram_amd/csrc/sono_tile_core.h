@@ -114,10 +114,12 @@ constexpr int bitrev(int i, int bits)
 constexpr int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
 
 // Decimation-in-time butterfly (a, b) -> (a + w b, a - w b), w = W_64^K64.
-// The second output is formed as 2a - (a + w b), which keeps a general butterfly
-// at eight operations, six of them fused multiply-adds.  (Written as
-// fma(-w.im, b.im, fma(w.re, b.re, a.re)) it would be six, and the kernel no faster:
-// measured; the form below rounds like the sum of products it stands for.)
+// A general butterfly is six fused multiply-adds: a + w b as two chained ones per
+// component, the second output as 2a - (a + w b).  Every constant is a literal of
+// the instruction (v_fmamk_f32 / v_fmaak_f32) or an inline constant; no operand
+// carries a negation of a product, which would force the constant into a scalar
+// register -- and a vector instruction with a scalar-register operand issues in
+// 3.2 cycles instead of 1.96 on gfx950 (tools/valubench.hip).
 template <int K64>
 SONO_HD void bfly(float &ar, float &ai, float &br, float &bi)
 {
@@ -129,20 +131,20 @@ SONO_HD void bfly(float &ar, float &ai, float &br, float &bi)
         const float yr = ar - bi, yi = ai + br;
         ar = xr; ai = xi; br = yr; bi = yi;
     } else if constexpr (K64 == 8) {            // w = (1 - i)/sqrt 2: w b = c (b.re + b.im, b.im - b.re)
-        constexpr float c = 0.70710678118654757f;
+        constexpr float c = 0.70710678118654757f, nc = -c;
         const float s1 = br + bi, s2 = bi - br;
-        const float xr = ar + c * s1, xi = ai + c * s2;
-        br = ar - c * s1; bi = ai - c * s2; ar = xr; ai = xi;
+        const float xr = __builtin_fmaf(s1, c, ar), xi = __builtin_fmaf(s2, c, ai);
+        br = __builtin_fmaf(s1, nc, ar); bi = __builtin_fmaf(s2, nc, ai); ar = xr; ai = xi;
     } else if constexpr (K64 == 24) {           // w = (-1 - i)/sqrt 2: w b = c (b.im - b.re, -(b.re + b.im))
-        constexpr float c = 0.70710678118654757f;
+        constexpr float c = 0.70710678118654757f, nc = -c;
         const float s1 = bi - br, s2 = br + bi;
-        const float xr = ar + c * s1, xi = ai - c * s2;
-        br = ar - c * s1; bi = ai + c * s2; ar = xr; ai = xi;
+        const float xr = __builtin_fmaf(s1, c, ar), xi = __builtin_fmaf(s2, nc, ai);
+        br = __builtin_fmaf(s1, nc, ar); bi = __builtin_fmaf(s2, c, ai); ar = xr; ai = xi;
     } else {
-        constexpr float wr = w64_re(K64), wi = w64_im(K64);
-        const float xr = ar + (wr * br - wi * bi);
-        const float xi = ai + (wr * bi + wi * br);
-        br = 2.0f * ar - xr; bi = 2.0f * ai - xi; ar = xr; ai = xi;
+        constexpr float wr = w64_re(K64), wi = w64_im(K64), nwi = -wi;
+        const float xr = __builtin_fmaf(br, wr, __builtin_fmaf(bi, nwi, ar));
+        const float xi = __builtin_fmaf(bi, wr, __builtin_fmaf(br, wi, ai));
+        br = __builtin_fmaf(2.0f, ar, -xr); bi = __builtin_fmaf(2.0f, ai, -xi); ar = xr; ai = xi;
     }
 }
 
@@ -187,13 +189,14 @@ SONO_HD void rdft_combine(float (&v)[N])
     static_for<1, Q>([&](auto k_) {
         constexpr int k = decltype(k_)::value;
         constexpr float wr = w64_re(k * (64 / M)), wi = w64_im(k * (64 / M));
+        constexpr float nwi = -wi;
         const float er = v[BASE + k], ei = v[BASE + H - k], orr = v[BASE + H + k], oi = v[BASE + M - k];
-        const float xr = er + (wr * orr - wi * oi);
-        const float xi = ei + (wr * oi + wi * orr);
+        const float xr = __builtin_fmaf(orr, wr, __builtin_fmaf(oi, nwi, er));
+        const float xi = __builtin_fmaf(oi, wr, __builtin_fmaf(orr, wi, ei));
         v[BASE + k] = xr;
         v[BASE + M - k] = xi;
-        v[BASE + H - k] = 2.0f * er - xr;
-        v[BASE + H + k] = xi - 2.0f * ei;
+        v[BASE + H - k] = __builtin_fmaf(2.0f, er, -xr);
+        v[BASE + H + k] = __builtin_fmaf(-2.0f, ei, xi);
     });
 }
 template <int N, int FIRST = 2>
@@ -568,8 +571,7 @@ struct TileLane {
     }
 
     // Epilogue: lane (frame, l) owns bins 4l + 2*R1*m + r (m < R2/4, r < 4) of its frame.
-    // Returns the ordering key (peak_key) of the largest |2X|^2 among this lane's bins;
-    // the caller takes the maximum over the frame's R1/2 lanes (MODE_U8).  FLOOR = false leaves out the clamp to q_floor (for q_floor = 0).
+    // FLOOR = false leaves out the clamp to q_floor (for q_floor = 0).
     // The bins that came through the pair's shared rows are the multiples of R1/2:
     // the first of a lane's four wherever 4l is one.
     SONO_HD int bin_lane() const       // which quarter-row of four bins per 2*R1 this lane takes (see Geo::ROT)
@@ -582,8 +584,11 @@ struct TileLane {
         const int frame = lane >> (LOG_R1 - 1), l = bin_lane();
         return ((4 * l) & (G::HALF - 1)) == 0 ? meta[kMetaFix + frame] : 1.0f;
     }
+    // best_p / best_k: the largest |2X|^2 among this lane's bins and its bin (the lowest
+    // one on a tie; 0 where everything is zero).  The caller reduces them over the frame's
+    // R1/2 lanes: largest power, then the lowest bin among the lanes that hold it (MODE_U8).
     template <bool FLOOR>
-    SONO_HD unsigned long long epilogue(const TileRef &tr, const float *P, const float *meta)
+    SONO_HD void epilogue(const TileRef &tr, const float *P, const float *meta, float &best_p, unsigned int &best_k)
     {
         const int frame = lane >> (LOG_R1 - 1), l = bin_lane();
         const unsigned long long f = (unsigned long long)tr.j * G::FPW + (unsigned int)frame;
@@ -594,14 +599,16 @@ struct TileLane {
         // Peak search: per group of four bins only the group's maximum is compared
         // with the running one (strict >, so the lowest group wins a tie); which of
         // the four it was is settled once, after the loop.
-        float best_p = 0.0f;
+        best_p = 0.0f;
+        best_k = 0u;
         int best_m = 0;
         // The reads of a batch are issued together: the LDS serves every wave of the
         // workgroup from one queue, and a read that is waited for on its own sits
         // behind whatever bursts the other waves have queued.
         constexpr int NB = R2 / 4, B = LOG_R2 == 6 ? (LOG_R1 == 6 ? SONO_EPI_BATCH_4096 : SONO_EPI_BATCH_WIDE) : LOG_R1 == 5 ? SONO_EPI_BATCH : SONO_EPI_BATCH_512;
         static_assert(NB % B == 0, "the epilogue batch must divide the reads per lane");
-        if (!valid) return peak_key(0.0f, 0u);          // lanes of frames past the end of the stream have nothing to store
+        if (!valid) return;          // lanes of frames past the end of the stream have nothing to store
+        const float qa = in_vgpr(a.q_a), qc = in_vgpr(a.q_c);
         SONO_EPILOGUE_UNROLL
         for (int m0 = 0; m0 < NB; m0 += B) {
             float4 p4[B];
@@ -619,14 +626,15 @@ struct TileLane {
                     o.z = fast_sqrt(p[2]) * a.inv_n; o.w = fast_sqrt(p[3]) * a.inv_n;
                     *(float4 *)(a.out_mag + g * (unsigned long long)G::BINS + k0) = o;
                 } else {
-                    unsigned int packed = 0;
-                    static_for<0, 4>([&](auto r_) {
-                        constexpr int r = decltype(r_)::value;
-                        packed |= quantise<FLOOR>(p[r], a.q_a, a.q_c, a.q_floor) << (8 * r);
-                    });
+                    if (a.out_u8) {
+                        unsigned int packed = quantise<FLOOR, 0>(p[0], qa, qc, a.q_floor);
+                        packed = quantise<FLOOR, 1>(p[1], qa, qc, a.q_floor, packed);
+                        packed = quantise<FLOOR, 2>(p[2], qa, qc, a.q_floor, packed);
+                        packed = quantise<FLOOR, 3>(p[3], qa, qc, a.q_floor, packed);
+                        *(unsigned int *)(a.out_u8 + g * (unsigned long long)G::BINS + k0) = packed;
+                    }
                     const float top = max_of_4(p[0], p[1], p[2], p[3]);
                     if (top > best_p) { best_p = top; best_m = m0 + i; }        // false for a NaN
-                    if (a.out_u8) *(unsigned int *)(a.out_u8 + g * (unsigned long long)G::BINS + k0) = packed;
                 }
             });
         }
@@ -634,11 +642,9 @@ struct TileLane {
             const float4 w4 = *(const float4 *)(row + 2 * G::R1 * best_m);
             const float w[4] = {w4.x * fix, w4.y, w4.z, w4.w};
             const int r = w[0] == best_p ? 0 : w[1] == best_p ? 1 : w[2] == best_p ? 2 : 3;
-            const unsigned int best_k = best_p > 0.0f ? (unsigned int)(4 * l + 2 * G::R1 * best_m + r) : 0u;
+            best_k = best_p > 0.0f ? (unsigned int)(4 * l + 2 * G::R1 * best_m + r) : 0u;
             run_max = best_p > run_max ? best_p : run_max;
-            return peak_key(best_p, best_k);
         }
-        return peak_key(0.0f, 0u);
     }
 
     // MODE_BAND epilogue, step 1: this lane's share of its frame's band energy --
@@ -685,23 +691,16 @@ struct TileLane {
         if (a.band_energy) a.band_energy[g] = total;
     }
 
-    // `key` = the largest of the epilogue's keys over the frame's lanes: the frame's
-    // first lane emits the features.
-    SONO_HD void features(const TileRef &tr, unsigned long long key) const
+    // pmax / bin = the frame's largest |2X|^2 and its lowest bin (the epilogue's values
+    // reduced over the frame's lanes): the frame's first lane emits the features.
+    SONO_HD void features(const TileRef &tr, float pmax, unsigned int bin) const
     {
         const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
         if (MODE != MODE_U8 || l != 0) return;
         const unsigned long long f = (unsigned long long)tr.j * G::FPW + (unsigned int)frame;
         if (f >= tr.frames) return;
         const unsigned long long g = tr.row0 + f;
-        unsigned int bits = (unsigned int)(key >> 32);
-        float pmax;
-#if defined(__HIP_DEVICE_COMPILE__)
-        pmax = __uint_as_float(bits);
-#else
-        std::memcpy(&pmax, &bits, 4);
-#endif
-        if (a.peak_bin) a.peak_bin[g] = (uint16_t)(0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull));
+        if (a.peak_bin) a.peak_bin[g] = (uint16_t)bin;
         if (a.peak_mag) a.peak_mag[g] = fast_sqrt(pmax) * a.inv_n;
     }
 };

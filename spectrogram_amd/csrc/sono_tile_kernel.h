@@ -67,30 +67,62 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP(i) do { } while (0)
 #endif
 
-// Maximum of a 64-bit key over each group of 2^LOG_LANES consecutive lanes (4 ... 32), in every
-// lane of the group, by data-parallel-primitive moves: no LDS round trip.
-template <int CTRL>
-__device__ __forceinline__ unsigned long long max_with_dpp(unsigned long long v)
-{
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_mov_dpp((int)(unsigned int)v, CTRL, 0xf, 0xf, true);
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_mov_dpp((int)(unsigned int)(v >> 32), CTRL, 0xf, 0xf, true);
-    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-    return o > v ? o : v;
-}
+// One step of a reduction over neighbouring lanes in a single instruction: v_max_f32 /
+// v_min_u32 with a data-parallel-primitive operand (the lane's partner is named by the
+// DPP control).  The compiler writes such a step as a move plus the operation, and a move
+// with a DPP operand costs as much as the fused instruction (3.2 cycles of a SIMD).
+// The s_nop is the hardware's rule, not padding: a DPP operand must not be read within two
+// wait states of the vector instruction that wrote it, and the compiler, which keeps that
+// distance for its own DPP instructions, does not look inside an asm statement.
+#define SONO_DPP_OP(name, type, op, ctrl)                                                                  \
+    __device__ __forceinline__ type name(type v)                                                           \
+    {                                                                                                      \
+        type r;                                                                                            \
+        asm volatile("s_nop 1\n\t" op " %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v)); \
+        return r;                                                                                          \
+    }
+SONO_DPP_OP(max_quad_1, float, "v_max_f32_dpp", "quad_perm:[1,0,3,2]")
+SONO_DPP_OP(max_quad_2, float, "v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+SONO_DPP_OP(max_half_mirror, float, "v_max_f32_dpp", "row_half_mirror")
+SONO_DPP_OP(max_mirror, float, "v_max_f32_dpp", "row_mirror")
+SONO_DPP_OP(max_ror_8, float, "v_max_f32_dpp", "row_ror:8")
+SONO_DPP_OP(max_ror_4, float, "v_max_f32_dpp", "row_ror:4")
+SONO_DPP_OP(max_ror_2, float, "v_max_f32_dpp", "row_ror:2")
+SONO_DPP_OP(max_ror_1, float, "v_max_f32_dpp", "row_ror:1")
+SONO_DPP_OP(min_quad_1, unsigned int, "v_min_u32_dpp", "quad_perm:[1,0,3,2]")
+SONO_DPP_OP(min_quad_2, unsigned int, "v_min_u32_dpp", "quad_perm:[2,3,0,1]")
+SONO_DPP_OP(min_half_mirror, unsigned int, "v_min_u32_dpp", "row_half_mirror")
+SONO_DPP_OP(min_mirror, unsigned int, "v_min_u32_dpp", "row_mirror")
+#undef SONO_DPP_OP
+
+// Maximum of a non-negative float / minimum of an unsigned integer over each group of
+// 2^LOG_LANES consecutive lanes (4 ... 32), in every lane of the group: no LDS round trip.
 template <int LOG_LANES>
-__device__ __forceinline__ unsigned long long group_max(unsigned long long v)
+__device__ __forceinline__ float group_max_f32(float v)
 {
     static_assert(LOG_LANES >= 2 && LOG_LANES <= 5, "groups of 4 to 32 lanes");
-    if constexpr (LOG_LANES >= 4) v = max_with_dpp<0x140>(v);     // row_mirror: lane i <-> 15 - i
-    if constexpr (LOG_LANES >= 3) v = max_with_dpp<0x141>(v);     // row_half_mirror: i <-> 7 - i inside each half row
-    v = max_with_dpp<0x4E>(v);                                    // quad_perm [2,3,0,1]
-    v = max_with_dpp<0xB1>(v);                                    // quad_perm [1,0,3,2]
+    v = max_quad_1(v);
+    v = max_quad_2(v);
+    if constexpr (LOG_LANES >= 3) v = max_half_mirror(v);     // lane i <-> 7 - i inside each half row
+    if constexpr (LOG_LANES >= 4) v = max_mirror(v);          // lane i <-> 15 - i
     if constexpr (LOG_LANES == 5) {
         // rows 0/1 and 2/3 trade places
-        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned int)v, (unsigned int)v, false, false);
-        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned int)(v >> 32), (unsigned int)(v >> 32), false, false);
-        const unsigned long long x = ((unsigned long long)hi[0] << 32) | lo[0], y = ((unsigned long long)hi[1] << 32) | lo[1];
-        v = x > y ? x : y;
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    return v;
+}
+template <int LOG_LANES>
+__device__ __forceinline__ unsigned int group_min_u32(unsigned int v)
+{
+    static_assert(LOG_LANES >= 2 && LOG_LANES <= 5, "groups of 4 to 32 lanes");
+    v = min_quad_1(v);
+    v = min_quad_2(v);
+    if constexpr (LOG_LANES >= 3) v = min_half_mirror(v);
+    if constexpr (LOG_LANES >= 4) v = min_mirror(v);
+    if constexpr (LOG_LANES == 5) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        v = r[0] < r[1] ? r[0] : r[1];
     }
     return v;
 }
@@ -111,10 +143,10 @@ __device__ __forceinline__ void wave_lds_fence()
 template <int LOG_R2>
 __device__ __forceinline__ float column_max(float v)
 {
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xf, 0xf, true)));   // row_ror:8
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x124, 0xf, 0xf, true)));   // row_ror:4
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x122, 0xf, 0xf, true)));   // row_ror:2
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x121, 0xf, 0xf, true)));   // row_ror:1
+    v = max_ror_8(v);
+    v = max_ror_4(v);
+    v = max_ror_2(v);
+    v = max_ror_1(v);
     // rows 0/1 and 2/3 trade places: every lane then holds both rows' maxima of its half
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
@@ -219,10 +251,16 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
             for (int o = G::HALF / 2; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
             L.band_emit(tr, e);
         } else {
-            unsigned long long key;
-            if (MODE == MODE_U8 && a.q_floor > 0.0f) key = L.template epilogue<true>(tr, img, meta);
-            else key = L.template epilogue<false>(tr, img, meta);
-            if (MODE == MODE_U8) L.features(tr, group_max<LOG_R1 - 1>(key));
+            float best_p;
+            unsigned int best_k;
+            if (MODE == MODE_U8 && a.q_floor > 0.0f) L.template epilogue<true>(tr, img, meta, best_p, best_k);
+            else L.template epilogue<false>(tr, img, meta, best_p, best_k);
+            if (MODE == MODE_U8) {
+                // the frame's largest power, then the lowest bin among the lanes that hold it (lib.rs:370-378)
+                const float pmax = group_max_f32<LOG_R1 - 1>(best_p);
+                const unsigned int bin = group_min_u32<LOG_R1 - 1>(best_p == pmax ? best_k : 0xFFFFFFFFu);
+                L.features(tr, pmax, bin);
+            }
         }
         wave_lds_fence();
         __builtin_amdgcn_s_setprio(0);

@@ -68,17 +68,21 @@ static void run_tiles(const StftArgs &a)
             for (int l = 0; l < 64; ++l) lanes[l].band_emit(tr, e[l]);
             continue;
         }
-        unsigned long long key[64], best[64];
+        float bp[64], pmax[64];
+        unsigned int bk[64], bin[64];
         for (int l = 0; l < 64; ++l) {
-            if (MODE == MODE_U8 && a.q_floor > 0.0f) key[l] = lanes[l].template epilogue<true>(tr, img, meta);
-            else key[l] = lanes[l].template epilogue<false>(tr, img, meta);
+            if (MODE == MODE_U8 && a.q_floor > 0.0f) lanes[l].template epilogue<true>(tr, img, meta, bp[l], bk[l]);
+            else lanes[l].template epilogue<false>(tr, img, meta, bp[l], bk[l]);
         }
-        for (int l = 0; l < 64; ++l) {                      // maximum over the lanes of each frame
+        for (int l = 0; l < 64; ++l) {                      // over the lanes of each frame: largest power, then its lowest bin
             const int f0 = l & ~(G::HALF - 1);
-            best[l] = key[f0];
-            for (int m = f0; m < f0 + G::HALF; ++m) best[l] = key[m] > best[l] ? key[m] : best[l];
+            pmax[l] = bp[f0];
+            for (int m = f0; m < f0 + G::HALF; ++m) pmax[l] = bp[m] > pmax[l] ? bp[m] : pmax[l];
+            bin[l] = 0xFFFFFFFFu;
+            for (int m = f0; m < f0 + G::HALF; ++m)
+                if (bp[m] == pmax[l] && bk[m] < bin[l]) bin[l] = bk[m];
         }
-        for (int l = 0; l < 64; ++l) lanes[l].features(tr, best[l]);
+        for (int l = 0; l < 64; ++l) lanes[l].features(tr, pmax[l], bin[l]);
     }
     if (MODE == MODE_U8 && a.gmax_bits) {
         float m = 0.0f;

@@ -1,6 +1,6 @@
 // kbench.cpp -- times sono_stft_u8_dev of a given libsonostft build on device-resident
 // noise, without Python: `kbench <path/to/libsonostft.so> [fft] [noverlap] [seconds] [reps]`.
-// Build: hipcc -O2 -o tools/kbench tools/kbench.cpp -ldl
+// Build: hipcc -O2 --offload-arch=gfx950 -o tools/kbench tools/kbench.cpp -ldl
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
