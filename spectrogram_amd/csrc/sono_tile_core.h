@@ -209,6 +209,126 @@ SONO_HD void rdft_bitrev_in(float (&v)[N])
     });
 }
 
+// ---- packed pairs ---------------------------------------------------------------
+// Two f32 values in an aligned register pair, worked on by the packed instructions
+// (v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32).  One packed instruction issues in 3.2
+// cycles of a SIMD where the two plain ones it stands for take 3.8 - 3.9, and, what
+// counts for more, it takes ONE of the issue slots of its wave: a wave issues a vector
+// instruction at most every 5 cycles, so a SIMD needs three waves in arithmetic to
+// keep its ALU busy with plain instructions and hardly more than one with packed ones.
+// Pass 1 keeps (frame A, frame B) of a pair of frames in a register pair, pass 2 the
+// (real, imaginary) parts of a complex value; op_sel / neg modifiers of the packed
+// instructions do the half swaps and sign flips that complex arithmetic needs.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float pk2 __attribute__((ext_vector_type(2)));
+#else
+struct pk2 { float x, y; };
+#endif
+SONO_HD pk2 pk_make(float x, float y) { pk2 r; r.x = x; r.y = y; return r; }
+#if defined(__HIP_DEVICE_COMPILE__)
+SONO_HD pk2 pk_add(pk2 a, pk2 b) { return a + b; }
+SONO_HD pk2 pk_sub(pk2 a, pk2 b) { return a - b; }
+SONO_HD pk2 pk_mul(pk2 a, pk2 b) { return a * b; }
+SONO_HD pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return __builtin_elementwise_fma(a, b, c); }
+// a + (-i) b = (a.x + b.y, a.y - b.x)  and  a - (-i) b = (a.x - b.y, a.y + b.x), complex values as (re, im)
+SONO_HD pk2 pk_add_negi(pk2 a, pk2 b)
+{
+    pk2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+SONO_HD pk2 pk_sub_negi(pk2 a, pk2 b)
+{
+    pk2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + w b for complex a, b as (re, im) and the constant w = (WR, WI) given as the bit patterns of
+// its parts: a + b.re (wr, wr) + (b.im, b.re) (-wi, wi).  The constant rides in one scalar register pair.
+SONO_HD pk2 pk_add_wmul(pk2 a, pk2 b, unsigned long long w_bits)
+{
+    pk2 t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(b), "s"(w_bits), "v"(a));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(b), "s"(w_bits), "v"(t));
+    return r;
+}
+// 2 a - x
+SONO_HD pk2 pk_twice_minus(pk2 a, pk2 x)
+{
+    pk2 r;
+    asm("v_pk_fma_f32 %0, 2.0, %1, %2 op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(x));
+    return r;
+}
+#else
+SONO_HD pk2 pk_add(pk2 a, pk2 b) { return pk_make(a.x + b.x, a.y + b.y); }
+SONO_HD pk2 pk_sub(pk2 a, pk2 b) { return pk_make(a.x - b.x, a.y - b.y); }
+SONO_HD pk2 pk_mul(pk2 a, pk2 b) { return pk_make(a.x * b.x, a.y * b.y); }
+SONO_HD pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return pk_make(std::fmaf(a.x, b.x, c.x), std::fmaf(a.y, b.y, c.y)); }
+SONO_HD pk2 pk_add_negi(pk2 a, pk2 b) { return pk_make(a.x + b.y, a.y - b.x); }
+SONO_HD pk2 pk_sub_negi(pk2 a, pk2 b) { return pk_make(a.x - b.y, a.y + b.x); }
+SONO_HD pk2 pk_add_wmul(pk2 a, pk2 b, unsigned long long w_bits)
+{
+    const unsigned int lo = (unsigned int)w_bits, hi = (unsigned int)(w_bits >> 32);
+    float wr, wi;
+    std::memcpy(&wr, &lo, 4);
+    std::memcpy(&wi, &hi, 4);
+    const pk2 t = pk_make(std::fmaf(b.x, wr, a.x), std::fmaf(b.y, wr, a.y));
+    return pk_make(std::fmaf(b.y, -wi, t.x), std::fmaf(b.x, wi, t.y));
+}
+SONO_HD pk2 pk_twice_minus(pk2 a, pk2 x) { return pk_make(std::fmaf(2.0f, a.x, -x.x), std::fmaf(2.0f, a.y, -x.y)); }
+#endif
+
+// Bit pattern of a float at compile time (positive normal numbers, zero and their negatives: all
+// the twiddle tables hold), for constants that ride in scalar register pairs.
+constexpr unsigned int float_bits_ce(float v)
+{
+    if (v == 0.0f) return 0u;
+    const unsigned int sign = v < 0.0f ? 0x80000000u : 0u;
+    float m = v < 0.0f ? -v : v;
+    int e = 0;
+    while (m >= 2.0f) { m *= 0.5f; ++e; }
+    while (m < 1.0f) { m *= 2.0f; --e; }
+    const unsigned int frac = (unsigned int)((m - 1.0f) * 8388608.0f);       // exact: m - 1 has 23 fraction bits
+    return sign | ((unsigned int)(e + 127) << 23) | frac;
+}
+constexpr unsigned long long w64_bits(int k) { return ((unsigned long long)float_bits_ce(w64_im(k)) << 32) | float_bits_ce(w64_re(k)); }
+
+// Decimation-in-time butterfly on complex values held as (re, im) pairs:
+// (a, b) -> (a + w b, a - w b), w = W_64^K64.  Two packed instructions where w is 1 or -i, three otherwise.
+template <int K64>
+SONO_HD void bfly_pk(pk2 &a, pk2 &b)
+{
+    if constexpr (K64 == 0) {
+        const pk2 x = pk_add(a, b);
+        b = pk_sub(a, b); a = x;
+    } else if constexpr (K64 == 16) {
+        const pk2 x = pk_add_negi(a, b);
+        b = pk_sub_negi(a, b); a = x;
+    } else {
+        constexpr unsigned long long w = w64_bits(K64);      // evaluated here, at compile time
+        const pk2 x = pk_add_wmul(a, b, w);
+        b = pk_twice_minus(a, x); a = x;
+    }
+}
+
+// In-place N-point DFT (N = 2..64) of complex values held as (re, im) pairs, input in
+// bit-reversed order, output in natural order.
+template <int N>
+SONO_HD void cdft_bitrev_in(pk2 (&z)[N])
+{
+    constexpr int L = ilog2(N);
+    static_for<1, L + 1>([&](auto s_) {
+        constexpr int len = 1 << decltype(s_)::value, half = len / 2;
+        static_for<0, N / len>([&](auto b_) {
+            constexpr int base = decltype(b_)::value * len;
+            static_for<0, half>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                bfly_pk<j * (64 / len)>(z[base + j], z[base + j + half]);
+            });
+        });
+    });
+}
+
 // Makes the compiler finish computing v[0..N) here: without it the part of a
 // transform that the next few instructions do not need is sunk below them, and its
 // inputs (twice as many registers) stay alive instead of its outputs.
@@ -223,6 +343,16 @@ SONO_HD void pin_registers(float (&v)[N])
 #else
     (void)v;
 #endif
+}
+
+// Hides where a value comes from, so that the compiler computes what depends on it at the
+// point of use instead of keeping it in registers from before the tile loop.
+SONO_HD unsigned int opaque(unsigned int v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
 }
 
 // ---- tile geometry -----------------------------------------------------------
@@ -306,8 +436,9 @@ struct TileRef {
     unsigned long long frames;         // frames of that stream
     unsigned long long row0;           // output row of the stream's frame 0
     unsigned int j;                    // the tile's index inside the stream
+    bool full;                         // all FPW frames of the tile exist (false only for the last tile of a stream)
 };
-template <bool RAGGED>
+template <bool RAGGED, int FPW>
 SONO_HD TileRef locate(const StftArgs &a, const TileIter &it, unsigned long long tile)
 {
     TileRef r;
@@ -318,6 +449,7 @@ SONO_HD TileRef locate(const StftArgs &a, const TileIter &it, unsigned long long
         r.frames = st.frames;
         r.row0 = st.row0;
         r.j = (unsigned int)(tile - st.tile0);
+        r.full = ((unsigned long long)r.j + 1) * FPW <= st.frames;
     } else {
         const unsigned long long s = tile / it.tiles_per_stream;
         r.xs = a.x + s * a.stream_stride;
@@ -325,6 +457,7 @@ SONO_HD TileRef locate(const StftArgs &a, const TileIter &it, unsigned long long
         r.frames = a.frames_per_stream;
         r.row0 = s * a.frames_per_stream;
         r.j = (unsigned int)(tile - s * it.tiles_per_stream);
+        r.full = ((unsigned long long)r.j + 1) * FPW <= a.frames_per_stream;
     }
     return r;
 }
@@ -361,13 +494,12 @@ struct TileLane {
     }
 
     // Issues the loads of `tile` (pass-1 lane layout).  Frames past the end of a
-    // stream re-read the stream's frame 0 (with SHIFT, a frame B past the end is
-    // made of A's rows and frame 0's last rows); their results are never stored.
+    // stream re-read an existing frame (the tile's first one; 16-bit input: the stream's
+    // first one); their results are never stored.
     SONO_HD void load(const TileRef &tr)
     {
         const unsigned int j = tr.j;
         const int h = hgroup(), n2 = col();
-        const float *xs = tr.xs + n2;
         static_for<0, G::JPL>([&](auto jj_) {
             constexpr int jj = decltype(jj_)::value;
             unsigned long long fa = (unsigned long long)j * G::FPW + (unsigned int)(2 * (h * G::JPL + jj));
@@ -400,7 +532,15 @@ struct TileLane {
                 }
                 return;
             }
-            const float *pa = xs + fa * a.hop, *pb = xs + fb * a.hop;
+            // Addresses = the tile's first sample (the same in every lane: a scalar) + a 32-bit lane offset,
+            // n2 + (frame inside the tile) * hop, which does not change from tile to tile: hardly any vector
+            // instruction forms an address.  A frame past the end of the stream reads the tile's frame 0.
+            const float *base = tr.xs + (unsigned long long)j * G::FPW * a.hop;
+            const unsigned int rem = tr.full ? (unsigned int)G::FPW : (unsigned int)(tr.frames - (unsigned long long)j * G::FPW);
+            const unsigned int ta = (unsigned int)(2 * (h * G::JPL + jj)), tb = ta + 1u;
+            const unsigned int off_a = ta < rem ? (unsigned int)n2 + ta * a.hop : (unsigned int)n2;
+            const unsigned int off_b = tb < rem ? (unsigned int)n2 + tb * a.hop : (unsigned int)n2;
+            const float *pa = base + off_a, *pb = base + off_b;
             static_for<0, G::R1>([&](auto n_) {
                 constexpr int n1 = decltype(n_)::value;
 #ifdef SONO_EXP_NOLOAD      // diagnostic build: what the kernel costs without its sample loads
@@ -591,9 +731,11 @@ struct TileLane {
     SONO_HD void epilogue(const TileRef &tr, const float *P, const float *meta, float &best_p, unsigned int &best_k)
     {
         const int frame = lane >> (LOG_R1 - 1), l = bin_lane();
-        const unsigned long long f = (unsigned long long)tr.j * G::FPW + (unsigned int)frame;
-        const bool valid = f < tr.frames;
-        const unsigned long long g = tr.row0 + f;
+        const unsigned long long f0 = (unsigned long long)tr.j * G::FPW;          // the tile's first frame: the same in every lane
+        const bool valid = tr.full || f0 + (unsigned int)frame < tr.frames;
+        // first output element of the tile's first row (a scalar) + this lane's place in the tile (a 32-bit offset)
+        const unsigned long long tile_elem = (tr.row0 + f0) * (unsigned long long)G::BINS;
+        const unsigned int lane_elem = (unsigned int)(frame * G::BINS + 4 * l);
         const float fix = shared_fix(meta);
         const float *row = P + frame * G::PROW + 4 * l;
         // Peak search: per group of four bins only the group's maximum is compared
@@ -618,20 +760,19 @@ struct TileLane {
             });
             static_for<0, B>([&](auto i_) {
                 constexpr int i = decltype(i_)::value;
-                const int k0 = 4 * l + 2 * G::R1 * (m0 + i);
                 float p[4] = {p4[i].x * fix, p4[i].y, p4[i].z, p4[i].w};
                 if (MODE == MODE_MAG) {
                     float4 o;
                     o.x = fast_sqrt(p[0]) * a.inv_n; o.y = fast_sqrt(p[1]) * a.inv_n;
                     o.z = fast_sqrt(p[2]) * a.inv_n; o.w = fast_sqrt(p[3]) * a.inv_n;
-                    *(float4 *)(a.out_mag + g * (unsigned long long)G::BINS + k0) = o;
+                    *(float4 *)((a.out_mag + tile_elem) + ((size_t)lane_elem + 2 * G::R1 * (m0 + i))) = o;
                 } else {
                     if (a.out_u8) {
                         unsigned int packed = quantise<FLOOR, 0>(p[0], qa, qc, a.q_floor);
                         packed = quantise<FLOOR, 1>(p[1], qa, qc, a.q_floor, packed);
                         packed = quantise<FLOOR, 2>(p[2], qa, qc, a.q_floor, packed);
                         packed = quantise<FLOOR, 3>(p[3], qa, qc, a.q_floor, packed);
-                        *(unsigned int *)(a.out_u8 + g * (unsigned long long)G::BINS + k0) = packed;
+                        *(unsigned int *)((a.out_u8 + tile_elem) + ((size_t)lane_elem + 2 * G::R1 * (m0 + i))) = packed;
                     }
                     const float top = max_of_4(p[0], p[1], p[2], p[3]);
                     if (top > best_p) { best_p = top; best_m = m0 + i; }        // false for a NaN
@@ -697,11 +838,14 @@ struct TileLane {
     {
         const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
         if (MODE != MODE_U8 || l != 0) return;
-        const unsigned long long f = (unsigned long long)tr.j * G::FPW + (unsigned int)frame;
-        if (f >= tr.frames) return;
-        const unsigned long long g = tr.row0 + f;
-        if (a.peak_bin) a.peak_bin[g] = (uint16_t)bin;
-        if (a.peak_mag) a.peak_mag[g] = fast_sqrt(pmax) * a.inv_n;
+        const unsigned long long f0 = (unsigned long long)tr.j * G::FPW;
+        if (!tr.full && f0 + (unsigned int)frame >= tr.frames) return;
+        const unsigned long long g0 = tr.row0 + f0;           // a scalar; the lane adds its frame
+        // The lane's part is formed here, per tile (one shift): kept across tiles as two 64-bit
+        // pointers it costs four registers that the tile loop does not have.
+        const unsigned int fr = opaque((unsigned int)frame);
+        if (a.peak_bin) (a.peak_bin + g0)[(size_t)fr] = (uint16_t)bin;
+        if (a.peak_mag) (a.peak_mag + g0)[(size_t)fr] = fast_sqrt(pmax) * a.inv_n;
     }
 };
 

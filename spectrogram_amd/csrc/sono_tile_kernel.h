@@ -214,7 +214,7 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
     while (cur < t_count) {
         const unsigned long long t = t_first + cur;
         const unsigned long long nxt = claim();           // returns while this tile is being worked on
-        const tile::TileRef tr = tile::locate<RAGGED>(a, it, t);
+        const tile::TileRef tr = tile::locate<RAGGED, G::FPW>(a, it, t);
         float re[R2], im[R2];
         {
             float rr[R2], ri[R2];

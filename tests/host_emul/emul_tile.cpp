@@ -43,7 +43,7 @@ static void run_tiles(const StftArgs &a)
     static float rr[64][R2], ri[64][R2], re[64][R2], im[64][R2], ya[64][R2], yb[64][R2], ma[64][G::JPL], mb[64][G::JPL];
     float meta[tile::kMetaFloats];
     for (unsigned long long t = 0; t < it.n_tiles; ++t) {
-        const tile::TileRef tr = g_ragged ? tile::locate<true>(a, it, t) : tile::locate<false>(a, it, t);
+        const tile::TileRef tr = g_ragged ? tile::locate<true, G::FPW>(a, it, t) : tile::locate<false, G::FPW>(a, it, t);
         for (int l = 0; l < 64; ++l) lanes[l].load(tr);
         for (int l = 0; l < 64; ++l) lanes[l].pass1_dft(a.window, ya[l], yb[l], ma[l], mb[l]);
         for (int h = 0; h < HW; ++h)

@@ -95,6 +95,17 @@ __global__ __launch_bounds__(1024, 4) void asm_probe(Stamp *stamps, int iters)
     if (KIND == 40) asm volatile(INIT LOOP_BEGIN DST32("v_mul_f32_e64", "v8, v9") LOOP_END : : "s"(iters) : CLOBBERS);
     if (KIND == 41) asm volatile(INIT LOOP_BEGIN DST32("v_bfe_u32", "v8, 8, 8") LOOP_END : : "s"(iters) : CLOBBERS);
     if (KIND == 42) asm volatile(INIT LOOP_BEGIN DST32("v_cvt_u32_f32_sdwa", "v8 dst_sel:BYTE_1 dst_unused:UNUSED_PAD src0_sel:DWORD") LOOP_END : : "s"(iters) : CLOBBERS);
+    // packed f32: 16 instructions per round on the pairs v[40:41] ... v[70:71]
+#define PK16(op, srcs) \
+    op " v[40:41], " srcs "\n" op " v[42:43], " srcs "\n" op " v[44:45], " srcs "\n" op " v[46:47], " srcs "\n" op " v[48:49], " srcs "\n" op " v[50:51], " srcs "\n" op " v[52:53], " srcs "\n" op " v[54:55], " srcs "\n" \
+    op " v[56:57], " srcs "\n" op " v[58:59], " srcs "\n" op " v[60:61], " srcs "\n" op " v[62:63], " srcs "\n" op " v[64:65], " srcs "\n" op " v[66:67], " srcs "\n" op " v[68:69], " srcs "\n" op " v[70:71], " srcs "\n"
+    if (KIND == 60) asm volatile(INIT LOOP_BEGIN PK16("v_pk_fma_f32", "v[8:9], v[10:11], v[12:13]") PK16("v_pk_fma_f32", "v[8:9], v[10:11], v[12:13]") LOOP_END : : "s"(iters) : CLOBBERS);
+    if (KIND == 61) asm volatile(INIT LOOP_BEGIN PK16("v_pk_add_f32", "v[8:9], v[10:11]") PK16("v_pk_add_f32", "v[8:9], v[10:11]") LOOP_END : : "s"(iters) : CLOBBERS);
+    if (KIND == 62) asm volatile(INIT LOOP_BEGIN PK16("v_pk_mul_f32", "v[8:9], v[10:11]") PK16("v_pk_mul_f32", "v[8:9], v[10:11]") LOOP_END : : "s"(iters) : CLOBBERS);
+    if (KIND == 63) asm volatile(INIT LOOP_BEGIN PK16("v_pk_fma_f32", "v[8:9], v[10:11], v[12:13] op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]") PK16("v_pk_fma_f32", "v[8:9], v[10:11], v[12:13] op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]") LOOP_END : : "s"(iters) : CLOBBERS);
+    if (KIND == 64) asm volatile(INIT "s_mov_b32 s42, 0x3f3504f3\n s_mov_b32 s43, 0x3f3504f3\n" LOOP_BEGIN PK16("v_pk_fma_f32", "v[8:9], s[42:43], v[12:13]") PK16("v_pk_fma_f32", "v[8:9], s[42:43], v[12:13]") LOOP_END : : "s"(iters) : CLOBBERS, "s42", "s43");
+    if (KIND == 65) asm volatile(INIT LOOP_BEGIN PK16("v_pk_fma_f32", "v[8:9], v[10:11], v[12:13]") DST32("v_fma_f32", "v8, v9, v10") LOOP_END : : "s"(iters) : CLOBBERS);   // 16 packed + 32 plain per round
+    if (KIND == 66) asm volatile(INIT LOOP_BEGIN PK16("v_pk_mul_f32", "v[8:9], v[10:11] op_sel_hi:[1,0]") PK16("v_pk_mul_f32", "v[8:9], v[10:11] op_sel_hi:[1,0]") LOOP_END : : "s"(iters) : CLOBBERS);
     // compare-and-select sequences as the compiler writes them: 16 pairs = 32 instructions per round
 #define CS16(cmp, sel) cmp(40) sel(40) cmp(41) sel(41) cmp(42) sel(42) cmp(43) sel(43) cmp(44) sel(44) cmp(45) sel(45) cmp(46) sel(46) cmp(47) sel(47) \
                        cmp(48) sel(48) cmp(49) sel(49) cmp(50) sel(50) cmp(51) sel(51) cmp(52) sel(52) cmp(53) sel(53) cmp(54) sel(54) cmp(55) sel(55)
@@ -119,21 +130,28 @@ __global__ __launch_bounds__(1024, 4) void asm_probe(Stamp *stamps, int iters)
 // ---- the kernel's own transforms on registers -----------------------------------------------------
 // KIND 0: 64 multiplies by a constant (what keeps the values finite; subtracted from the others)
 // KIND 1: + complex DFT-32 (pass 2)      KIND 2: + two real-input DFT-32 (pass 1, both frames of a pair)
-// KIND 3: + 32 x (log2, fma, med3, convert, pack): the epilogue's arithmetic
+// KIND 3: + 32 quantised bins: the epilogue's arithmetic      KIND 4: + complex DFT-32 with packed instructions
 template <int KIND>
 __global__ __launch_bounds__(1024, 4) void core_probe(Stamp *stamps, float *sink, int iters)
 {
     float re[32], im[32];
     for (int i = 0; i < 32; ++i) { re[i] = (float)((threadIdx.x * 7 + i * 13) % 101) * 1e-2f - 0.5f; im[i] = (float)((threadIdx.x * 3 + i * 29) % 103) * 1e-2f - 0.5f; }
     unsigned int acc = 0;
+    const float qa = sono::in_vgpr(9.6f), qc = sono::in_vgpr(100.0f);
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
         if (KIND == 1) sono::tile::dft_bitrev_in<32>(re, im);
         if (KIND == 2) { sono::tile::rdft_bitrev_in<32>(re); sono::tile::rdft_bitrev_in<32>(im); }
+        if (KIND == 4) {
+            sono::tile::pk2 z[32];
+            for (int i = 0; i < 32; ++i) z[i] = sono::tile::pk_make(re[i], im[i]);
+            sono::tile::cdft_bitrev_in<32>(z);
+            for (int i = 0; i < 32; ++i) { re[i] = z[i].x; im[i] = z[i].y; }
+        }
         if (KIND == 3) {
             for (int i = 0; i < 32; i += 4) {
                 unsigned int packed = 0;
-                for (int r = 0; r < 4; ++r) packed |= sono::quantise<false>(re[i + r] * re[i + r], 9.6f, 100.0f, 0.0f) << (8 * r);
+                for (int r = 0; r < 4; ++r) packed |= sono::quantise<false>(re[i + r] * re[i + r], qa, qc, 0.0f) << (8 * r);
                 acc ^= packed;
             }
         }
@@ -260,6 +278,13 @@ int main()
     run_asm<33>("v_fma_f32 d, v8, v12, v9", cus);
     run_asm<36>("v_fmaak_f32 d, v8, v9, K", cus);
     run_asm<29>("v_mov_b32_dpp d, v8 quad_perm", cus);
+    run_asm<60>("v_pk_fma_f32 (32 per round)", cus);
+    run_asm<63>("v_pk_fma_f32 op_sel swap + neg_lo", cus);
+    run_asm<64>("v_pk_fma_f32 with s[42:43]", cus);
+    run_asm<61>("v_pk_add_f32", cus);
+    run_asm<62>("v_pk_mul_f32", cus);
+    run_asm<66>("v_pk_mul_f32 broadcast low half of src1", cus);
+    run_asm<65>("16 v_pk_fma_f32 + 32 v_fma_f32 per round (48 instructions; prints per 32)", cus);
     run_asm<50>("v_cmp_lt_f32 vcc + v_cndmask_e32 vcc (pairs)", cus);
     run_asm<51>("v_cmp_lt_f32_e64 s[] + v_cndmask_e64 s[] (pairs)", cus);
     run_asm<52>("v_cmp_e64 s[44:45] + v_cndmask_e64 s[42:43] (independent)", cus);
@@ -270,5 +295,6 @@ int main()
     run_core<1>("64 multiplies + complex DFT-32", cus);
     run_core<2>("64 multiplies + 2 real-input DFT-32", cus);
     run_core<3>("64 multiplies + 32 quantised bins", cus);
+    run_core<4>("64 multiplies + complex DFT-32 on (re, im) pairs", cus);
     return 0;
 }
