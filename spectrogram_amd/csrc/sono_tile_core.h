@@ -172,20 +172,24 @@ SONO_HD void dft_bitrev_in(float (&re)[N], float (&im)[N])
 // (k = 1..N/2-1).  Decimation in time on real data: a size-M block is combined
 // from the half-complex DFTs E (even samples, first half of the block) and O (odd
 // samples, second half):
-//   X[0] = E0 + O0,  X[M/2] = E0 - O0,  X[M/4] = E[M/4] - i O[M/4]  (all of E0, O0, E[M/4], O[M/4] real),
+//   X[0] = E0 + O0,  X[M/2] = E0 - O0,  X[M/4] = E[M/4] - i O[M/4]  (all of E0, O0, E[M/4], O[M/4] real; see rdft_flip),
 //   X[k] = E[k] + W_M^k O[k],  X[M/2-k] = conj(E[k] - W_M^k O[k])   for 0 < k < M/4,
 // about 200 operations at N = 32, 400 for the two frames of a pair, where one
 // complex transform of the pair takes 430 and the separation of the two spectra
 // 60 more.  FIRST = 4: the size-2 blocks
-// (v[2j] + v[2j+1], v[2j] - v[2j+1]) have been formed by the caller.
+// (v[2j] + v[2j+1], v[2j] - v[2j+1]; the difference negated in the odd blocks, see rdft_flip)
+// have been formed by the caller.
+// A block that is the odd-sample half of its parent (rdft_flip) stores its X[M/2]
+// negated: the parent wants Im X[M/4] = -O[M/4] in exactly that place.
+template <int M, int BASE, int N>
+constexpr bool rdft_flip() { return M < N && ((BASE / M) & 1) != 0; }
 template <int M, int BASE, int N>
 SONO_HD void rdft_combine(float (&v)[N])
 {
     constexpr int H = M / 2, Q = M / 4;
     const float e0 = v[BASE], o0 = v[BASE + H];
     v[BASE] = e0 + o0;
-    v[BASE + H] = e0 - o0;
-    if constexpr (M >= 4) v[BASE + H + Q] = -v[BASE + H + Q];
+    v[BASE + H] = rdft_flip<M, BASE, N>() ? o0 - e0 : e0 - o0;
     static_for<1, Q>([&](auto k_) {
         constexpr int k = decltype(k_)::value;
         constexpr float wr = w64_re(k * (64 / M)), wi = w64_im(k * (64 / M));
@@ -206,126 +210,6 @@ SONO_HD void rdft_bitrev_in(float (&v)[N])
     static_for<L0, L + 1>([&](auto s_) {
         constexpr int M = 1 << decltype(s_)::value;
         static_for<0, N / M>([&](auto b_) { rdft_combine<M, decltype(b_)::value * M>(v); });
-    });
-}
-
-// ---- packed pairs ---------------------------------------------------------------
-// Two f32 values in an aligned register pair, worked on by the packed instructions
-// (v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32).  One packed instruction issues in 3.2
-// cycles of a SIMD where the two plain ones it stands for take 3.8 - 3.9, and, what
-// counts for more, it takes ONE of the issue slots of its wave: a wave issues a vector
-// instruction at most every 5 cycles, so a SIMD needs three waves in arithmetic to
-// keep its ALU busy with plain instructions and hardly more than one with packed ones.
-// Pass 1 keeps (frame A, frame B) of a pair of frames in a register pair, pass 2 the
-// (real, imaginary) parts of a complex value; op_sel / neg modifiers of the packed
-// instructions do the half swaps and sign flips that complex arithmetic needs.
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef float pk2 __attribute__((ext_vector_type(2)));
-#else
-struct pk2 { float x, y; };
-#endif
-SONO_HD pk2 pk_make(float x, float y) { pk2 r; r.x = x; r.y = y; return r; }
-#if defined(__HIP_DEVICE_COMPILE__)
-SONO_HD pk2 pk_add(pk2 a, pk2 b) { return a + b; }
-SONO_HD pk2 pk_sub(pk2 a, pk2 b) { return a - b; }
-SONO_HD pk2 pk_mul(pk2 a, pk2 b) { return a * b; }
-SONO_HD pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return __builtin_elementwise_fma(a, b, c); }
-// a + (-i) b = (a.x + b.y, a.y - b.x)  and  a - (-i) b = (a.x - b.y, a.y + b.x), complex values as (re, im)
-SONO_HD pk2 pk_add_negi(pk2 a, pk2 b)
-{
-    pk2 r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-SONO_HD pk2 pk_sub_negi(pk2 a, pk2 b)
-{
-    pk2 r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// a + w b for complex a, b as (re, im) and the constant w = (WR, WI) given as the bit patterns of
-// its parts: a + b.re (wr, wr) + (b.im, b.re) (-wi, wi).  The constant rides in one scalar register pair.
-SONO_HD pk2 pk_add_wmul(pk2 a, pk2 b, unsigned long long w_bits)
-{
-    pk2 t, r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(b), "s"(w_bits), "v"(a));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(b), "s"(w_bits), "v"(t));
-    return r;
-}
-// 2 a - x
-SONO_HD pk2 pk_twice_minus(pk2 a, pk2 x)
-{
-    pk2 r;
-    asm("v_pk_fma_f32 %0, 2.0, %1, %2 op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(x));
-    return r;
-}
-#else
-SONO_HD pk2 pk_add(pk2 a, pk2 b) { return pk_make(a.x + b.x, a.y + b.y); }
-SONO_HD pk2 pk_sub(pk2 a, pk2 b) { return pk_make(a.x - b.x, a.y - b.y); }
-SONO_HD pk2 pk_mul(pk2 a, pk2 b) { return pk_make(a.x * b.x, a.y * b.y); }
-SONO_HD pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return pk_make(std::fmaf(a.x, b.x, c.x), std::fmaf(a.y, b.y, c.y)); }
-SONO_HD pk2 pk_add_negi(pk2 a, pk2 b) { return pk_make(a.x + b.y, a.y - b.x); }
-SONO_HD pk2 pk_sub_negi(pk2 a, pk2 b) { return pk_make(a.x - b.y, a.y + b.x); }
-SONO_HD pk2 pk_add_wmul(pk2 a, pk2 b, unsigned long long w_bits)
-{
-    const unsigned int lo = (unsigned int)w_bits, hi = (unsigned int)(w_bits >> 32);
-    float wr, wi;
-    std::memcpy(&wr, &lo, 4);
-    std::memcpy(&wi, &hi, 4);
-    const pk2 t = pk_make(std::fmaf(b.x, wr, a.x), std::fmaf(b.y, wr, a.y));
-    return pk_make(std::fmaf(b.y, -wi, t.x), std::fmaf(b.x, wi, t.y));
-}
-SONO_HD pk2 pk_twice_minus(pk2 a, pk2 x) { return pk_make(std::fmaf(2.0f, a.x, -x.x), std::fmaf(2.0f, a.y, -x.y)); }
-#endif
-
-// Bit pattern of a float at compile time (positive normal numbers, zero and their negatives: all
-// the twiddle tables hold), for constants that ride in scalar register pairs.
-constexpr unsigned int float_bits_ce(float v)
-{
-    if (v == 0.0f) return 0u;
-    const unsigned int sign = v < 0.0f ? 0x80000000u : 0u;
-    float m = v < 0.0f ? -v : v;
-    int e = 0;
-    while (m >= 2.0f) { m *= 0.5f; ++e; }
-    while (m < 1.0f) { m *= 2.0f; --e; }
-    const unsigned int frac = (unsigned int)((m - 1.0f) * 8388608.0f);       // exact: m - 1 has 23 fraction bits
-    return sign | ((unsigned int)(e + 127) << 23) | frac;
-}
-constexpr unsigned long long w64_bits(int k) { return ((unsigned long long)float_bits_ce(w64_im(k)) << 32) | float_bits_ce(w64_re(k)); }
-
-// Decimation-in-time butterfly on complex values held as (re, im) pairs:
-// (a, b) -> (a + w b, a - w b), w = W_64^K64.  Two packed instructions where w is 1 or -i, three otherwise.
-template <int K64>
-SONO_HD void bfly_pk(pk2 &a, pk2 &b)
-{
-    if constexpr (K64 == 0) {
-        const pk2 x = pk_add(a, b);
-        b = pk_sub(a, b); a = x;
-    } else if constexpr (K64 == 16) {
-        const pk2 x = pk_add_negi(a, b);
-        b = pk_sub_negi(a, b); a = x;
-    } else {
-        constexpr unsigned long long w = w64_bits(K64);      // evaluated here, at compile time
-        const pk2 x = pk_add_wmul(a, b, w);
-        b = pk_twice_minus(a, x); a = x;
-    }
-}
-
-// In-place N-point DFT (N = 2..64) of complex values held as (re, im) pairs, input in
-// bit-reversed order, output in natural order.
-template <int N>
-SONO_HD void cdft_bitrev_in(pk2 (&z)[N])
-{
-    constexpr int L = ilog2(N);
-    static_for<1, L + 1>([&](auto s_) {
-        constexpr int len = 1 << decltype(s_)::value, half = len / 2;
-        static_for<0, N / len>([&](auto b_) {
-            constexpr int base = decltype(b_)::value * len;
-            static_for<0, half>([&](auto j_) {
-                constexpr int j = decltype(j_)::value;
-                bfly_pk<j * (64 / len)>(z[base + j], z[base + j + half]);
-            });
-        });
     });
 }
 
@@ -353,6 +237,17 @@ SONO_HD unsigned int opaque(unsigned int v)
     asm volatile("" : "+v"(v));
 #endif
     return v;
+}
+
+// dst = src as one move instruction that stays a move: written as a plain assignment under a
+// lane-dependent condition it would be turned into a select, which costs twice as much.
+SONO_HD void move_in_place(float &dst, float src)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(src));
+#else
+    dst = src;
+#endif
 }
 
 // ---- tile geometry -----------------------------------------------------------
@@ -436,7 +331,7 @@ struct TileRef {
     unsigned long long frames;         // frames of that stream
     unsigned long long row0;           // output row of the stream's frame 0
     unsigned int j;                    // the tile's index inside the stream
-    bool full;                         // all FPW frames of the tile exist (false only for the last tile of a stream)
+    unsigned int rem;                  // how many of the tile's FPW frames exist (fewer than FPW only in the last tile of a stream)
 };
 template <bool RAGGED, int FPW>
 SONO_HD TileRef locate(const StftArgs &a, const TileIter &it, unsigned long long tile)
@@ -449,7 +344,8 @@ SONO_HD TileRef locate(const StftArgs &a, const TileIter &it, unsigned long long
         r.frames = st.frames;
         r.row0 = st.row0;
         r.j = (unsigned int)(tile - st.tile0);
-        r.full = ((unsigned long long)r.j + 1) * FPW <= st.frames;
+        const unsigned long long left = st.frames - (unsigned long long)r.j * FPW;
+        r.rem = left < (unsigned long long)FPW ? (unsigned int)left : (unsigned int)FPW;
     } else {
         const unsigned long long s = tile / it.tiles_per_stream;
         r.xs = a.x + s * a.stream_stride;
@@ -457,7 +353,8 @@ SONO_HD TileRef locate(const StftArgs &a, const TileIter &it, unsigned long long
         r.frames = a.frames_per_stream;
         r.row0 = s * a.frames_per_stream;
         r.j = (unsigned int)(tile - s * it.tiles_per_stream);
-        r.full = ((unsigned long long)r.j + 1) * FPW <= a.frames_per_stream;
+        const unsigned long long left = a.frames_per_stream - (unsigned long long)r.j * FPW;
+        r.rem = left < (unsigned long long)FPW ? (unsigned int)left : (unsigned int)FPW;
     }
     return r;
 }
@@ -502,11 +399,11 @@ struct TileLane {
         const int h = hgroup(), n2 = col();
         static_for<0, G::JPL>([&](auto jj_) {
             constexpr int jj = decltype(jj_)::value;
-            unsigned long long fa = (unsigned long long)j * G::FPW + (unsigned int)(2 * (h * G::JPL + jj));
-            unsigned long long fb = fa + 1;
-            if (fa >= tr.frames) fa = 0;
-            if (fb >= tr.frames) fb = 0;
             if constexpr (PCM) {
+                unsigned long long fa = (unsigned long long)j * G::FPW + (unsigned int)(2 * (h * G::JPL + jj));
+                unsigned long long fb = fa + 1;
+                if (fa >= tr.frames) fa = 0;
+                if (fb >= tr.frames) fb = 0;
                 const unsigned long long c = a.x16_channels, row = (unsigned long long)R2 * c;
                 const int16_t *qa = a.x16 + (tr.xs_off + (unsigned int)n2 + fa * a.hop) * c + a.x16_channel;
                 const int16_t *qb = a.x16 + (tr.xs_off + (unsigned int)n2 + fb * a.hop) * c + a.x16_channel;
@@ -536,8 +433,8 @@ struct TileLane {
             // n2 + (frame inside the tile) * hop, which does not change from tile to tile: hardly any vector
             // instruction forms an address.  A frame past the end of the stream reads the tile's frame 0.
             const float *base = tr.xs + (unsigned long long)j * G::FPW * a.hop;
-            const unsigned int rem = tr.full ? (unsigned int)G::FPW : (unsigned int)(tr.frames - (unsigned long long)j * G::FPW);
-            const unsigned int ta = (unsigned int)(2 * (h * G::JPL + jj)), tb = ta + 1u;
+            const unsigned int rem = tr.rem;
+            const unsigned int ta = opaque((unsigned int)(2 * (h * G::JPL + jj))), tb = ta + 1u;      // formed per tile: see opaque()
             const unsigned int off_a = ta < rem ? (unsigned int)n2 + ta * a.hop : (unsigned int)n2;
             const unsigned int off_b = tb < rem ? (unsigned int)n2 + tb * a.hop : (unsigned int)n2;
             const float *pa = base + off_a, *pb = base + off_b;
@@ -570,13 +467,14 @@ struct TileLane {
             static_for<0, G::HALF>([&](auto j_) {
                 constexpr int i = 2 * decltype(j_)::value, na = bitrev(i, LOG_R1), nb = na + G::HALF;
                 static_assert(bitrev(i + 1, LOG_R1) == nb, "stage-1 partner");
+                constexpr bool flip = rdft_flip<2, i, G::R1>();      // the difference negated in the odd blocks
                 const float wa = win[R2 * na + n2], wb = win[R2 * nb + n2];
                 const float a0 = xa[jj * G::R1 + na] * wa, a1 = xa[jj * G::R1 + nb];
                 va[i] = __builtin_fmaf(a1, wb, a0);
-                va[i + 1] = __builtin_fmaf(-a1, wb, a0);
+                va[i + 1] = flip ? __builtin_fmaf(a1, wb, -a0) : __builtin_fmaf(-a1, wb, a0);
                 const float b0 = b_at<jj, na>() * wa, b1 = b_at<jj, nb>();
                 vb[i] = __builtin_fmaf(b1, wb, b0);
-                vb[i + 1] = __builtin_fmaf(-b1, wb, b0);
+                vb[i + 1] = flip ? __builtin_fmaf(b1, wb, -b0) : __builtin_fmaf(-b1, wb, b0);
             });
             rdft_bitrev_in<G::R1, 4>(va);
             rdft_bitrev_in<G::R1, 4>(vb);
@@ -699,10 +597,23 @@ struct TileLane {
         const int frame = 2 * q + (rho >> (LOG_R1 - 1));
         float *row1 = P + (shared ? 2 * q * G::PROW + rho : frame * G::PROW + k1);
         float *row2 = P + (shared ? (2 * q + 1) * G::PROW + rho : frame * G::PROW + G::R1 - k1);
+        // The partner of register t is register R2-1-t in every row but row 0, where it is (R2-t) mod R2:
+        // the lanes of row 0 (two of 64) move their upper registers one place down, C[0] into the last,
+        // after which one rule serves all.  (Moves under the execution mask: half the cost of the selects
+        // that would pick the partner lane by lane.)
+        if (row0) {
+            static_for<R2 / 2, R2 - 1>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                move_in_place(re[j], re[j + 1]);
+                move_in_place(im[j], im[j + 1]);
+            });
+            move_in_place(re[R2 - 1], re[0]);
+            move_in_place(im[R2 - 1], im[0]);
+        }
         static_for<0, R2 / 2>([&](auto t_) {
             constexpr int t = decltype(t_)::value;
-            const float br = row0 ? re[(R2 - t) & (R2 - 1)] : re[R2 - 1 - t];
-            const float bi = row0 ? im[(R2 - t) & (R2 - 1)] : im[R2 - 1 - t];
+            const float br = re[R2 - 1 - t];
+            const float bi = im[R2 - 1 - t];
             const float er = re[t] + s * br, ei = im[t] - s * bi;
             const float dr = s * re[t] - br, di = s * im[t] + bi;
             row1[G::R1 * t] = er * er + ei * ei;
@@ -732,10 +643,10 @@ struct TileLane {
     {
         const int frame = lane >> (LOG_R1 - 1), l = bin_lane();
         const unsigned long long f0 = (unsigned long long)tr.j * G::FPW;          // the tile's first frame: the same in every lane
-        const bool valid = tr.full || f0 + (unsigned int)frame < tr.frames;
+        const bool valid = (unsigned int)frame < tr.rem;
         // first output element of the tile's first row (a scalar) + this lane's place in the tile (a 32-bit offset)
         const unsigned long long tile_elem = (tr.row0 + f0) * (unsigned long long)G::BINS;
-        const unsigned int lane_elem = (unsigned int)(frame * G::BINS + 4 * l);
+        const unsigned int lane_elem = opaque((unsigned int)frame) * (unsigned int)G::BINS + (unsigned int)(4 * l);
         const float fix = shared_fix(meta);
         const float *row = P + frame * G::PROW + 4 * l;
         // Peak search: per group of four bins only the group's maximum is compared
@@ -825,9 +736,8 @@ struct TileLane {
     {
         const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
         if (l != 0) return;
-        const unsigned long long f = (unsigned long long)tr.j * G::FPW + (unsigned int)frame;
-        if (f >= tr.frames) return;
-        const unsigned long long g = tr.row0 + f;
+        if ((unsigned int)frame >= tr.rem) return;
+        const unsigned long long g = tr.row0 + (unsigned long long)tr.j * G::FPW + (unsigned int)frame;
         a.band_active[g] = total > a.band_target ? 1 : 0;
         if (a.band_energy) a.band_energy[g] = total;
     }
@@ -839,7 +749,7 @@ struct TileLane {
         const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
         if (MODE != MODE_U8 || l != 0) return;
         const unsigned long long f0 = (unsigned long long)tr.j * G::FPW;
-        if (!tr.full && f0 + (unsigned int)frame >= tr.frames) return;
+        if ((unsigned int)frame >= tr.rem) return;
         const unsigned long long g0 = tr.row0 + f0;           // a scalar; the lane adds its frame
         // The lane's part is formed here, per tile (one shift): kept across tiles as two 64-bit
         // pointers it costs four registers that the tile loop does not have.

@@ -15,6 +15,136 @@
 
 #include "../spectrogram_amd/csrc/sono_tile_core.h"
 
+// The complex DFT on (re, im) register pairs with packed f32 instructions: measured here and in
+// a build of the tiled kernel, and not used by the library.  A packed instruction does two
+// lanes' worth of work per issue slot, but the SIMD charges it as much as the two plain
+// instructions it stands for (4.8 against 2 x 2.4 cycles), the dependent ones need wait states
+// in between, and register pairs must be aligned: the kernel with its pass 1 packed ran 3 %
+// slower (2.85 against 2.77 ms per hour of audio at fft 1024, same box, bit-identical rows).
+namespace sono {
+namespace tile {
+// Two f32 values in an aligned register pair, worked on by the packed instructions
+// (v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32).  One packed instruction issues in 3.2
+// cycles of a SIMD where the two plain ones it stands for take 3.8 - 3.9, and, what
+// counts for more, it takes ONE of the issue slots of its wave: a wave issues a vector
+// instruction at most every 5 cycles, so a SIMD needs three waves in arithmetic to
+// keep its ALU busy with plain instructions and hardly more than one with packed ones.
+// Pass 1 keeps (frame A, frame B) of a pair of frames in a register pair, pass 2 the
+// (real, imaginary) parts of a complex value; op_sel / neg modifiers of the packed
+// instructions do the half swaps and sign flips that complex arithmetic needs.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float pk2 __attribute__((ext_vector_type(2)));
+#else
+struct pk2 { float x, y; };
+#endif
+SONO_HD pk2 pk_make(float x, float y) { pk2 r; r.x = x; r.y = y; return r; }
+#if defined(__HIP_DEVICE_COMPILE__)
+SONO_HD pk2 pk_add(pk2 a, pk2 b) { return a + b; }
+SONO_HD pk2 pk_sub(pk2 a, pk2 b) { return a - b; }
+SONO_HD pk2 pk_mul(pk2 a, pk2 b) { return a * b; }
+SONO_HD pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return __builtin_elementwise_fma(a, b, c); }
+// a + (-i) b = (a.x + b.y, a.y - b.x)  and  a - (-i) b = (a.x - b.y, a.y + b.x), complex values as (re, im)
+SONO_HD pk2 pk_add_negi(pk2 a, pk2 b)
+{
+    pk2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+SONO_HD pk2 pk_sub_negi(pk2 a, pk2 b)
+{
+    pk2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + w b for complex a, b as (re, im) and the constant w = (WR, WI) given as the bit patterns of
+// its parts: a + b.re (wr, wr) + (b.im, b.re) (-wi, wi).  The constant rides in one scalar register pair.
+SONO_HD pk2 pk_add_wmul(pk2 a, pk2 b, unsigned long long w_bits)
+{
+    pk2 t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(b), "s"(w_bits), "v"(a));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(b), "s"(w_bits), "v"(t));
+    return r;
+}
+// 2 a - x
+SONO_HD pk2 pk_twice_minus(pk2 a, pk2 x)
+{
+    pk2 r;
+    asm("v_pk_fma_f32 %0, 2.0, %1, %2 op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(x));
+    return r;
+}
+#else
+SONO_HD pk2 pk_add(pk2 a, pk2 b) { return pk_make(a.x + b.x, a.y + b.y); }
+SONO_HD pk2 pk_sub(pk2 a, pk2 b) { return pk_make(a.x - b.x, a.y - b.y); }
+SONO_HD pk2 pk_mul(pk2 a, pk2 b) { return pk_make(a.x * b.x, a.y * b.y); }
+SONO_HD pk2 pk_fma(pk2 a, pk2 b, pk2 c) { return pk_make(std::fmaf(a.x, b.x, c.x), std::fmaf(a.y, b.y, c.y)); }
+SONO_HD pk2 pk_add_negi(pk2 a, pk2 b) { return pk_make(a.x + b.y, a.y - b.x); }
+SONO_HD pk2 pk_sub_negi(pk2 a, pk2 b) { return pk_make(a.x - b.y, a.y + b.x); }
+SONO_HD pk2 pk_add_wmul(pk2 a, pk2 b, unsigned long long w_bits)
+{
+    const unsigned int lo = (unsigned int)w_bits, hi = (unsigned int)(w_bits >> 32);
+    float wr, wi;
+    std::memcpy(&wr, &lo, 4);
+    std::memcpy(&wi, &hi, 4);
+    const pk2 t = pk_make(std::fmaf(b.x, wr, a.x), std::fmaf(b.y, wr, a.y));
+    return pk_make(std::fmaf(b.y, -wi, t.x), std::fmaf(b.x, wi, t.y));
+}
+SONO_HD pk2 pk_twice_minus(pk2 a, pk2 x) { return pk_make(std::fmaf(2.0f, a.x, -x.x), std::fmaf(2.0f, a.y, -x.y)); }
+#endif
+
+// Bit pattern of a float at compile time (positive normal numbers, zero and their negatives: all
+// the twiddle tables hold), for constants that ride in scalar register pairs.
+constexpr unsigned int float_bits_ce(float v)
+{
+    if (v == 0.0f) return 0u;
+    const unsigned int sign = v < 0.0f ? 0x80000000u : 0u;
+    float m = v < 0.0f ? -v : v;
+    int e = 0;
+    while (m >= 2.0f) { m *= 0.5f; ++e; }
+    while (m < 1.0f) { m *= 2.0f; --e; }
+    const unsigned int frac = (unsigned int)((m - 1.0f) * 8388608.0f);       // exact: m - 1 has 23 fraction bits
+    return sign | ((unsigned int)(e + 127) << 23) | frac;
+}
+constexpr unsigned long long w64_bits(int k) { return ((unsigned long long)float_bits_ce(w64_im(k)) << 32) | float_bits_ce(w64_re(k)); }
+
+// Decimation-in-time butterfly on complex values held as (re, im) pairs:
+// (a, b) -> (a + w b, a - w b), w = W_64^K64.  Two packed instructions where w is 1 or -i, three otherwise.
+template <int K64>
+SONO_HD void bfly_pk(pk2 &a, pk2 &b)
+{
+    if constexpr (K64 == 0) {
+        const pk2 x = pk_add(a, b);
+        b = pk_sub(a, b); a = x;
+    } else if constexpr (K64 == 16) {
+        const pk2 x = pk_add_negi(a, b);
+        b = pk_sub_negi(a, b); a = x;
+    } else {
+        constexpr unsigned long long w = w64_bits(K64);      // evaluated here, at compile time
+        const pk2 x = pk_add_wmul(a, b, w);
+        b = pk_twice_minus(a, x); a = x;
+    }
+}
+
+// In-place N-point DFT (N = 2..64) of complex values held as (re, im) pairs, input in
+// bit-reversed order, output in natural order.
+template <int N>
+SONO_HD void cdft_bitrev_in(pk2 (&z)[N])
+{
+    constexpr int L = ilog2(N);
+    static_for<1, L + 1>([&](auto s_) {
+        constexpr int len = 1 << decltype(s_)::value, half = len / 2;
+        static_for<0, N / len>([&](auto b_) {
+            constexpr int base = decltype(b_)::value * len;
+            static_for<0, half>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                bfly_pk<j * (64 / len)>(z[base + j], z[base + j + half]);
+            });
+        });
+    });
+}
+
+}  // namespace tile
+}  // namespace sono
+
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 #define R4(s) s s s s
