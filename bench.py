@@ -17,7 +17,9 @@ must equal N); started plainly with --gpus N > 1 it launches the N ranks itself
 500 kHz files spread over the ranks, strong scaling; cfg4: FFT 4096 Blackman 95 %
 overlap over 10 min; cfg5: survey pass over a long channel per rank -- per-frame
 peak features at 75 % overlap plus the detector's fast scan at 50 % overlap, no u8
-rows); those lines carry their own workload description and the same fields.
+rows -- cfg5 with the whole detector behind it and the call-summary rows gathered
+over the ranks, cfg5_pcm16 up to the fast scan's run list on 16-bit PCM); those
+lines carry their own workload description and the same fields.
 
 Prints ONE JSON line on rank 0.  `roofline` prices the fused kernel against the
 HBM peak using the algorithmic bytes per frame (each sample read once, each
@@ -145,8 +147,8 @@ FILE_SAMPLES = 2500000          # cfg3: 5 s at 500 kHz
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; cfg5: 2)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 3; cfg5: 1)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
     ap.add_argument("--seconds", type=int, default=None,
                     help="length of the recording per GPU (default: 3600 for cfg2, 600 for cfg4, 43200 for cfg5)")
@@ -155,6 +157,10 @@ def main():
                     help="seconds of audio in the CPU baseline's sample, processed repeatedly for >= 10 s (0 disables it)")
     args = ap.parse_args()
 
+    if args.steps is None:
+        args.steps = 2 if args.workload == "cfg5" else 20
+    if args.warmup is None:
+        args.warmup = 1 if args.workload == "cfg5" else 3
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args.gpus)
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
@@ -205,6 +211,12 @@ def main():
     if pcm16:
         x = torch.clamp(torch.round(x * 32768.0), -32768, 32767).to(torch.int16)
     bytes_per_frame = (2 if pcm16 else 4) * hop + (0 if features_only else bins) + 6
+    detect = args.workload == "cfg5"          # the survey pass with the detector behind it
+    if detect:
+        # sono_process_full_file takes the recording as the reference's processFullFile does: a host array
+        from spectrogram_amd import framing
+        x_host = x.cpu().numpy()
+        det_rows = []
     if not features_only:
         out = torch.empty(frames * bins, dtype=torch.uint8, device="cuda")
     else:
@@ -241,6 +253,13 @@ def main():
             return
         engine.stft_features_dev(x.data_ptr(), 1, per, per, noverlap, peak_bin.data_ptr(), peak_mag.data_ptr(),
                                  gmax.data_ptr(), stream.cuda_stream)
+        if detect:
+            # processFullFile (batCallDetector.js:584-840) in one library call: fast scan at 50 % overlap, regions,
+            # analysis spectrograms at hop 32, framing and measurement of every call; then the table's rows
+            calls = framing.process_full_file_native(engine, x_host, sr, 10.0, 128.0, {"threshold_dB": -60, "padding_ms": 5},
+                                                     {"debugMode": True})
+            det_rows[:] = [sharding.calls_to_rows(calls, file_id=rank, channel=0)]
+            return
         engine.stft_band_active_dev(x.data_ptr(), 1, per, per, scan_v, min_bin, max_bin, target, active.data_ptr(), 0,
                                     stream.cuda_stream)
         sa._check(sa.lib().sono_detect_runs_dev(engine._handle(), active.data_ptr(), scan_frames, run_first.data_ptr(),
@@ -274,6 +293,11 @@ def main():
     gmax_f = float(gmax.view(torch.float32).item())
     active_frames = int((peak_mag > 0.4 * gmax_f).sum().item())
     extra = float(run_count.item()) if features_only else 0.0
+    call_table = None
+    if detect:
+        # the path's one collective: the per-GPU call-summary tables, gathered (row counts first, then the rows)
+        call_table = sharding.gather_call_tables(det_rows[0], device=coll_device)
+        extra = float(det_rows[0].shape[0])
     row = torch.tensor([float(rank), float(frames), gmax_f, float(active_frames), extra], dtype=torch.float64,
                        device=coll_device)
     rows = [row]
@@ -300,7 +324,9 @@ def main():
             "cfg5_pcm16": f"{seconds / 3600:g} h synthetic {sr} Hz channel per GPU as 16-bit PCM in HBM: per-frame peak features at FFT "
                           f"{n_fft} 75% overlap ({frames} frames, no u8 rows) + fused fast scan at 50% overlap + run extraction",
             "cfg5": f"{seconds / 3600:g} h synthetic {sr} Hz channel per GPU: per-frame peak features at FFT {n_fft} 75% overlap "
-                    f"({frames} frames, no u8 rows) + fused fast scan at 50% overlap (band energy test in the STFT kernel, run extraction)",
+                    f"({frames} frames, no u8 rows) + the whole detector on the channel (processFullFile: fast scan at 50% overlap, "
+                    f"regions, analysis spectrograms at hop 32, call framing and measurement; recording handed over as a host "
+                    f"array, so its upload is inside the step) + call-summary rows, gathered over the ranks after the timed region",
         }[args.workload]
         result = {
             "metric": "STFT frames/sec (audio-sec/sec) at FFT 1024, 75% overlap, 384 kHz; % HBM roofline",
@@ -333,8 +359,11 @@ def main():
         }
         if features_only:
             # the step is more than the one kernel the roofline prices: say so instead of a misleading fraction
-            result["roofline"]["note"] = ("kernel_ms covers the features pass AND the fast scan; bytes_per_frame counts "
-                                          "the features pass only")
+            result["roofline"]["note"] = ("kernel_ms covers the features pass AND what follows it in the step (fast scan; cfg5: "
+                                          "the detector's device work); bytes_per_frame counts the features pass only")
+        if detect:
+            result["calls"] = {"rows_all_ranks": int(call_table.shape[0]), "rows_rank0": int(det_rows[0].shape[0]),
+                               "columns": len(sharding.COLUMNS)}
         traffic = measured_traffic() if args.workload == "cfg2" and seconds == SECONDS else None
         if traffic:
             result["roofline"]["traffic"] = traffic["hbm_bytes"]

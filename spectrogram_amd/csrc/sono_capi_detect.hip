@@ -571,9 +571,12 @@ int sono_wav_parse(const uint8_t *b, size_t len, sono_wav_info *info)
     auto u32 = [&](size_t p) { return u16(p) | (u16(p + 2) << 16); };
     bool have_fmt = false, have_data = false;
     size_t pos = 12;                                                             // fileLoader.js:11
-    while (pos + 8 <= len) {                                                     // fileLoader.js:12
+    // The reference stops at the first 'data' chunk (js:50-53) and takes the sample rate from the first 'fmt '
+    // chunk (js:20-22).  This walk keeps both choices -- later 'fmt ' and 'data' chunks change nothing -- but goes
+    // on past 'data', on purpose: a GUANO chunk usually follows the samples.
+    while (pos + 8 < len) {                                                      // fileLoader.js:12: pos < byteLength - 8
         const uint32_t size = u32(pos + 4);
-        if (std::memcmp(b + pos, "fmt ", 4) == 0 && pos + 8 + 16 <= len) {
+        if (std::memcmp(b + pos, "fmt ", 4) == 0 && !have_fmt && !have_data && pos + 8 + 16 <= len) {
             info->format_tag = u16(pos + 8);
             info->channels = u16(pos + 10);                                      // fileLoader.js:45
             info->sample_rate = u32(pos + 12);                                   // fileLoader.js:20,46

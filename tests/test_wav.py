@@ -1,6 +1,9 @@
 """WAV / PCM ingest: the RIFF chunk walk on any machine, the GPU conversion against numpy.
 The reference decodes in the browser (WebAudio), so there is no reference vector for the sample
-scaling: integer PCM / 2^(bits-1) is the WebAudio convention -- parity unpinned."""
+scaling: integer PCM / 2^(bits-1) is the WebAudio convention -- parity unpinned.  The header walk is
+checked against hand-derived cases (expected values from reading fileLoader.js:7-63) and a CPU
+restatement of its two functions (oracle/wav_oracle.py): unpinned as well, nothing of the reference
+was run for them."""
 import struct
 
 import numpy as np
@@ -48,6 +51,73 @@ def test_wav_parse_walks_chunks_like_the_reference():
     for bad in (b"", b"RIFF\0\0\0\0WAVX", w[:20]):
         with pytest.raises(sa.SonoError):
             sa.wav_info(bad)
+
+
+def riff(chunks, pad=True):
+    body = b"WAVE"
+    for cid, payload in chunks:
+        body += cid + struct.pack("<I", len(payload)) + payload + (b"\0" if pad and len(payload) % 2 else b"")
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def fmt_chunk(sr, channels=1, bits=16, tag=1, extra=b""):
+    return struct.pack("<HHIIHH", tag, channels, sr, sr * channels * bits // 8, channels * bits // 8, bits) + extra
+
+
+# Files whose expected values follow from reading modules/fileLoader.js:7-63 (nothing of the reference was run:
+# parity unpinned); oracle/wav_oracle.py restates the two functions and is checked against the same literals.
+HAND_CASES = [
+    # name, file, sample rate (getWavSampleRate), channels, bits, declared data size, duration or None (walk raises)
+    ("plain", riff([(b"fmt ", fmt_chunk(384000)), (b"data", bytes(200))]), 384000, 1, 16, 200, 100 / 384000),
+    ("odd chunks before fmt and data",
+     riff([(b"junk", b"abc"), (b"fmt ", fmt_chunk(500000, 2, 16)), (b"LIST", b"x"), (b"data", bytes(400))]),
+     500000, 2, 16, 400, 100 / 500000),
+    # two 'fmt ' chunks in front of 'data': getWavSampleRate returns at the first (js:20-22), getWavDuration keeps the last (js:46-49)
+    ("two fmt chunks", riff([(b"fmt ", fmt_chunk(96000)), (b"fmt ", fmt_chunk(192000, 2, 24)), (b"data", bytes(600))]),
+     96000, 2, 24, 600, 100 / 192000),
+    # a 'fmt ' chunk behind 'data' is never reached by getWavDuration (break, js:52)
+    ("fmt after data", riff([(b"fmt ", fmt_chunk(256000)), (b"data", bytes(64)), (b"fmt ", fmt_chunk(8000, 2, 8))]),
+     256000, 1, 16, 64, 32 / 256000),
+    # a data chunk that declares more than the file holds: the declared size counts (js:51, 57-60)
+    ("truncated data", riff([(b"fmt ", fmt_chunk(384000)), (b"data", bytes(100))])[:-40], 384000, 1, 16, 100, 50 / 384000),
+    ("extensible format", riff([(b"fmt ", fmt_chunk(250000, 1, 16, 0xFFFE, struct.pack("<HHI", 22, 16, 4) + struct.pack("<H", 1) + bytes(14))),
+                                (b"data", bytes(50))]), 250000, 1, 16, 50, 25 / 250000),
+    # no 'fmt ': the rate falls back to 256000 (js:26) and the duration to 0 (js:57, 62)
+    ("no fmt", riff([(b"LIST", b"abcd"), (b"data", bytes(32))]), 256000, 1, 16, 32, 0.0),
+    ("no data", riff([(b"fmt ", fmt_chunk(384000))]), 384000, 1, 16, 0, 0.0),
+    # the header of the last chunk ends exactly at the end of the file: `pos < byteLength - 8` is false, it is not looked at
+    ("data header at the very end", riff([(b"fmt ", fmt_chunk(384000))]) + b"data" + struct.pack("<I", 16), 384000, 1, 16, 0, 0.0),
+]
+
+
+@pytest.mark.parametrize("case", HAND_CASES, ids=[c[0] for c in HAND_CASES])
+def test_wav_header_hand_derived_cases(case):
+    from oracle import wav_oracle as wo
+    name, w, rate, channels, bits, data_size, duration = case
+    assert wo.get_wav_sample_rate(w) == rate
+    parts = wo.get_wav_duration_parts(w)
+    assert (parts["channels"], parts["bits_per_sample"], parts["data_size"]) == (channels, bits, data_size)
+    assert parts["duration"] == pytest.approx(duration, rel=1e-12, abs=0.0)
+    # sono_wav_parse against the same reading.  Where the two reference functions disagree (two 'fmt ' chunks) it
+    # keeps the first chunk, as getWavSampleRate does; it clips a data chunk to the file; and it reports a file
+    # without fmt or data, which the reference answers with its defaults, as an error.
+    if name in ("no fmt", "no data", "data header at the very end"):
+        with pytest.raises(sa.SonoError):
+            sa.wav_info(w)
+        return
+    info = sa.wav_info(w)
+    assert info["sample_rate"] == rate
+    if name == "two fmt chunks":
+        assert (info["channels"], info["bits_per_sample"]) == (1, 16)
+        return
+    assert (info["channels"], info["bits_per_sample"]) == (channels, bits)
+    assert info["data_offset"] == parts["data_pos"]
+    held = min(data_size, len(w) - parts["data_pos"])
+    assert info["data_bytes"] == held and info["frames"] == held // (channels * bits // 8)
+    if name != "truncated data":
+        assert info["frames"] / info["sample_rate"] == pytest.approx(duration, rel=1e-12)
+    if name == "extensible format":
+        assert info["format_tag"] == 1                       # the sub-format of the extension
 
 
 @pytest.mark.gpu
