@@ -93,6 +93,39 @@ def cpu_baseline(x, threads, min_seconds=10.0):
             "audio_s_per_s": done * HOP / SAMPLE_RATE / dt}
 
 
+def end_to_end(sa, torch, engine, x_dev, n_fft, noverlap, frames, bins):
+    """What a host caller of compute_spectrogram_u8 sees (the wasm glue copies in and out as well,
+    spectrogram_wasm.js:58-63, 313-320): the recording in pageable host memory, the rows into a host buffer,
+    through sono_stft_u8's chunked pipeline; and beside it the plain PCIe copies of the same bytes from and to
+    pinned memory.  Outside the timed region; never part of `value`."""
+    import ctypes as C
+    import numpy as np
+    x = x_dev.cpu().numpy()
+    out = np.zeros(frames * bins, dtype=np.uint8)                 # touched: no page faults inside the timing
+    got = C.c_size_t(0)
+    f32p, u8p = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+
+    def call():
+        t0 = time.perf_counter()
+        sa._check(sa.lib().sono_stft_u8(engine._handle(), x.ctypes.data_as(f32p), x.size, noverlap, GAIN_DB, RANGE_DB,
+                                        out.ctypes.data_as(u8p), out.size, C.byref(got)))
+        return time.perf_counter() - t0
+    call()                                                        # first call builds the pinned and device rings
+    dt = min(call() for _ in range(3))
+    pin_in = torch.empty(x.size, dtype=torch.float32, pin_memory=True)
+    pin_out = torch.empty(out.size, dtype=torch.uint8, pin_memory=True)
+    dev_out = torch.empty(out.size, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); x_dev.copy_(pin_in, non_blocking=True); torch.cuda.synchronize(); h2d = time.perf_counter() - t0
+    t0 = time.perf_counter(); pin_out.copy_(dev_out, non_blocking=True); torch.cuda.synchronize(); d2h = time.perf_counter() - t0
+    x_dev.copy_(torch.from_numpy(x))                              # the recording back in place
+    return {"ms": dt * 1e3, "frames_per_s": got.value / dt, "audio_s_per_s": got.value * (n_fft - noverlap) / SAMPLE_RATE / dt,
+            "GBps_h2d": x.nbytes / h2d / 1e9, "GBps_d2h": out.nbytes / d2h / 1e9,
+            "pcie_floor_ms": max(h2d, d2h) * 1e3, "over_pcie_floor": dt / max(h2d, d2h),
+            "note": "host pointers in and out (pageable memory), sono_stft_u8: chunks of frames through pinned rings, copy-in, upload, "
+                    "kernel, download and copy-out overlapped; GBps_* = one plain copy of the same bytes from / to pinned memory"}
+
+
 def measured_traffic():
     """HBM bytes per launch of the timed kernel from the committed rocprofv3 counter passes
     (profiles/hbm_traffic.json, written by tools/profile_summary.py), or None."""
@@ -153,6 +186,7 @@ def main():
     ap.add_argument("--seconds", type=int, default=None,
                     help="length of the recording per GPU (default: 3600 for cfg2, 600 for cfg4, 43200 for cfg5)")
     ap.add_argument("--files", type=int, default=10000, help="cfg3: number of files over all ranks")
+    ap.add_argument("--no-end-to-end", action="store_true", help="cfg2: skip the host-pointer (PCIe-inclusive) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=600.0,
                     help="seconds of audio in the CPU baseline's sample, processed repeatedly for >= 10 s (0 disables it)")
     args = ap.parse_args()
@@ -368,6 +402,8 @@ def main():
         if traffic:
             result["roofline"]["traffic"] = traffic["hbm_bytes"]
             result["roofline"]["traffic_source"] = traffic["source"]
+        if world == 1 and args.workload == "cfg2" and not args.no_end_to_end:
+            result["end_to_end"] = end_to_end(sa, torch, engine, x, n_fft, noverlap, frames, bins)
         if world == 1 and args.cpu_seconds > 0 and args.workload == "cfg2":
             threads = min(16, os.cpu_count() or 1)
             n_cpu = int(min(args.cpu_seconds, seconds) * sr)

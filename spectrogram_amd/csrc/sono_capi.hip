@@ -152,6 +152,7 @@ void sono_engine_destroy(sono_engine *e)
         slot.buf.release();
     }
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    if (e->pipe) sono::stream_pipe_destroy(e->pipe);
     delete e;
 }
 
@@ -196,6 +197,7 @@ int sono_engine_release_memory(sono_engine *e)
     e->d_mags.release(); e->d_bank.release();
     e->d_db.release(); e->d_flags.release(); e->d_edges.release(); e->d_runs.release(); e->d_select_tmp.release();
     e->h_in.release(); e->h_out.release(); e->full_file_calls.clear(); e->full_file_calls.shrink_to_fit();
+    if (e->pipe) { sono::stream_pipe_destroy(e->pipe); e->pipe = nullptr; }
     return SONO_OK;
 }
 
@@ -235,6 +237,14 @@ int check_batch(const sono_engine *e, const sono_batch *in, uint32_t noverlap, c
     if (in->n_streams > 1 && in->stream_stride < in->samples_per_stream)
         return fail(SONO_EINVAL, std::string(who) + ": stream_stride < samples_per_stream");
     return SONO_OK;
+}
+
+// SONO_NO_STREAMING=1 (read per call) keeps long host-pointer calls on the one-copy-each-way form: the tests
+// compare the two.
+bool no_streaming()
+{
+    const char *v = std::getenv("SONO_NO_STREAMING");
+    return v && v[0] && v[0] != '0';
 }
 
 // Uploads the samples the frames actually touch.
@@ -548,6 +558,18 @@ int sono_stft_u8(sono_engine *e, const float *x, size_t n, uint32_t noverlap, fl
     if (F == 0) return SONO_OK;
     if (!out || cap < F * out_bins) return fail(SONO_ECAPACITY, "sono_stft_u8: output buffer too small");
     DeviceGuard guard(e->device);
+    if (!bank && F > 2 * sono::stream_chunk_frames(e->N - noverlap) && !no_streaming()) {
+        // a long recording: chunks of frames through pinned rings, copies and kernels overlapped (sono_stream.hip)
+        e->last_peak_bin.resize(F);
+        e->last_peak_mag.resize(F);
+        uint32_t gbits = 0;
+        const int rc = sono::stream_stft_u8(e, &e->pipe, x, F, noverlap, gain_db, range_db, out, e->last_peak_bin.data(),
+                                            e->last_peak_mag.data(), &gbits);
+        if (rc) { e->last_peak_bin.clear(); e->last_peak_mag.clear(); return rc; }
+        std::memcpy(&e->last_gmax, &gbits, 4);
+        if (frames) *frames = F;
+        return SONO_OK;
+    }
     int rc = stage_input(e, x, n, noverlap, F);
     if (rc) return rc;
     HIP_TRY(e->d_out.reserve(F * out_bins));

@@ -12,6 +12,8 @@
 #include "sono_core.h"
 #include "sono_tile.h"
 
+struct sono_engine;
+
 namespace sono {
 
 // Records the calling thread's error message and returns `code`.
@@ -72,6 +74,11 @@ struct Tables {
     }
 };
 
+// The chunked host-pointer pipeline of sono_stft_u8 (sono_stream.hip): pinned and device rings, copy threads.
+struct StreamPipe;
+void stream_pipe_destroy(StreamPipe *p);
+size_t stream_chunk_frames(uint32_t hop);
+
 // Makes `dev` (if >= 0) the current HIP device for the lifetime of the guard.
 class DeviceGuard {
 public:
@@ -90,6 +97,9 @@ private:
     bool ok_, changed_ = false;
     int prev_;
 };
+
+int stream_stft_u8(sono_engine *e, StreamPipe **pipe, const float *x, size_t frames, uint32_t noverlap, float gain_db,
+                   float range_db, uint8_t *out, uint16_t *peak_bin, float *peak_mag, uint32_t *gmax_bits);
 
 }  // namespace sono
 
@@ -116,6 +126,7 @@ struct sono_engine {
     RaggedSlot ragged[2];
     unsigned int ragged_next = 0;
     hipStream_t copy_stream = nullptr;      // uploads the tables without waiting for the caller's stream
+    sono::StreamPipe *pipe = nullptr;       // rings of the chunked host-pointer path, created on first use
     // calls of the last sono_process_full_file, kept for sono_full_file_results
     std::vector<sono_full_file_call> full_file_calls;
     // filter bank (lib.rs:20-22)
