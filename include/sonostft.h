@@ -143,7 +143,11 @@ typedef struct sono_batch {
  * frame f lands at row s*frames_per_stream + f.  d_peak_bin / d_peak_mag /
  * d_gmax_bits may be NULL.  d_gmax_bits is ONE uint32 holding the f32 bit pattern
  * of the running maximum; the caller zeroes it (it is only ever raised).
- * hip_stream: a hipStream_t, or NULL for the engine's stream. */
+ * hip_stream: a hipStream_t, or NULL for the engine's stream.
+ * Alignment (all _dev forms, uniform and ragged): d_out of the u8 forms on 4 bytes, d_out of the
+ * magnitude forms on 16 bytes -- the rows are written with dword / 4-dword stores; anything else is
+ * SONO_EINVAL.  (hipMalloc returns 256-byte aligned memory; only offset pointers can fail this.)
+ * The samples need no alignment beyond that of their type. */
 int sono_stft_u8_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap,
                      float gain_db, float range_db,
                      uint8_t *d_out, uint16_t *d_peak_bin, float *d_peak_mag,

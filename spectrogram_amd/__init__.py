@@ -301,12 +301,14 @@ def lib():
     """The loaded libsonostft.so.  Raises if the in-tree build is missing."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        # SONO_LIB_PATH: another build of the same library (the host-sanitizer build of build.py --asan)
+        path = os.environ.get("SONO_LIB_PATH") or LIB_PATH
+        if not os.path.exists(path):
             raise ImportError(
-                f"{LIB_PATH} is missing: build it with `python -m spectrogram_amd.build` "
+                f"{path} is missing: build it with `python -m spectrogram_amd.build` "
                 "(hipcc, gfx950).  There is no CPU fallback.")
         _share_torch_hip_runtime()
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res

@@ -44,24 +44,37 @@ def _all_headers():
     return hs
 
 
-def build(force=False, verbose=False):
+# --asan: the same library with AddressSanitizer and UndefinedBehaviorSanitizer on the HOST code of every
+# translation unit (the C ABI, the framing and measurement stages; device code is compiled as always: there is
+# no GPU sanitizer on this hardware pool).  Loaded through SONO_LIB_PATH by tools/asan_tests.sh.
+ASAN_LIB = os.path.join(LIBDIR, "libsonostft_asan.so")
+ASAN_OBJDIR = os.path.join(HERE, "build", "asan")
+ASAN_HOST = ["-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined", "-Xarch_host", "-fno-omit-frame-pointer", "-g"]
+
+
+def build(force=False, verbose=False, asan=False):
     os.makedirs(LIBDIR, exist_ok=True)
-    os.makedirs(OBJDIR, exist_ok=True)
+    objdir, lib_path = (ASAN_OBJDIR, ASAN_LIB) if asan else (OBJDIR, LIB)
+    os.makedirs(objdir, exist_ok=True)
     headers = _all_headers()
     objs = []
     jobs = []
     for src in HIP_SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJDIR, src + ".o")
+        o = os.path.join(objdir, src + ".o")
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + HIP_FLAGS + (ASAN_HOST if asan else []) + ["-c", s, "-o", o])
     for src in CXX_SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJDIR, src + ".o")
+        o = os.path.join(objdir, src + ".o")
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            jobs.append(["g++"] + CXX_FLAGS + ["-c", s, "-o", o])
+            if asan:        # one sanitizer runtime for the whole library: clang's, through hipcc
+                jobs.append([HIPCC, "-x", "c++"] + CXX_FLAGS + ["-fsanitize=address", "-fsanitize=undefined", "-fno-omit-frame-pointer", "-g",
+                                                              "-c", s, "-o", o])
+            else:
+                jobs.append(["g++"] + CXX_FLAGS + ["-c", s, "-o", o])
     procs = []
     for cmd in jobs:
         if verbose:
@@ -70,13 +83,15 @@ def build(force=False, verbose=False):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("build failed: " + " ".join(cmd))
-    if jobs or force or not os.path.exists(LIB):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    if jobs or force or not os.path.exists(lib_path):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib_path] + objs
+        if asan:
+            cmd += ["-fsanitize=address", "-fsanitize=undefined", "-shared-libsan"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, asan="--asan" in sys.argv))

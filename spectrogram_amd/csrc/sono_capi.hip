@@ -239,6 +239,14 @@ int check_batch(const sono_engine *e, const sono_batch *in, uint32_t noverlap, c
     return SONO_OK;
 }
 
+// Every kernel writes its rows with 16-byte (magnitudes) or 4-byte (u8 codes) stores.
+int check_aligned(const void *p, unsigned int bytes, const char *who, const char *what)
+{
+    if (reinterpret_cast<uintptr_t>(p) & (bytes - 1))
+        return fail(SONO_EINVAL, std::string(who) + ": " + what + " must be " + std::to_string(bytes) + "-byte aligned");
+    return SONO_OK;
+}
+
 // SONO_NO_STREAMING=1 (read per call) keeps long host-pointer calls on the one-copy-each-way form: the tests
 // compare the two.
 bool no_streaming()
@@ -270,6 +278,7 @@ int sono_stft_mag_f32_dev(sono_engine *e, const sono_batch *in, uint32_t noverla
     fill_args(e, *in, noverlap, a);
     if (a.n_streams * a.frames_per_stream == 0) return SONO_OK;
     if (!d_out) return fail(SONO_EINVAL, "sono_stft_mag_f32_dev: d_out is NULL");
+    if ((rc = check_aligned(d_out, 16, "sono_stft_mag_f32_dev", "d_out")) != SONO_OK) return rc;
     a.out_mag = d_out;
     DeviceGuard guard(e->device);
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
@@ -287,6 +296,7 @@ int sono_stft_u8_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap, fl
     fill_args(e, *in, noverlap, a);
     if (a.n_streams * a.frames_per_stream == 0) return SONO_OK;
     if (!d_out) return fail(SONO_EINVAL, "sono_stft_u8_dev: d_out is NULL");
+    if ((rc = check_aligned(d_out, 4, "sono_stft_u8_dev", "d_out")) != SONO_OK) return rc;
     const sono::Quant q = sono::make_quant(e->N, gain_db, range_db);
     a.out_u8 = d_out; a.peak_bin = d_peak_bin; a.peak_mag = d_peak_mag; a.gmax_bits = d_gmax_bits;
     a.q_a = q.a; a.q_c = q.c; a.q_floor = q.floor;
@@ -449,6 +459,7 @@ int sono_stft_u8_ragged_dev(sono_engine *e, const sono_ragged_batch *in, uint32_
     const sono::Quant q = sono::make_quant(e->N, gain_db, range_db);
     a.out_u8 = d_out; a.peak_bin = d_peak_bin; a.peak_mag = d_peak_mag; a.gmax_bits = d_gmax_bits;
     a.q_a = q.a; a.q_c = q.c; a.q_floor = q.floor;
+    if (const int rc = check_aligned(d_out, 4, "sono_stft_u8_ragged_dev", "d_out")) return rc;
     return run_ragged(e, in, noverlap, sono::MODE_U8, a, hip_stream, "sono_stft_u8_ragged_dev");
 }
 
@@ -460,6 +471,7 @@ int sono_stft_mag_f32_ragged_dev(sono_engine *e, const sono_ragged_batch *in, ui
     sono::StftArgs a;
     fill_common(e, noverlap, a);
     a.out_mag = d_out;
+    if (const int rc = check_aligned(d_out, 16, "sono_stft_mag_f32_ragged_dev", "d_out")) return rc;
     return run_ragged(e, in, noverlap, sono::MODE_MAG, a, hip_stream, "sono_stft_mag_f32_ragged_dev");
 }
 

@@ -141,3 +141,35 @@ extern "C" int emul_tile(int mode, const float *x, unsigned long long n_streams,
 #undef RUN
     return 0;
 }
+
+// The per-frame peak of ONE frame given as 512 values of |2X|^2 (fft 1024 geometry): the epilogue's search over the
+// frame's 16 lanes and the reduction over them, as the kernel does it.  For the test of the tie rule.
+extern "C" int emul_peak_of_powers(const float *p512, unsigned int *bin, float *mag)
+{
+    using G = tile::Geo<5, 5>;
+    StftArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.N = 1024; a.hop = 256; a.frames_per_stream = 1; a.n_streams = 1; a.inv_n = 1.0f / 1024.0f;
+    const Quant q = make_quant(1024, 20.0f, 80.0f);
+    a.q_a = q.a; a.q_c = q.c; a.q_floor = q.floor;
+    alignas(16) static float img[G::REGION];
+    std::memset(img, 0, sizeof(img));
+    for (int k = 0; k < G::BINS; ++k) img[k] = p512[k];                      // frame 0 of the power image
+    float meta[tile::kMetaFloats];
+    for (float &m : meta) m = 1.0f;
+    tile::TileRef tr;
+    std::memset(&tr, 0, sizeof(tr));
+    tr.frames = 1; tr.rem = 1;
+    float best = -1.0f;
+    unsigned int best_bin = 0xFFFFFFFFu;
+    for (int l = 0; l < G::HALF; ++l) {                                      // the 16 lanes of frame 0
+        tile::TileLane<5, 5, MODE_U8, 1> lane(a, l);
+        float bp; unsigned int bk;
+        lane.template epilogue<false>(tr, img, meta, bp, bk);
+        if (bp > best) { best = bp; best_bin = bk; }
+        else if (bp == best && bk < best_bin) best_bin = bk;
+    }
+    *bin = best_bin;
+    *mag = fast_sqrt(best) * a.inv_n;
+    return 0;
+}

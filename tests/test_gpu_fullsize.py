@@ -131,3 +131,38 @@ def test_pulse_frames_peak_on_the_sweep(hour):
     for pulse in (0, 5, 12345, 35999):
         f = pulse * 150 + 2            # frame starting 2 hops into the pulse
         assert 75 <= pb[f].item() <= 220, (pulse, pb[f].item())
+
+
+def test_peak_bins_against_first_maximum_of_the_magnitude_rows(hour):
+    """The reference takes the per-frame peak on the ROUNDED f32 magnitude, first maximum wins (lib.rs:370-378); the
+    kernel takes it on |2X|^2 -- largest power, lowest bin among equal powers -- and the two differ exactly when two
+    bins whose powers differ by an ulp or two round to the same magnitude and the earlier one has the smaller power.
+    Counted here on the benchmark recording: over every frame, the kernel's peak bin against the first maximum of
+    its own magnitude rows (sqrt of the same powers).  Such near-ties are rare enough to be counted in single
+    frames, and where they happen the two bins hold the same magnitude bit for bit, so peak magnitudes, the global
+    maximum and every threshold test are unaffected."""
+    torch = hour["torch"]
+    e, x, F = hour["e"], hour["x"], hour["F"]
+    block = 1 << 19
+    mags = torch.empty(block * 512, dtype=torch.float32, device="cuda")
+    differ = ties = 0
+    for f0 in range(0, F, block):
+        nf = min(block, F - f0)
+        ns = (nf - 1) * H + N
+        e.stft_mag_f32_dev(x.data_ptr() + 4 * f0 * H, 1, ns, ns, V, mags.data_ptr())
+        e.synchronize()
+        m = mags[: nf * 512].view(nf, 512)
+        top = m.max(dim=1, keepdim=True).values
+        at_top = m == top
+        first = torch.where(at_top, torch.arange(512, device="cuda").expand(nf, 512), 512).min(dim=1).values
+        got = hour["pb"][f0:f0 + nf].to(torch.int64) & 0xFFFF
+        silent = top[:, 0] == 0
+        bad = (first != got) & ~silent
+        differ += int(bad.sum().item())
+        ties += int(((at_top.sum(dim=1) > 1) & ~silent).sum().item())
+        assert torch.equal(hour["pm"][f0:f0 + nf], top[:, 0])            # the peak magnitude is the row maximum, always
+        if bad.any():                                                   # where they differ, both bins hold the row maximum
+            idx = torch.nonzero(bad)[:, 0]
+            assert torch.equal(m[idx, got[idx]], top[idx, 0])
+    print(f"frames {F}: magnitude ties at the row maximum {ties}, peak bin differs from the first maximum in {differ}")
+    assert differ <= F // 100000

@@ -244,6 +244,32 @@ def test_unaligned_input_pointer(kernel_path):
     e.free()
 
 
+def test_misaligned_output_pointers_are_refused():
+    # rows are written with dword (u8) and 4-dword (magnitude) stores: an output that starts off such a boundary
+    # is an argument error, not a silent fallback to stores the pointer does not allow
+    import torch
+    N, V = 1024, 768
+    x = torch.from_numpy(signal(N + 15 * 256, 7)).cuda()
+    F = sa.frames_for(x.numel(), N, V)
+    e = sa.SpectrogramEngine(N, "hann")
+    u8 = torch.zeros(F * 512 + 16, dtype=torch.uint8, device="cuda")
+    mag = torch.zeros(F * 512 + 16, dtype=torch.float32, device="cuda")
+    for off in (1, 2, 3):
+        with pytest.raises(sa.SonoError) as ei:
+            e.stft_u8_dev(x.data_ptr(), 1, x.numel(), x.numel(), V, 20.0, 80.0, u8.data_ptr() + off, 0, 0, 0)
+        assert ei.value.status == 1 and "4-byte aligned" in str(ei.value)
+    for off in (4, 8, 12):
+        with pytest.raises(sa.SonoError) as ei:
+            e.stft_mag_f32_dev(x.data_ptr(), 1, x.numel(), x.numel(), V, mag.data_ptr() + off)
+        assert ei.value.status == 1 and "16-byte aligned" in str(ei.value)
+    # aligned offsets are fine, and nothing in front of them is touched
+    e.stft_u8_dev(x.data_ptr(), 1, x.numel(), x.numel(), V, 20.0, 80.0, u8.data_ptr() + 4, 0, 0, 0)
+    e.stft_mag_f32_dev(x.data_ptr(), 1, x.numel(), x.numel(), V, mag.data_ptr() + 16)
+    e.synchronize()
+    assert u8[:4].sum().item() == 0 and mag[:4].abs().sum().item() == 0 and u8[4:].any().item() and mag[4:].any().item()
+    e.free()
+
+
 def test_time_chunks_of_the_sharding_layer_equal_one_call(kernel_path):
     # one recording cut into 3 chunks the way sharding.frame_chunks cuts it for 3 GPUs: rows bit-identical to
     # the unchunked call, global maximum = max over the chunks (the value reduce_global_max all-reduces)

@@ -17,6 +17,8 @@ EMUL_DIR = os.path.join(HERE, "host_emul")
 
 @pytest.fixture(scope="module")
 def emul():
+    if os.environ.get("SONO_EMUL_LIB"):                  # another build of the same sources (tools/asan_tests.sh)
+        return C.CDLL(os.environ["SONO_EMUL_LIB"])
     lib = os.path.join(EMUL_DIR, "libemul.so")
     srcs = [os.path.join(EMUL_DIR, f) for f in os.listdir(EMUL_DIR) if f.endswith(".cpp")]
     deps = srcs + [os.path.join(HERE, "..", "spectrogram_amd", "csrc", h)
@@ -278,3 +280,48 @@ def test_tile_wave_shared_loads_change_nothing(emul, N, V, mode):
     for u, v in zip(res[0], res[1]):
         assert np.array_equal(u, v)
     assert any(np.any(u) for u in res[0])
+
+
+def test_tile_peak_rule_on_near_ties(emul):
+    """The kernels take the per-frame peak on |2X|^2: the largest power wins, the lowest bin among EQUAL powers.  The
+    reference takes it on the rounded f32 magnitude, first maximum wins (lib.rs:370-378).  The two rules differ only when
+    two powers an ulp or two apart round to the same magnitude and the earlier bin holds the smaller power -- the case
+    built here; the magnitude reported is the same either way."""
+    import ctypes as C
+    emul.emul_peak_of_powers.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_uint), C.POINTER(C.c_float)]
+    emul.emul_peak_of_powers.restype = C.c_int
+
+    def peak(p):
+        p = np.ascontiguousarray(p, np.float32)
+        b, m = C.c_uint(0), C.c_float(0)
+        assert emul.emul_peak_of_powers(p.ctypes.data_as(C.POINTER(C.c_float)), C.byref(b), C.byref(m)) == 0
+        return b.value, np.float32(m.value)
+
+    def reference_rule(p):                    # lib.rs:370-378 on mag = sqrt(p) / N in f32
+        mag = np.sqrt(p.astype(np.float32)) * np.float32(1.0 / 1024.0)
+        best, at = np.float32(0.0), 0
+        for k, v in enumerate(mag):
+            if v > best:
+                best, at = v, k
+        return at, best
+
+    rng = np.random.default_rng(3)
+    base = (rng.random(512) * 0.5 + 0.1).astype(np.float32)
+    # exact ties: the lowest bin wins under both rules, wherever the tied bins sit (same lane, other lanes, other groups)
+    for bins in ([7, 300], [300, 301], [4, 5, 6, 7], [0, 511], [129, 130, 400]):
+        p = base.copy()
+        p[bins] = np.float32(2.5)
+        assert peak(p)[0] == reference_rule(p)[0] == min(bins)
+    # a near-tie: two powers one ulp apart whose square roots round to the same f32
+    lo = np.float32(2.5)
+    hi = np.nextafter(lo, np.float32(4.0))
+    assert hi > lo and np.sqrt(lo) == np.sqrt(hi)
+    p = base.copy()
+    p[10], p[200] = lo, hi
+    kb, km = peak(p)
+    rb, rm = reference_rule(p)
+    assert (kb, rb) == (200, 10)              # the larger power / the first of the equal magnitudes
+    assert km == rm                           # and the same magnitude
+    p[10], p[200] = hi, lo                    # the earlier bin larger: both rules agree
+    assert peak(p)[0] == reference_rule(p)[0] == 10
+    assert peak(np.zeros(512, np.float32)) == (0, np.float32(0.0))

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Host-side sanitizer run (CPU only, in the build container): builds libsonostft_asan.so -- AddressSanitizer and
+# UndefinedBehaviorSanitizer on the host code of the C ABI, the framing and measurement stages -- and the
+# lane-by-lane emulation of the kernels the same way, and runs the CPU tests that exercise them against these builds.
+#   bash tools/asan_tests.sh            -> prints pytest's summary; any sanitizer report fails the run
+set -e
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+cd "$ROOT"
+python -m spectrogram_amd.build --asan > /tmp/sono_asan_build.log 2>&1 || { tail -20 /tmp/sono_asan_build.log; exit 1; }
+RT="$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)"
+# the emulation library: same sources the tests build with g++, here with clang and the sanitizers
+/opt/rocm/lib/llvm/bin/clang++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -fsanitize=address -fsanitize=undefined -shared-libsan \
+    -fno-omit-frame-pointer -o tests/host_emul/libemul_asan.so tests/host_emul/emul_generic.cpp tests/host_emul/emul_tile.cpp
+export SONO_LIB_PATH="$ROOT/spectrogram_amd/lib/libsonostft_asan.so" SONO_EMUL_LIB="$ROOT/tests/host_emul/libemul_asan.so"
+export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1
+LD_PRELOAD="$RT${LD_PRELOAD:+:$LD_PRELOAD}" python -m pytest -x -q tests/test_measure_host.py tests/test_framing_host.py tests/test_host_emul.py \
+    tests/test_abi_cpu.py tests/test_wav.py tests/test_guano.py tests/test_plugin_host.py -m "not gpu" "$@"
