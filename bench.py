@@ -164,6 +164,16 @@ def launch_ranks(n):
     return subprocess.call(cmd)
 
 
+def measured_valu():
+    """Vector-ALU counters per launch of the timed kernel from the committed rocprofv3 passes
+    (profiles/valu_counters.json, written by tools/profile_summary.py), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_counters.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
 WORKLOADS = {
     # name: fft, window, alpha, noverlap, sample rate
     "cfg2": dict(fft=1024, window="hann", alpha=None, noverlap=768, sr=384000),
@@ -402,6 +412,18 @@ def main():
         if traffic:
             result["roofline"]["traffic"] = traffic["hbm_bytes"]
             result["roofline"]["traffic_source"] = traffic["source"]
+        counters = measured_valu() if args.workload == "cfg2" and seconds == SECONDS else None
+        if counters:
+            # what the vector ALU actually issued (hardware counters of the committed profile), beside the
+            # conventional-flop figure above: instructions per launch and how busy that keeps the issue ports
+            result["valu_issue"] = {"sq_insts_valu": counters["insts_valu"],
+                                    "issue_busy": counters.get("issue_busy_at_2_cycles"),
+                                    "instructions_per_frame": counters["insts_valu"] * 64.0 / frames,
+                                    "note": "SQ_INSTS_VALU per launch (wave instructions); issue_busy = instructions x 2 cycles / "
+                                            "(1024 SIMDs x the dispatch's shader cycles): plain add/mul/fma issue at one per 2 cycles "
+                                            "and SIMD, conversions, min/max, selects and DPP moves at 4.8, v_log_f32 at 9 "
+                                            "(tools/valubench.hip)",
+                                    "source": counters.get("source")}
         if world == 1 and args.workload == "cfg2" and not args.no_end_to_end:
             result["end_to_end"] = end_to_end(sa, torch, engine, x, n_fft, noverlap, frames, bins)
         if world == 1 and args.cpu_seconds > 0 and args.workload == "cfg2":

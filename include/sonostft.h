@@ -398,6 +398,17 @@ int sono_rms_snr(sono_engine *e, const float *power_db, size_t frames, uint32_t 
 
 /* ---- measurement stage, threshold searches (host only, serial per call) ------- */
 
+/* The two global switches the measurement stage reads, as bits of every `debug_mode` field and argument below.
+ * SONO_DEBUG_MODE: the detector's debugMode (setDebugMode, batCallDetector.js:359-361): the reference keeps a log
+ *   table only then and raises a TypeError without it on some inputs.
+ * SONO_TIME_EXPANSION: getTimeExpansionMode() (fileState.js:158-166), for recordings played back 10 x slowed down:
+ *   a call that reaches the end of measureFrequencyParameters has its frequencies (peak, high, start, end, low,
+ *   characteristic, knee, heel, bandwidth) multiplied by 10 and its times and durations (start / end time, duration,
+ *   every *_ms field, start / end frequency times) divided by 10 (BatCall.applyTimeExpansion, js:185-278, 3890-3893).
+ *   What follows sees the scaled values, as in the reference: the <= 1 ms filter, Flow / Fhigh, the bandwidth classes,
+ *   and the region offset, which is added unscaled (js:802-825). */
+enum { SONO_DEBUG_MODE = 1, SONO_TIME_EXPANSION = 2 };
+
 /* The call's slice of the analysis spectrogram and what the searches need beside it. */
 typedef struct sono_call_matrix {
     const float *power_db;     /* frames x num_bins, row-major */
@@ -408,8 +419,7 @@ typedef struct sono_call_matrix {
     const double *zonal;       /* floors of the 10 kHz zones (sono_zonal_noise_floors), or NULL: the searches
                                   compute them from the slice over the frames the reference uses */
     size_t num_zones;
-    int32_t debug_mode;        /* the detector's debugMode switch (setDebugMode, batCallDetector.js:359-361): the reference
-                                  keeps a log table only then and raises a TypeError without it on some inputs */
+    int32_t debug_mode;        /* SONO_DEBUG_MODE and SONO_TIME_EXPANSION or-ed together (0 and 1 mean what they always did) */
     int32_t pad;
 } sono_call_matrix;
 
@@ -535,14 +545,14 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filter
 /* processFullFile (batCallDetector.js:584-840) in one call: fast scan, merge & pad, batched region analysis, framing,
  * measurement, and the follow-up of js:802-827 (discarded and <= 1 ms calls dropped, classification, placeholder SNR
  * = peak + 80 dB, quality, region time -> file time).  Calls come in the reference's order (per region, strongest
- * first).  SONO_EREFERENCE: debug_mode is 0 and the reference would raise on one of the calls (its promise rejects). */
+ * first).  SONO_EREFERENCE: SONO_DEBUG_MODE is not set and the reference would raise on one of the calls (its promise rejects). */
 typedef struct sono_full_file_options {
     double threshold_db;            /* options.threshold_dB of the fast scan, reference default -60 */
     double padding_ms;              /* options.padding_ms of mergeAndPadSegments, default 5 */
     double hop_percent;             /* config.hopPercent, default 3.125 */
     double call_threshold_db;       /* config.callThreshold_dB, default -24 */
     double min_call_duration_ms;    /* config.minCallDuration_ms, default 1 */
-    int32_t debug_mode;             /* the detector's debugMode switch */
+    int32_t debug_mode;             /* SONO_DEBUG_MODE | SONO_TIME_EXPANSION */
     uint32_t threads;               /* host threads of the measurement stage, 0 = up to 16 */
 } sono_full_file_options;
 enum { SONO_CALL_CF = 0, SONO_CALL_FM = 1, SONO_CALL_CF_FM = 2 };

@@ -33,14 +33,15 @@ function init() { return Promise.resolve(module.exports); }
 // spectrogram, framing and the measurement stage run batched on the GPU and on host threads.  Same calls, same order;
 // each call is a BatCall (when the class is given) carrying the numeric fields, callType and quality -- not the
 // per-call spectrogram slice, which the whole-file pass only needs internally.  Rejects where the reference's promise
-// rejects; detectors without a GPU engine keep the JavaScript path.
-function accelerateBatCallDetector(BatCallDetector, BatCall) {
+// rejects; detectors without a GPU engine keep the JavaScript path.  getTimeExpansionMode is fileState.js's getter
+// (fileState.js:164-166), which the reference's measurement stage reads as a module global (batCallDetector.js:3891).
+function accelerateBatCallDetector(BatCallDetector, BatCall, getTimeExpansionMode) {
   const original = BatCallDetector.prototype.processFullFile;
   BatCallDetector.prototype.processFullFile = async function (fullAudioData, sampleRate, flowKHz, fhighKHz, options = {}) {
     const engine = this.wasmEngine;
     if (!(engine instanceof addon.SpectrogramEngine)) return original.call(this, fullAudioData, sampleRate, flowKHz, fhighKHz, options);
     const progress = options.progressCallback || (() => {});
-    const config = Object.assign({}, this.config, { debugMode: !!this.debugMode });
+    const config = Object.assign({}, this.config, { debugMode: !!this.debugMode, timeExpansion: !!(getTimeExpansionMode && getTimeExpansionMode()) });
     const rows = engine.process_full_file(fullAudioData, sampleRate, flowKHz, fhighKHz, options, config);
     progress(1);
     return rows.map((row) => Object.assign(BatCall ? new BatCall() : {}, row));

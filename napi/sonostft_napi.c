@@ -572,7 +572,7 @@ static napi_value fn_device_count(napi_env env, napi_callback_info info)
  * engine.process_full_file(audio: Float32Array, sampleRate, flowKHz, fhighKHz, options, config) -> Array of objects
  * carrying BatCall's numeric fields under BatCall's own names (null where the reference leaves null).
  * options: {threshold_dB = -60, padding_ms = 5}; config: {hopPercent = 3.125, callThreshold_dB = -24,
- * minCallDuration_ms = 1, debugMode = false}.  Throws where the reference's promise rejects. */
+ * minCallDuration_ms = 1, debugMode = false, timeExpansion = false}.  Throws where the reference's promise rejects. */
 static double prop_f64(napi_env env, napi_value obj, const char *name, double dflt)
 {
     napi_value v;
@@ -628,7 +628,8 @@ static napi_value engine_process_full_file(napi_env env, napi_callback_info info
     opt.hop_percent = prop_f64(env, argv[5], "hopPercent", 3.125);
     opt.call_threshold_db = prop_f64(env, argv[5], "callThreshold_dB", -24);
     opt.min_call_duration_ms = prop_f64(env, argv[5], "minCallDuration_ms", 1);
-    opt.debug_mode = prop_f64(env, argv[5], "debugMode", 0) != 0;
+    opt.debug_mode = (prop_f64(env, argv[5], "debugMode", 0) != 0 ? SONO_DEBUG_MODE : 0) |
+                     (prop_f64(env, argv[5], "timeExpansion", 0) != 0 ? SONO_TIME_EXPANSION : 0);
     opt.threads = 0;
     size_t count = 0;
     int rc = sono_process_full_file(b->e, (const float *)x, n, sr, flow, fhigh, &opt, NULL, 0, &count);

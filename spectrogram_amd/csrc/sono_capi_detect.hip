@@ -438,7 +438,8 @@ int sono_find_optimal_low_frequency_threshold(const sono_call_matrix *m, double 
     int rc = check_matrix(m, false, "sono_find_optimal_low_frequency_threshold");
     if (rc) return rc;
     if (peak_frame < 0) return fail(SONO_EINVAL, "sono_find_optimal_low_frequency_threshold: peak_frame < 0");
-    const sono::CallMatrix cm{m->power_db, m->frames, m->num_bins, m->freq_bins, m->zonal, m->num_zones, m->debug_mode != 0};
+    const sono::CallMatrix cm{m->power_db, m->frames, m->num_bins, m->freq_bins, m->zonal, m->num_zones, (m->debug_mode & SONO_DEBUG_MODE) != 0,
+                              (m->debug_mode & SONO_TIME_EXPANSION) != 0};
     const sono::LowResult r = sono::find_optimal_low_threshold(cm, peak, peak_frame, limit_frame);
     *out = {r.threshold_db, r.low_freq_hz, r.end_freq_hz, r.frame, r.bin, r.has_freq, r.has_frame, r.warning, r.discard,
             r.reference_throws, 0};
@@ -451,7 +452,8 @@ int sono_find_optimal_high_frequency_threshold(const sono_call_matrix *m, double
     int rc = check_matrix(m, true, "sono_find_optimal_high_frequency_threshold");
     if (rc) return rc;
     if (peak_frame < 0) return fail(SONO_EINVAL, "sono_find_optimal_high_frequency_threshold: peak_frame < 0");
-    const sono::CallMatrix cm{m->power_db, m->frames, m->num_bins, m->freq_bins, m->zonal, m->num_zones, m->debug_mode != 0};
+    const sono::CallMatrix cm{m->power_db, m->frames, m->num_bins, m->freq_bins, m->zonal, m->num_zones, (m->debug_mode & SONO_DEBUG_MODE) != 0,
+                              (m->debug_mode & SONO_TIME_EXPANSION) != 0};
     const sono::HighResult r = sono::find_optimal_high_threshold(cm, m->time_frames, peak, peak_frame);
     *out = {r.threshold_db, r.high_freq_hz, r.start_freq_hz, r.bin, r.frame, r.final_search_limit_frame, r.has_freq, r.has_start,
             r.has_limit, r.warning, r.is_cf, r.reference_throws};
@@ -466,7 +468,8 @@ int sono_measure_frequency_parameters(const sono_call_matrix *m, size_t num_time
     if (rc) return rc;
     if (num_times < m->frames) return fail(SONO_EINVAL, "sono_measure_frequency_parameters: fewer times than frames");
     if (!(freq_res > 0)) return fail(SONO_EINVAL, "sono_measure_frequency_parameters: freq_resolution_hz must be positive");
-    const sono::CallMatrix cm{m->power_db, m->frames, m->num_bins, m->freq_bins, m->zonal, m->num_zones, m->debug_mode != 0};
+    const sono::CallMatrix cm{m->power_db, m->frames, m->num_bins, m->freq_bins, m->zonal, m->num_zones, (m->debug_mode & SONO_DEBUG_MODE) != 0,
+                              (m->debug_mode & SONO_TIME_EXPANSION) != 0};
     sono::CallMeasure c;
     c.start_time_s = io->start_time_s; c.end_time_s = io->end_time_s; c.duration_ms = io->duration_ms;
     sono::measure_frequency_parameters(cm, m->time_frames, num_times, fhigh_khz, freq_res, c);

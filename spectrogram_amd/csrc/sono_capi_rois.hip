@@ -473,7 +473,8 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filter
                 for (size_t f = 0; f < times; ++f)
                     tf[f] = ((double)(k.start_frame + f) * (double)b.hop + (double)N / 2) / sample_rate;     // js:1350-1351
                 const sono::CallMatrix m{db + (row[i] + (size_t)slices[c0 + i].lead) * b.nb, call_frames, b.nb, freq_bins.data(),
-                                         t->zonal + (size_t)k.roi * SONO_MAX_ZONES, t->num_zones, debug_mode != 0};
+                                         t->zonal + (size_t)k.roi * SONO_MAX_ZONES, t->num_zones, (debug_mode & SONO_DEBUG_MODE) != 0,
+                                         (debug_mode & SONO_TIME_EXPANSION) != 0};
                 sono::CallMeasure cm;
                 cm.start_time_s = tf[0];                                                           // js:791-794
                 cm.end_time_s = tf[times - 1];

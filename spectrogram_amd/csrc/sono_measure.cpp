@@ -669,6 +669,23 @@ void measure_frequency_parameters(const CallMatrix &m, const double *tf, size_t 
     }
     if (c.start_freq_time_s == c.start_freq_time_s) c.start_time_s = c.start_freq_time_s;
     if (c.end_freq_time_s == c.end_freq_time_s) c.end_time_s = c.end_freq_time_s;
+    if (m.time_expansion) apply_time_expansion(c, kTimeExpansionFactor);        // js:3890-3893
+}
+
+// BatCall.applyTimeExpansion (batCallDetector.js:185-278): frequencies times the factor, times and durations divided by
+// it.  A NaN here is the reference's null, which it leaves alone; NaN * factor is NaN as well.  Flow and Fhigh are still
+// null when the reference gets here (processFullFile sets them afterwards from the scaled fields, js:813-814), and the
+// threshold and power fields are not touched.
+void apply_time_expansion(CallMeasure &c, double factor)
+{
+    if (!(factor > 1)) return;                                                   // js:186
+    for (double *f : {&c.peak_freq_khz, &c.high_freq_khz, &c.start_freq_khz, &c.end_freq_khz, &c.low_freq_khz,
+                      &c.characteristic_freq_khz, &c.knee_freq_khz, &c.heel_freq_khz, &c.bandwidth_khz})
+        *f *= factor;
+    for (double *t : {&c.start_time_s, &c.end_time_s, &c.duration_ms, &c.peak_freq_ms, &c.high_freq_ms, &c.start_freq_ms,
+                      &c.end_freq_ms, &c.low_freq_ms, &c.characteristic_freq_ms, &c.knee_freq_ms, &c.heel_freq_ms,
+                      &c.start_freq_time_s, &c.end_freq_time_s})
+        *t /= factor;
 }
 
 }  // namespace sono

@@ -16,6 +16,7 @@ struct CallMatrix {
     const double *zonal;      // noise floor of every 10 kHz zone, or nullptr: computed from the slice as the reference does
     size_t num_zones;
     bool debug_mode = false;  // the detector's debugMode switch (setDebugMode, batCallDetector.js:359)
+    bool time_expansion = false;  // getTimeExpansionMode() (fileState.js:158-166): the recording plays 10 x slowed down
 };
 
 struct LowResult {
@@ -49,8 +50,11 @@ struct CallMeasure {
     int64_t peak_frame, high_freq_frame, start_freq_frame, start_freq_bin, end_frame_for_low_freq, knee_frame, heel_frame;
     bool discarded, reference_throws;
 };
-// measureFrequencyParameters (batCallDetector.js:2994-3894) with the time-expansion switch off.  time_frames holds
-// num_times centre times: the call's frames and, unless the call ends the analysis matrix, one more (js:787, 1201).
+// measureFrequencyParameters (batCallDetector.js:2994-3894).  time_frames holds num_times centre times: the call's
+// frames and, unless the call ends the analysis matrix, one more (js:787, 1201).  With m.time_expansion the call that
+// reaches the end of the measurement is rescaled by 10 as BatCall.applyTimeExpansion does (js:185-278, 3890-3893).
+constexpr double kTimeExpansionFactor = 10;
+void apply_time_expansion(CallMeasure &c, double factor);
 void measure_frequency_parameters(const CallMatrix &m, const double *time_frames, size_t num_times, double fhigh_khz,
                                   double freq_resolution_hz, CallMeasure &c);
 

@@ -142,7 +142,7 @@ def detect_calls(engine, audio_data, sample_rate, flow_khz, fhigh_khz, options=N
     """detectCalls (batCallDetector.js:1070-1289), whole: framing, the measurement stage on every call, classification,
     and the noise-floor / SNR loop.  options: {'skipSNR': False, 'noiseSpectrogram': None} as in the reference;
     config['debugMode'] is the detector's debug switch (outside it the reference raises on some calls:
-    measure.ReferenceThrows).  -> list of call dicts with the reference's BatCall fields.  Unlike processFullFile the
+    measure.ReferenceThrows), config['timeExpansion'] the global getTimeExpansionMode() (fileState.js:158-166).  -> list of call dicts with the reference's BatCall fields.  Unlike processFullFile the
     reference does not look at isDiscarded here: such calls stay in the list, flagged, with null frequencies."""
     from . import measure as _ms
     opt = dict({"skipSNR": False, "noiseSpectrogram": None}, **(options or {}))
@@ -156,7 +156,8 @@ def detect_calls(engine, audio_data, sample_rate, flow_khz, fhigh_khz, options=N
         f0, f1 = k["startFrame"], k["endFrame"]
         call = {"spectrogram": p[f0:f1 + 1], "timeFrames": tf[f0:f1 + 2], "startTime_s": k["startTime_s"],
                 "endTime_s": k["endTime_s"], "duration_ms": k["duration_ms"]}
-        _ms.measure_frequency_parameters(call, flow_khz, fhigh_khz, fb, sp["freqResolution"], zonal, cfg.get("debugMode", False))
+        _ms.measure_frequency_parameters(call, flow_khz, fhigh_khz, fb, sp["freqResolution"], zonal, cfg.get("debugMode", False),
+                                         cfg.get("timeExpansion", False))
         call["Flow"] = (call["lowFreq_kHz"] or 0.0) * 1000                                             # null * 1000 is 0 in JavaScript
         call["Fhigh"] = call["highFreq_kHz"]
         call["callType"] = _ms.classify_call_type(call)
@@ -186,14 +187,14 @@ def detect_calls(engine, audio_data, sample_rate, flow_khz, fhigh_khz, options=N
     return kept
 
 
-def _measure_framed(power, tf, fb, framed, flow_khz, fhigh_khz, freq_res, zonal, offset, debug_mode):
+def _measure_framed(power, tf, fb, framed, flow_khz, fhigh_khz, freq_res, zonal, offset, debug_mode, time_expansion=False):
     """One framed call of a region through measureFrequencyParameters and processFullFile's follow-up
     (batCallDetector.js:786-827) -> the finished call dict, or None where the reference drops the call."""
     from . import measure as _ms
     f0, f1 = framed["startFrame"], framed["endFrame"]
     call = {"spectrogram": power[f0:f1 + 1], "timeFrames": tf[f0:f1 + 2], "startTime_s": framed["startTime_s"],
             "endTime_s": framed["endTime_s"], "duration_ms": framed["duration_ms"]}
-    _ms.measure_frequency_parameters(call, flow_khz, fhigh_khz, fb, freq_res, zonal, debug_mode)
+    _ms.measure_frequency_parameters(call, flow_khz, fhigh_khz, fb, freq_res, zonal, debug_mode, time_expansion)
     call = _ms.finish_full_file_call(call, offset)
     if call is not None:
         del call["spectrogram"], call["timeFrames"]
@@ -205,7 +206,8 @@ def process_full_file(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz,
     """processFullFile (batCallDetector.js:584-840).  measure=True runs the measurement stage on every framed call and
     returns the reference's BatCall fields (measure.CALL_FIELDS, 'Flow', 'Fhigh', 'callType', 'snr_dB', 'quality', frame
     numbers; config['debugMode'] is the detector's debug switch, outside which the reference -- and this -- raises on
-    some calls: measure.ReferenceThrows).  measure=False stops before it: fast scan -> merge & pad ->
+    some calls: measure.ReferenceThrows; config['timeExpansion'] is the global getTimeExpansionMode(), under which every
+    measured call is rescaled by 10 before the <= 1 ms filter, js:3890-3893).  measure=False stops before it: fast scan -> merge & pad ->
     per region: analysis spectrogram, automatic high-pass, call segments, strongest-first 30 ms echo filter,
     5 ms padding + oscillogram refinement -> calls in the reference's order (per region, strongest first):
     {'startTime_s', 'endTime_s', 'duration_ms' (file time), 'peakPower_dB', 'peakTime_s', 'peakFreq_kHz' and 'peakFreq_ms'
@@ -257,7 +259,7 @@ def process_full_file(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz,
             for k in framed:
                 if measure:
                     done = _measure_framed(power, tf, fb, k, flow_khz, fhigh_khz, spec["freqResolution"], zonal, offset,
-                                           cfg.get("debugMode", False))
+                                           cfg.get("debugMode", False), cfg.get("timeExpansion", False))
                     if done is not None:
                         calls.append(dict(done, roi=roi, highpass_kHz=cutoff))
                     continue
@@ -323,7 +325,7 @@ def process_full_file_batched(engine, full_audio_data, sample_rate, flow_khz, fh
         m = (_Measurement * max(got.value, 1))()
         _check(lib().sono_measure_roi_calls(engine._handle(), _p(x), _p(xf), x.size, rois, n, C.byref(table), out, got.value,
                                             float(sample_rate), float(flow_khz), float(fhigh_khz), float(cfg["hopPercent"]),
-                                            int(bool(cfg.get("debugMode", False))), 0, m))
+                                            _ms.mode_flags(cfg.get("debugMode", False), cfg.get("timeExpansion", False)), 0, m))
         for i in range(got.value):
             c, r = out[i], int(out[i].roi)
             if m[i].reference_throws:
@@ -369,7 +371,8 @@ def process_full_file_native(engine, full_audio_data, sample_rate, flow_khz, fhi
     cfg = dict(DEFAULT_FRAMING_CONFIG, **(config or {}))
     x = _f32(full_audio_data)
     o = _Opt(float(opt["threshold_dB"]), float(opt["padding_ms"]), float(cfg["hopPercent"]), float(cfg["callThreshold_dB"]),
-             float(cfg["minCallDuration_ms"]), int(bool(cfg.get("debugMode", False))), int(threads))
+             float(cfg["minCallDuration_ms"]), _ms.mode_flags(cfg.get("debugMode", False), cfg.get("timeExpansion", False)),
+             int(threads))
     cap = 4096
     out = (_Call * cap)()
     got = C.c_size_t(0)

@@ -18,7 +18,13 @@ class ReferenceThrows(RuntimeError):
     debug mode creates: batCallDetector.js:2815, 2261)."""
 
 
-def _matrix(spectrogram, time_frames, freq_bins, zonal_noise_map, debug_mode=False):
+def mode_flags(debug_mode=False, time_expansion=False):
+    """The library's `debug_mode` word: SONO_DEBUG_MODE (the detector's debugMode, batCallDetector.js:359-361) and
+    SONO_TIME_EXPANSION (getTimeExpansionMode(), fileState.js:158-166) or-ed together."""
+    return (1 if debug_mode else 0) | (2 if time_expansion else 0)
+
+
+def _matrix(spectrogram, time_frames, freq_bins, zonal_noise_map, debug_mode=False, time_expansion=False):
     p = np.ascontiguousarray(spectrogram, dtype=np.float32)
     fb = _f32(freq_bins)
     tf = np.ascontiguousarray(time_frames, dtype=np.float64)
@@ -31,7 +37,7 @@ def _matrix(spectrogram, time_frames, freq_bins, zonal_noise_map, debug_mode=Fal
         if keys != [10 * i for i in range(len(keys))]:
             raise ValueError("zonal noise map keys must be 0, 10, 20, ...")
     m = _CallMatrix(_p(p) if p.size else None, F, B, _p(fb), tf.ctypes.data_as(dp) if tf.size else None,
-                    z.ctypes.data_as(dp) if z is not None else None, 0 if z is None else z.size, int(bool(debug_mode)), 0)
+                    z.ctypes.data_as(dp) if z is not None else None, 0 if z is None else z.size, mode_flags(debug_mode, time_expansion), 0)
     return m, (p, fb, tf, z)
 
 
@@ -84,13 +90,16 @@ _FRAME_FIELDS = ("peakFrameIdx", "highFreqFrameIdx", "startFreqFrameIdx", "start
                  "heelFrameIdx")
 
 
-def measure_frequency_parameters(call, flow_khz, fhigh_khz, freq_bins, freq_resolution, zonal_noise_map=None, debug_mode=False):
+def measure_frequency_parameters(call, flow_khz, fhigh_khz, freq_bins, freq_resolution, zonal_noise_map=None, debug_mode=False,
+                                 time_expansion=False):
     """measureFrequencyParameters (batCallDetector.js:2994-3894).  `call` is a dict with the reference's BatCall fields
     "spectrogram" (frames x bins, dB), "timeFrames" (the frames' centre times, one more than frames unless the call ends
     the matrix), "startTime_s", "endTime_s", "duration_ms"; it is updated in place like the reference's object (None for
-    null; "isDiscarded" set when the reference sets it) and returned.  Raises ReferenceThrows where the reference does."""
+    null; "isDiscarded" set when the reference sets it) and returned.  Raises ReferenceThrows where the reference does.
+    time_expansion = getTimeExpansionMode() (fileState.js:158-166): a call that reaches the end of the measurement gets
+    BatCall.applyTimeExpansion(10) (js:185-278, 3890-3893), frequencies x 10, times and durations / 10."""
     tf = np.ascontiguousarray(call["timeFrames"], dtype=np.float64)
-    m, keep = _matrix(call["spectrogram"], tf, freq_bins, zonal_noise_map, debug_mode)
+    m, keep = _matrix(call["spectrogram"], tf, freq_bins, zonal_noise_map, debug_mode, time_expansion)
     r = _Measurement()
     nan = float("nan")
     r.start_time_s, r.end_time_s, r.duration_ms = (nan if call.get(k) is None else float(call[k])

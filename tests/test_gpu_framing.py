@@ -253,6 +253,46 @@ def test_batched_region_analysis_on_a_long_recording():
     e.free()
 
 
+def test_full_file_in_time_expansion_mode():
+    """getTimeExpansionMode() on (fileState.js:158-166): every measured call is rescaled by 10 at the end of
+    measureFrequencyParameters (batCallDetector.js:3890-3893), BEFORE processFullFile's <= 1 ms filter, Flow / Fhigh,
+    the bandwidth classes and the (unscaled) region offset (js:802-825).  The three forms of the whole-file pass agree
+    bit for bit, and against the run with the switch off: frequencies * 10, durations / 10, calls of 10 ms or less gone."""
+    sr = 256000
+    rng = np.random.default_rng(5)
+    x = (0.005 * rng.standard_normal(3 * sr)).astype(np.float32)
+    for i, k in enumerate(range(20000, 3 * sr - 20000, 40000)):
+        n = [1200, 2600, 5200, 9000][i % 4]                      # 4.7 to 35 ms: some calls fall under 10 ms
+        t = np.arange(n) / sr
+        x[k:k + n] += (0.4 * np.hanning(n) * np.sin(2 * np.pi * (60000 * t - 2.5e4 / t[-1] * t * t / 2))).astype(np.float32)
+    e = sa.SpectrogramEngine(1024, "hann")
+    args = (e, x, sr, 10.0, 128.0, {"threshold_dB": -50.0})
+    plain = fr.process_full_file_native(*args, {"debugMode": True})
+    cfg = {"debugMode": True, "timeExpansion": True}
+    native = fr.process_full_file_native(*args, cfg)
+    batched = fr.process_full_file_batched(*args, cfg, measure=True)
+    one = fr.process_full_file(*args, cfg, measure=True)
+    strip = lambda c: {k: v for k, v in c.items() if k != "zonalNoiseMap"}
+    assert [strip(c) for c in one] == [strip(c) for c in batched] == native
+    key = lambda c: (c["roi"], c["startFrame"], c["endFrame"])
+    by_key = {key(c): c for c in plain}
+    survivors = [c for c in plain if c["duration_ms"] / 10 > 1.0]
+    assert 0 < len(survivors) < len(plain), (len(survivors), len(plain))
+    assert [key(c) for c in native] == [key(c) for c in survivors]
+    for c in native:
+        p = by_key[key(c)]
+        for k in ("peakFreq_kHz", "highFreq_kHz", "lowFreq_kHz", "startFreq_kHz", "endFreq_kHz", "characteristicFreq_kHz",
+                  "bandwidth_kHz", "kneeFreq_kHz", "heelFreq_kHz"):
+            assert c[k] == (None if p[k] is None else p[k] * 10), k
+        for k in ("duration_ms", "peakFreq_ms", "highFreq_ms", "endFreq_ms", "lowFreq_ms", "kneeFreq_ms"):
+            assert c[k] == (None if p[k] is None else p[k] / 10), k
+        assert c["Flow"] == c["lowFreq_kHz"] * 1000 and c["Fhigh"] == c["highFreq_kHz"]
+        assert c["peakPower_dB"] == p["peakPower_dB"] and c["snr_dB"] == p["snr_dB"]
+        assert abs((c["endTime_s"] - c["startTime_s"]) - (p["endTime_s"] - p["startTime_s"]) / 10) < 1e-9
+        assert c["callType"] == ("CF" if c["bandwidth_kHz"] < 5 else "FM" if c["bandwidth_kHz"] > 20 else "CF-FM")
+    e.free()
+
+
 def test_rms_based_snr(golden):
     g, meta = golden
     e = sa.SpectrogramEngine(1024, "hann")

@@ -117,6 +117,47 @@ def test_whole_measurement_matches_the_reference(golden, debug):
     assert measured >= 30 and discarded >= 5 and knees >= 3, (measured, discarded, knees, heels)
 
 
+_TIMES_10 = ("peakFreq_kHz", "highFreq_kHz", "startFreq_kHz", "endFreq_kHz", "lowFreq_kHz", "characteristicFreq_kHz", "kneeFreq_kHz",
+             "heelFreq_kHz", "bandwidth_kHz")
+_OVER_10 = ("startTime_s", "endTime_s", "duration_ms", "peakFreq_ms", "highFreq_ms", "startFreq_ms", "endFreq_ms", "lowFreq_ms",
+            "characteristicFreq_ms", "kneeFreq_ms", "heelFreq_ms", "startFreqTime_s", "endFreqTime_s")
+
+
+def test_time_expansion_rescales_a_measured_call(golden):
+    """getTimeExpansionMode() on: BatCall.applyTimeExpansion(10) at the end of measureFrequencyParameters
+    (batCallDetector.js:185-278, 3890-3893).  The fixtures were captured with the switch off, so the expected values are
+    the captured ones put through the reference's rule: frequency fields * 10, time fields / 10 (one IEEE operation
+    each, hence bit-exact), everything else and every call that leaves the measurement early (discarded) unchanged."""
+    g, meta = golden
+    scaled = untouched = 0
+    for c in [c for c in meta if c["kind"] == "measure"]:
+        n = c["name"]
+        F, nb = (int(v) for v in g[n + "/shape"])
+        db, fb, tf = g[n + "/db"].reshape(F, nb), g[n + "/freq"], g[n + "/time"]
+        res = float(g[n + "/freqres"][0])
+        want = g[n + "/measured_debug"].reshape(-1, len(_GOLDEN_FIELDS) + 2)
+        for q, w in zip(c["slices"], want):
+            a, b = max(0, q[0]), min(F - 1, q[1])
+            call = {"spectrogram": db[a:b + 1], "timeFrames": tf[a:b + 2], "startTime_s": float(tf[a]),
+                    "endTime_s": float(tf[min(b + 1, F - 1)])}
+            call["duration_ms"] = (call["endTime_s"] - call["startTime_s"]) * 1000
+            zonal = _zonal_first_frames(db, fb) if q[2] else None
+            ms.measure_frequency_parameters(call, c["flow_khz"], c["fhigh_khz"], fb, res, zonal, True, time_expansion=True)
+            plain = dict(zip(_GOLDEN_FIELDS, w[:-2].tolist()))
+            early = bool(w[-2])                        # isDiscarded: the reference returns before the correction
+            for k in _GOLDEN_FIELDS:
+                if k == "snr_dB":
+                    continue
+                e = plain[k]
+                if not early:
+                    e = e * 10 if k in _TIMES_10 else e / 10 if k in _OVER_10 else e
+                got = _num(call.get(k))
+                assert got == e or (got != got and e != e), (n, q, k, got, e)
+            scaled += not early
+            untouched += early
+    assert scaled >= 20 and untouched >= 5, (scaled, untouched)
+
+
 def test_measurement_of_an_empty_call_changes_nothing():
     fb = np.arange(4, dtype=np.float32) * 1000
     call = {"spectrogram": np.zeros((0, 4), np.float32), "timeFrames": [], "startTime_s": 1.0, "endTime_s": 2.0, "duration_ms": 1000.0}

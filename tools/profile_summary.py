@@ -76,3 +76,20 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         json.dump(out_json, fh, indent=1)
     print()
     print(f"== HBM traffic per dispatch: read {read_b/1e9:.3f} GB + write {write_b/1e9:.3f} GB = {(read_b+write_b)/1e9:.3f} GB ==")
+
+# Vector-ALU counters per dispatch for bench.py's `valu_issue` object.  SQ_* cycle counters are in quad-cycles
+# summed over the waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs.
+if "SQ_INSTS_VALU" in vals and "SQ_WAVE_CYCLES" in vals:
+    cyc = vals.get("GRBM_GUI_ACTIVE", 0.0) / 8.0                       # shader cycles the dispatch took
+    vc = {"insts_valu": vals["SQ_INSTS_VALU"], "active_inst_valu_quadcycles": vals.get("SQ_ACTIVE_INST_VALU"),
+          "wave_quadcycles": vals["SQ_WAVE_CYCLES"], "wait_inst_any_quadcycles": vals.get("SQ_WAIT_INST_ANY"),
+          "wait_any_quadcycles": vals.get("SQ_WAIT_ANY"), "active_inst_any_quadcycles": vals.get("SQ_ACTIVE_INST_ANY"),
+          "waves": vals.get("SQ_WAVES"), "dispatch_cycles": cyc,
+          "source": "rocprofv3 --pmc passes of tools/profile.sh over bench.py, mean per dispatch of the STFT kernel"}
+    if cyc > 0:
+        # one vector instruction per 2 cycles and SIMD is the rate plain add / mul / fma instructions issue at
+        vc["issue_busy_at_2_cycles"] = vals["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cyc)
+    with open(os.path.join(out, "valu_counters.json"), "w") as fh:
+        json.dump(vc, fh, indent=1)
+    print(f"== vector ALU: {vals['SQ_INSTS_VALU']/1e9:.3f} G instructions per dispatch, "
+          f"issue busy {vc.get('issue_busy_at_2_cycles', float('nan')):.3f} of one instruction per 2 cycles and SIMD ==")
