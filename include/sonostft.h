@@ -406,8 +406,10 @@ int sono_rms_snr(sono_engine *e, const float *power_db, size_t frames, uint32_t 
  *   characteristic, knee, heel, bandwidth) multiplied by 10 and its times and durations (start / end time, duration,
  *   every *_ms field, start / end frequency times) divided by 10 (BatCall.applyTimeExpansion, js:185-278, 3890-3893).
  *   What follows sees the scaled values, as in the reference: the <= 1 ms filter, Flow / Fhigh, the bandwidth classes,
- *   and the region offset, which is added unscaled (js:802-825). */
-enum { SONO_DEBUG_MODE = 1, SONO_TIME_EXPANSION = 2 };
+ *   and the region offset, which is added unscaled (js:802-825).
+ * SONO_KEEP_CALL_SPECTROGRAMS (sono_full_file_options only): keep every returned call's slice of its region's
+ *   analysis spectrogram for sono_full_file_call_spectrogram, as the reference leaves it on the BatCall (js:785-787). */
+enum { SONO_DEBUG_MODE = 1, SONO_TIME_EXPANSION = 2, SONO_KEEP_CALL_SPECTROGRAMS = 4 };
 
 /* The call's slice of the analysis spectrogram and what the searches need beside it. */
 typedef struct sono_call_matrix {
@@ -552,7 +554,7 @@ typedef struct sono_full_file_options {
     double hop_percent;             /* config.hopPercent, default 3.125 */
     double call_threshold_db;       /* config.callThreshold_dB, default -24 */
     double min_call_duration_ms;    /* config.minCallDuration_ms, default 1 */
-    int32_t debug_mode;             /* SONO_DEBUG_MODE | SONO_TIME_EXPANSION */
+    int32_t debug_mode;             /* SONO_DEBUG_MODE | SONO_TIME_EXPANSION | SONO_KEEP_CALL_SPECTROGRAMS */
     uint32_t threads;               /* host threads of the measurement stage, 0 = up to 16 */
 } sono_full_file_options;
 enum { SONO_CALL_CF = 0, SONO_CALL_FM = 1, SONO_CALL_CF_FM = 2 };
@@ -571,6 +573,17 @@ int sono_process_full_file(sono_engine *e, const float *x, size_t n, double samp
  * number of calls, the first cap of them written), fetch them all here with a larger buffer instead of running the
  * recording again.  cap = 0 only asks for the count. */
 int sono_full_file_results(sono_engine *e, sono_full_file_call *out, size_t cap, size_t *count);
+/* Call `index` (position in the results) of the engine's last sono_process_full_file run with SONO_KEEP_CALL_SPECTROGRAMS:
+ * what processFullFile leaves on the BatCall beside the numbers (batCallDetector.js:785-787): call.spectrogram = the
+ * call's rows of its region's dB matrix (frames x num_bins, row-major, the very values the measurement read),
+ * call.timeFrames = the rows' centre times in seconds from the region's start and one more (frames + 1 values; frames
+ * where the call ends its region's matrix) -- neither shifted to file time nor rescaled by time expansion, as in the
+ * reference -- and call.freqBins = the num_bins centre frequencies in Hz.  Any buffer may be NULL; frames, times and
+ * num_bins always receive the sizes, so a first call with NULL buffers sizes the second.  SONO_ECAPACITY: a buffer is
+ * too small.  Each kept call holds frames x num_bins floats in host memory until the engine's next run or its end. */
+int sono_full_file_call_spectrogram(sono_engine *e, size_t index, float *power_db, size_t cap_floats, double *time_frames,
+                                    size_t cap_times, float *freq_bins, size_t cap_bins, size_t *frames, size_t *times,
+                                    uint32_t *num_bins);
 
 /* mergeAndPadSegments (batCallDetector.js:1028-1056).  Host only; sorts `segs` in place. */
 int sono_merge_and_pad_segments(sono_segment *segs, size_t count, uint64_t total_samples, double sample_rate,

@@ -31,8 +31,9 @@ function init() { return Promise.resolve(module.exports); }
 // (BatCallDetector.prototype.processFullFile, batCallDetector.js:584-840) by ONE native call on the detector's own
 // engine (`new BatCallDetector(config, engine)`, js:346-351): fast scan, merge & pad, every region's analysis
 // spectrogram, framing and the measurement stage run batched on the GPU and on host threads.  Same calls, same order;
-// each call is a BatCall (when the class is given) carrying the numeric fields, callType and quality -- not the
-// per-call spectrogram slice, which the whole-file pass only needs internally.  Rejects where the reference's promise
+// each call is a BatCall (when the class is given) carrying the numeric fields, callType, quality and -- unless
+// options.keepSpectrograms is false -- the call's spectrogram rows, timeFrames and freqBins (js:785-787; they cost
+// frames x bins floats of host memory per call).  Rejects where the reference's promise
 // rejects; detectors without a GPU engine keep the JavaScript path.  getTimeExpansionMode is fileState.js's getter
 // (fileState.js:164-166), which the reference's measurement stage reads as a module global (batCallDetector.js:3891).
 function accelerateBatCallDetector(BatCallDetector, BatCall, getTimeExpansionMode) {
@@ -41,7 +42,8 @@ function accelerateBatCallDetector(BatCallDetector, BatCall, getTimeExpansionMod
     const engine = this.wasmEngine;
     if (!(engine instanceof addon.SpectrogramEngine)) return original.call(this, fullAudioData, sampleRate, flowKHz, fhighKHz, options);
     const progress = options.progressCallback || (() => {});
-    const config = Object.assign({}, this.config, { debugMode: !!this.debugMode, timeExpansion: !!(getTimeExpansionMode && getTimeExpansionMode()) });
+    const config = Object.assign({}, this.config, { debugMode: !!this.debugMode, timeExpansion: !!(getTimeExpansionMode && getTimeExpansionMode()),
+      keepSpectrograms: options.keepSpectrograms !== false });
     const rows = engine.process_full_file(fullAudioData, sampleRate, flowKHz, fhighKHz, options, config);
     progress(1);
     return rows.map((row) => Object.assign(BatCall ? new BatCall() : {}, row));

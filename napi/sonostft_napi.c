@@ -572,7 +572,8 @@ static napi_value fn_device_count(napi_env env, napi_callback_info info)
  * engine.process_full_file(audio: Float32Array, sampleRate, flowKHz, fhighKHz, options, config) -> Array of objects
  * carrying BatCall's numeric fields under BatCall's own names (null where the reference leaves null).
  * options: {threshold_dB = -60, padding_ms = 5}; config: {hopPercent = 3.125, callThreshold_dB = -24,
- * minCallDuration_ms = 1, debugMode = false, timeExpansion = false}.  Throws where the reference's promise rejects. */
+ * minCallDuration_ms = 1, debugMode = false, timeExpansion = false,
+ * keepSpectrograms = false (true: every call also carries spectrogram, timeFrames and freqBins, js:785-787)}.  Throws where the reference's promise rejects. */
 static double prop_f64(napi_env env, napi_value obj, const char *name, double dflt)
 {
     napi_value v;
@@ -604,6 +605,39 @@ static int set_str(napi_env env, napi_value obj, const char *name, const char *v
     return napi_create_string_utf8(env, v, NAPI_AUTO_LENGTH, &x) == napi_ok && napi_set_named_property(env, obj, name, x) == napi_ok;
 }
 
+/* call.spectrogram, call.timeFrames, call.freqBins of result `i` (batCallDetector.js:785-787): an Array of Float32Array
+ * rows (views of one buffer per call), an Array of numbers, and the Float32Array `*freq_bins` shared by all calls of the
+ * run as in the reference (created with the first call). */
+static int set_spectrogram(napi_env env, napi_value o, sono_engine *e, size_t i, napi_value *freq_bins)
+{
+    size_t frames = 0, times = 0;
+    uint32_t nb = 0;
+    if (sono_full_file_call_spectrogram(e, i, NULL, 0, NULL, 0, NULL, 0, &frames, &times, &nb) != SONO_OK) return 0;
+    void *db = NULL, *fb = NULL;
+    napi_value all = make_typed(env, napi_float32_array, sizeof(float), frames * nb, &db);
+    if (!all) return 0;
+    if (!*freq_bins && !(*freq_bins = make_typed(env, napi_float32_array, sizeof(float), nb, &fb))) return 0;
+    double *tf = (double *)malloc((times ? times : 1) * sizeof(double));
+    if (!tf) return 0;
+    int ok = sono_full_file_call_spectrogram(e, i, (float *)db, frames * nb, tf, times, (float *)fb, fb ? nb : 0, NULL, NULL, NULL) == SONO_OK;
+    napi_value rows, tarr, ab;
+    ok = ok && napi_get_typedarray_info(env, all, NULL, NULL, NULL, &ab, NULL) == napi_ok &&
+         napi_create_array_with_length(env, frames, &rows) == napi_ok && napi_create_array_with_length(env, times, &tarr) == napi_ok;
+    for (size_t f = 0; ok && f < frames; ++f) {
+        napi_value row;
+        ok = napi_create_typedarray(env, napi_float32_array, nb, ab, f * nb * sizeof(float), &row) == napi_ok &&
+             napi_set_element(env, rows, (uint32_t)f, row) == napi_ok;
+    }
+    for (size_t f = 0; ok && f < times; ++f) {
+        napi_value v;
+        ok = napi_create_double(env, tf[f], &v) == napi_ok && napi_set_element(env, tarr, (uint32_t)f, v) == napi_ok;
+    }
+    free(tf);
+    return ok && napi_set_named_property(env, o, "spectrogram", rows) == napi_ok &&
+           napi_set_named_property(env, o, "timeFrames", tarr) == napi_ok &&
+           napi_set_named_property(env, o, "freqBins", *freq_bins) == napi_ok;
+}
+
 static napi_value engine_process_full_file(napi_env env, napi_callback_info info)
 {
     static const char *const types[] = {"CF", "FM", "CF-FM"};
@@ -630,6 +664,9 @@ static napi_value engine_process_full_file(napi_env env, napi_callback_info info
     opt.min_call_duration_ms = prop_f64(env, argv[5], "minCallDuration_ms", 1);
     opt.debug_mode = (prop_f64(env, argv[5], "debugMode", 0) != 0 ? SONO_DEBUG_MODE : 0) |
                      (prop_f64(env, argv[5], "timeExpansion", 0) != 0 ? SONO_TIME_EXPANSION : 0);
+    const int keep = prop_f64(env, argv[5], "keepSpectrograms", 0) != 0;
+    if (keep) opt.debug_mode |= SONO_KEEP_CALL_SPECTROGRAMS;
+    napi_value freq_bins = NULL;
     opt.threads = 0;
     size_t count = 0;
     int rc = sono_process_full_file(b->e, (const float *)x, n, sr, flow, fhigh, &opt, NULL, 0, &count);
@@ -666,7 +703,7 @@ static napi_value engine_process_full_file(napi_env env, napi_callback_info info
              set_str(env, o, "callType", types[k->call_type]) && set_str(env, o, "quality", qualities[k->quality]) &&
              set_f64(env, o, "roi", (double)k->roi) && set_f64(env, o, "startFrame", (double)k->start_frame) &&
              set_f64(env, o, "endFrame", (double)k->end_frame) && set_f64(env, o, "highpass_kHz", k->highpass_khz) &&
-             napi_set_element(env, arr, (uint32_t)i, o) == napi_ok;
+             (!keep || set_spectrogram(env, o, b->e, i, &freq_bins)) && napi_set_element(env, arr, (uint32_t)i, o) == napi_ok;
         if (!ok) { free(calls); napi_throw_error(env, NULL, "sonostft: cannot build the result array"); return NULL; }
     }
     free(calls);

@@ -230,6 +230,8 @@ _SIGNATURES = {
     "sono_process_full_file": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_double, C.c_double, C.c_double,
                                          C.POINTER(FullFileOptions), C.POINTER(FullFileCall), C.c_size_t, _szp]),
     "sono_full_file_results": (C.c_int, [C.c_void_p, C.POINTER(FullFileCall), C.c_size_t, _szp]),
+    "sono_full_file_call_spectrogram": (C.c_int, [C.c_void_p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_double), C.c_size_t, _f32p,
+                                                  C.c_size_t, _szp, _szp, _u32p]),
     "sono_measure_roi_calls": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_size_t, C.POINTER(Segment), C.c_size_t, C.POINTER(RoiTable),
                                          C.POINTER(RoiCall), C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                          C.c_uint, C.POINTER(CallMeasurement)]),

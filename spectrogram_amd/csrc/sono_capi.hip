@@ -197,6 +197,7 @@ int sono_engine_release_memory(sono_engine *e)
     e->d_mags.release(); e->d_bank.release();
     e->d_db.release(); e->d_flags.release(); e->d_edges.release(); e->d_runs.release(); e->d_select_tmp.release();
     e->h_in.release(); e->h_out.release(); e->full_file_calls.clear(); e->full_file_calls.shrink_to_fit();
+    e->full_file_slices.clear(); e->full_file_slices.shrink_to_fit();
     if (e->pipe) { sono::stream_pipe_destroy(e->pipe); e->pipe = nullptr; }
     return SONO_OK;
 }

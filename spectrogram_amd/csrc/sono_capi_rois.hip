@@ -386,9 +386,12 @@ int sono_frame_roi_calls(const float *x, const float *x_filtered, size_t n, cons
     return SONO_OK;
 }
 
-int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filtered, size_t n, const sono_segment *rois, size_t n_rois, const sono_roi_table *t,
-                           const sono_roi_call *calls, size_t n_calls, double sample_rate, double flow_khz, double fhigh_khz,
-                           double hop_percent, int debug_mode, unsigned int threads, sono_call_measurement *out)
+// sono_measure_roi_calls; `keep` (or nullptr) receives, for every call that processFullFile goes on to keep (not
+// discarded, longer than 1 ms: js:802-810), the call's own rows of the dB matrix and the number of its centre times.
+static int measure_roi_calls(sono_engine *e, const float *x, const float *x_filtered, size_t n, const sono_segment *rois, size_t n_rois,
+                             const sono_roi_table *t, const sono_roi_call *calls, size_t n_calls, double sample_rate, double flow_khz,
+                             double fhigh_khz, double hop_percent, int debug_mode, unsigned int threads, sono_call_measurement *out,
+                             std::vector<sono::FullFileSlice> *keep)
 {
     if (!e || !t || (n && !x) || (n_rois && (!rois || !t->row0 || !t->zonal)) || (n_calls && (!calls || !out)))
         return fail(SONO_EINVAL, "sono_measure_roi_calls: NULL argument");
@@ -487,6 +490,11 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filter
                                cm.heel_freq_khz, cm.heel_freq_ms, cm.bandwidth_khz, cm.high_threshold_db_used, cm.low_threshold_db_used,
                                cm.peak_frame, cm.high_freq_frame, cm.start_freq_frame, cm.start_freq_bin, cm.end_frame_for_low_freq,
                                cm.knee_frame, cm.heel_frame, cm.discarded, cm.reference_throws};
+                if (keep && !cm.discarded && !cm.reference_throws && cm.duration_ms > 1.0) {
+                    sono::FullFileSlice &sl = (*keep)[c0 + i];
+                    sl.db.assign(m.db, m.db + call_frames * b.nb);                               // js:785
+                    sl.times = (uint32_t)times;
+                }
             }
         };
         const unsigned int nt = (unsigned int)std::min<size_t>(threads, cnt);
@@ -500,12 +508,21 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filter
     return SONO_OK;
 }
 
+int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filtered, size_t n, const sono_segment *rois, size_t n_rois, const sono_roi_table *t,
+                           const sono_roi_call *calls, size_t n_calls, double sample_rate, double flow_khz, double fhigh_khz,
+                           double hop_percent, int debug_mode, unsigned int threads, sono_call_measurement *out)
+{
+    return measure_roi_calls(e, x, x_filtered, n, rois, n_rois, t, calls, n_calls, sample_rate, flow_khz, fhigh_khz, hop_percent,
+                             debug_mode, threads, out, nullptr);
+}
+
 int sono_process_full_file(sono_engine *e, const float *x, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
                            const sono_full_file_options *opt, sono_full_file_call *out, size_t cap, size_t *count)
 {
     if (count) *count = 0;
     if (!e || !opt || (n && !x) || (cap && !out)) return fail(SONO_EINVAL, "sono_process_full_file: NULL argument");
     e->full_file_calls.clear();
+    e->full_file_slices.clear();
     if (!(sample_rate > 0)) return fail(SONO_EINVAL, "sono_process_full_file: sample_rate must be positive");
     const uint32_t N = e->N;
     StageTimer timer("sono_process_full_file");
@@ -548,15 +565,19 @@ int sono_process_full_file(sono_engine *e, const float *x, size_t n, double samp
     if (rc) return rc;
     lap("framing (host)");
     std::vector<sono_call_measurement> meas(n_calls + 1);
-    rc = sono_measure_roi_calls(e, x, xf, n, rois.data(), n_rois, &t, framed.data(), n_calls, sample_rate, flow_khz, fhigh_khz,
-                                opt->hop_percent, opt->debug_mode, opt->threads, meas.data());
+    const bool keep_slices = (opt->debug_mode & SONO_KEEP_CALL_SPECTROGRAMS) != 0;
+    std::vector<sono::FullFileSlice> slices(keep_slices ? n_calls : 0);
+    rc = measure_roi_calls(e, x, xf, n, rois.data(), n_rois, &t, framed.data(), n_calls, sample_rate, flow_khz, fhigh_khz,
+                           opt->hop_percent, opt->debug_mode, opt->threads, meas.data(), keep_slices ? &slices : nullptr);
     if (rc) return rc;
+    e->full_file_axes = {t.hop, t.min_bin, t.num_bins, sample_rate};
     lap("measurement (GPU + threads)");
     std::vector<sono_full_file_call> &kept = e->full_file_calls;
     for (size_t i = 0; i < n_calls; ++i) {
         sono_call_measurement &m = meas[i];
         if (m.reference_throws) {
             kept.clear();
+            e->full_file_slices.clear();
             return fail(SONO_EREFERENCE, "sono_process_full_file: the reference raises a TypeError on call " + std::to_string(i) +
                                              " of this recording outside its debug mode (batCallDetector.js:2261, 2815)");
             }
@@ -567,6 +588,7 @@ int sono_process_full_file(sono_engine *e, const float *x, size_t n, double samp
         if (m.start_freq_time_s == m.start_freq_time_s) m.start_freq_time_s += offset;
         if (m.end_freq_time_s == m.end_freq_time_s) m.end_freq_time_s += offset;
         kept.emplace_back();
+        if (keep_slices) e->full_file_slices.push_back(std::move(slices[i]));
         sono_full_file_call &o = kept.back();
         o.m = m;
         o.roi = framed[i].roi; o.start_frame = framed[i].start_frame; o.end_frame = framed[i].end_frame;
@@ -589,6 +611,35 @@ int sono_full_file_results(sono_engine *e, sono_full_file_call *out, size_t cap,
     const size_t take = std::min(cap, kept.size());
     if (take) std::memcpy(out, kept.data(), take * sizeof(sono_full_file_call));
     if (kept.size() > cap) return fail(SONO_ECAPACITY, "sono_full_file_results: output buffer too small (count holds the number of calls)");
+    return SONO_OK;
+}
+
+int sono_full_file_call_spectrogram(sono_engine *e, size_t index, float *power_db, size_t cap_floats, double *time_frames,
+                                    size_t cap_times, float *freq_bins, size_t cap_bins, size_t *frames, size_t *times,
+                                    uint32_t *num_bins)
+{
+    if (!e) return fail(SONO_EINVAL, "sono_full_file_call_spectrogram: NULL engine");
+    if (e->full_file_slices.size() != e->full_file_calls.size() || e->full_file_calls.empty())
+        return fail(SONO_EINVAL, "sono_full_file_call_spectrogram: the engine's last sono_process_full_file kept no spectrograms "
+                                 "(SONO_KEEP_CALL_SPECTROGRAMS was not set, or it found no calls)");
+    if (index >= e->full_file_slices.size()) return fail(SONO_EINVAL, "sono_full_file_call_spectrogram: no such call");
+    const sono::FullFileSlice &sl = e->full_file_slices[index];
+    const sono::FullFileAxes &ax = e->full_file_axes;
+    const size_t F = sl.db.size() / ax.num_bins;
+    if (frames) *frames = F;
+    if (times) *times = sl.times;
+    if (num_bins) *num_bins = ax.num_bins;
+    if ((power_db && cap_floats < sl.db.size()) || (time_frames && cap_times < sl.times) || (freq_bins && cap_bins < ax.num_bins))
+        return fail(SONO_ECAPACITY, "sono_full_file_call_spectrogram: output buffer too small (frames, times and num_bins hold the sizes)");
+    if (power_db) std::memcpy(power_db, sl.db.data(), sl.db.size() * sizeof(float));
+    const double res = ax.sample_rate / (double)e->N;
+    if (freq_bins)
+        for (uint32_t i = 0; i < ax.num_bins; ++i) freq_bins[i] = (float)((double)(ax.min_bin + i) * res);          // js:1343-1345
+    if (time_frames) {
+        const uint64_t f0 = e->full_file_calls[index].start_frame;
+        for (uint32_t f = 0; f < sl.times; ++f)
+            time_frames[f] = ((double)(f0 + f) * (double)ax.hop + (double)e->N / 2) / ax.sample_rate;              // js:1350-1351
+    }
     return SONO_OK;
 }
 

@@ -76,6 +76,17 @@ struct Tables {
 
 // The chunked host-pointer pipeline of sono_stft_u8 (sono_stream.hip): pinned and device rings, copy threads.
 struct StreamPipe;
+
+// What sono_process_full_file keeps of a call's analysis spectrogram when asked to (SONO_KEEP_CALL_SPECTROGRAMS):
+// the call's rows of the region's dB matrix (batCallDetector.js:785) and how many centre times go with them (js:786).
+struct FullFileSlice {
+    std::vector<float> db;
+    uint32_t times = 0;
+};
+struct FullFileAxes {
+    uint32_t hop, min_bin, num_bins;
+    double sample_rate;
+};
 void stream_pipe_destroy(StreamPipe *p);
 size_t stream_chunk_frames(uint32_t hop);
 
@@ -129,6 +140,8 @@ struct sono_engine {
     sono::StreamPipe *pipe = nullptr;       // rings of the chunked host-pointer path, created on first use
     // calls of the last sono_process_full_file, kept for sono_full_file_results
     std::vector<sono_full_file_call> full_file_calls;
+    std::vector<sono::FullFileSlice> full_file_slices;      // parallel to full_file_calls when the run kept them, else empty
+    sono::FullFileAxes full_file_axes{};
     // filter bank (lib.rs:20-22)
     std::vector<float> bank;
     unsigned int num_filters = 0;

@@ -187,7 +187,8 @@ def detect_calls(engine, audio_data, sample_rate, flow_khz, fhigh_khz, options=N
     return kept
 
 
-def _measure_framed(power, tf, fb, framed, flow_khz, fhigh_khz, freq_res, zonal, offset, debug_mode, time_expansion=False):
+def _measure_framed(power, tf, fb, framed, flow_khz, fhigh_khz, freq_res, zonal, offset, debug_mode, time_expansion=False,
+                    keep_spectrogram=False):
     """One framed call of a region through measureFrequencyParameters and processFullFile's follow-up
     (batCallDetector.js:786-827) -> the finished call dict, or None where the reference drops the call."""
     from . import measure as _ms
@@ -197,17 +198,22 @@ def _measure_framed(power, tf, fb, framed, flow_khz, fhigh_khz, freq_res, zonal,
     _ms.measure_frequency_parameters(call, flow_khz, fhigh_khz, fb, freq_res, zonal, debug_mode, time_expansion)
     call = _ms.finish_full_file_call(call, offset)
     if call is not None:
-        del call["spectrogram"], call["timeFrames"]
+        if keep_spectrogram:
+            call["freqBins"] = fb                                                                   # js:787
+        else:
+            del call["spectrogram"], call["timeFrames"]
         call.update(startFrame=f0, endFrame=f1, zonalNoiseMap=zonal)
     return call
 
 
-def process_full_file(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options=None, config=None, measure=False):
+def process_full_file(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options=None, config=None, measure=False,
+                      keep_spectrograms=False):
     """processFullFile (batCallDetector.js:584-840).  measure=True runs the measurement stage on every framed call and
     returns the reference's BatCall fields (measure.CALL_FIELDS, 'Flow', 'Fhigh', 'callType', 'snr_dB', 'quality', frame
     numbers; config['debugMode'] is the detector's debug switch, outside which the reference -- and this -- raises on
     some calls: measure.ReferenceThrows; config['timeExpansion'] is the global getTimeExpansionMode(), under which every
-    measured call is rescaled by 10 before the <= 1 ms filter, js:3890-3893).  measure=False stops before it: fast scan -> merge & pad ->
+    measured call is rescaled by 10 before the <= 1 ms filter, js:3890-3893; keep_spectrograms leaves 'spectrogram',
+    'timeFrames' and 'freqBins' on the measured calls as the reference does, js:785-787).  measure=False stops before it: fast scan -> merge & pad ->
     per region: analysis spectrogram, automatic high-pass, call segments, strongest-first 30 ms echo filter,
     5 ms padding + oscillogram refinement -> calls in the reference's order (per region, strongest first):
     {'startTime_s', 'endTime_s', 'duration_ms' (file time), 'peakPower_dB', 'peakTime_s', 'peakFreq_kHz' and 'peakFreq_ms'
@@ -259,7 +265,7 @@ def process_full_file(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz,
             for k in framed:
                 if measure:
                     done = _measure_framed(power, tf, fb, k, flow_khz, fhigh_khz, spec["freqResolution"], zonal, offset,
-                                           cfg.get("debugMode", False), cfg.get("timeExpansion", False))
+                                           cfg.get("debugMode", False), cfg.get("timeExpansion", False), keep_spectrograms)
                     if done is not None:
                         calls.append(dict(done, roi=roi, highpass_kHz=cutoff))
                     continue
@@ -361,17 +367,20 @@ _CALL_TYPES = ("CF", "FM", "CF-FM")
 _QUALITIES = ("Very Poor", "Poor", "Normal", "Good", "Excellent")
 
 
-def process_full_file_native(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options=None, config=None, threads=0):
+def process_full_file_native(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options=None, config=None, threads=0,
+                             keep_spectrograms=False):
     """processFullFile (batCallDetector.js:584-840) as ONE library call (sono_process_full_file): same calls, order and
     values as process_full_file_batched(..., measure=True), without the per-region tables (zonalNoiseMap).  Raises
     measure.ReferenceThrows where the reference's promise rejects (config['debugMode'] False and a call on which the
-    reference raises outside its debug mode)."""
+    reference raises outside its debug mode).  keep_spectrograms=True adds what the reference leaves on every BatCall
+    beside the numbers (js:785-787): 'spectrogram' (the call's rows of its region's dB matrix), 'timeFrames' (their centre
+    times from the region's start, and one more) and 'freqBins' (Hz)."""
     from . import FullFileCall as _Call, FullFileOptions as _Opt, SonoError, measure as _ms
     opt = dict({"threshold_dB": -60, "padding_ms": 5}, **(options or {}))
     cfg = dict(DEFAULT_FRAMING_CONFIG, **(config or {}))
     x = _f32(full_audio_data)
     o = _Opt(float(opt["threshold_dB"]), float(opt["padding_ms"]), float(cfg["hopPercent"]), float(cfg["callThreshold_dB"]),
-             float(cfg["minCallDuration_ms"]), _ms.mode_flags(cfg.get("debugMode", False), cfg.get("timeExpansion", False)),
+             float(cfg["minCallDuration_ms"]), _ms.mode_flags(cfg.get("debugMode", False), cfg.get("timeExpansion", False)) | (4 if keep_spectrograms else 0),
              int(threads))
     cap = 4096
     out = (_Call * cap)()
@@ -395,6 +404,15 @@ def process_full_file_native(engine, full_audio_data, sample_rate, flow_khz, fhi
         call.update(Flow=k.flow_hz, Fhigh=k.fhigh_khz, callType=_CALL_TYPES[k.call_type], snr_dB=k.snr_db,
                     quality=_QUALITIES[k.quality], startFrame=int(k.start_frame), endFrame=int(k.end_frame), roi=int(k.roi),
                     highpass_kHz=float(k.highpass_khz))
+        if keep_spectrograms:
+            frames, times, nb = C.c_size_t(0), C.c_size_t(0), C.c_uint32(0)
+            args = (engine._handle(), i)
+            _check(lib().sono_full_file_call_spectrogram(*args, None, 0, None, 0, None, 0, C.byref(frames), C.byref(times), C.byref(nb)))
+            db = np.empty((frames.value, nb.value), np.float32)
+            tf, fb = np.empty(times.value, np.float64), np.empty(nb.value, np.float32)
+            _check(lib().sono_full_file_call_spectrogram(*args, _p(db), db.size, tf.ctypes.data_as(C.POINTER(C.c_double)), tf.size,
+                                                         _p(fb), fb.size, None, None, None))
+            call.update(spectrogram=db, timeFrames=tf, freqBins=fb)
         calls.append(call)
     return calls
 

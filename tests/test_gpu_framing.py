@@ -219,6 +219,20 @@ def test_full_file_with_the_measurement_stage(golden):
     assert len(native) == len(batched)
     for a, b in zip(native, batched):
         assert a == {k: v for k, v in b.items() if k != "zonalNoiseMap"}
+    # call.spectrogram / timeFrames / freqBins (js:785-787): the native run's re-transform of every call's frames
+    # against the rows of the region's own matrix that the region-by-region form measured
+    with_rows = fr.process_full_file_native(*args, dict(cfg, debugMode=True), keep_spectrograms=True)
+    regions = fr.process_full_file(*args, dict(cfg, debugMode=True), measure=True, keep_spectrograms=True)
+    assert len(with_rows) == len(regions) == len(native)
+    for a, b, plain in zip(with_rows, regions, native):
+        f = a["endFrame"] - a["startFrame"] + 1
+        assert a["spectrogram"].shape == (f, len(a["freqBins"])) and len(a["timeFrames"]) in (f, f + 1)
+        assert np.array_equal(a["spectrogram"], np.asarray(b["spectrogram"]))                       # bit for bit
+        assert np.array_equal(a["timeFrames"], np.asarray(b["timeFrames"], np.float64))
+        assert np.array_equal(a["freqBins"], b["freqBins"])
+        assert {k: v for k, v in a.items() if k not in ("spectrogram", "timeFrames", "freqBins")} == plain
+    fr.process_full_file_native(*args, dict(cfg, debugMode=True))                                   # this run keeps none
+    assert sa.lib().sono_full_file_call_spectrogram(e._handle(), 0, None, 0, None, 0, None, 0, None, None, None) == sa.SONO_EINVAL
     e.free()
 
 

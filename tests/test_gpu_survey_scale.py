@@ -1,0 +1,103 @@
+"""The survey-scale pass (a night-long channel per GPU: per-frame features, the fused fast scan and run
+extraction, all on 16-bit PCM as it lies in a WAV data chunk) on ONE HOUR of a 384 kHz int16 channel:
+the PCM forms against the float forms over every frame, the fused fast scan against the two-pass form
+(magnitudes, then sono_detect_band_active_dev) on spot ranges, and the run lists against runs taken
+from the flags with torch."""
+import numpy as np
+import pytest
+
+import spectrogram_amd as sa
+from spectrogram_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+N, SR = 1024, 384000
+SAMPLES = 3600 * SR
+LO, HI = 26, 341                         # bins of 10 .. 128 kHz at 375 Hz per bin (batCallDetector.js:884-885)
+
+
+@pytest.fixture(scope="module")
+def night():
+    import torch
+    x = synth.chirp_torch(0, SAMPLES, SR, device="cuda")
+    pcm = torch.clamp(torch.round(x * 32767.0), -32768, 32767).to(torch.int16)
+    del x
+    xf = pcm.to(torch.float32) / 32768.0                  # what the browser's decoder makes of the integers
+    e = sa.SpectrogramEngine(N, "hann")
+    torch.cuda.synchronize()
+    yield dict(torch=torch, pcm=pcm, xf=xf, e=e)
+    e.free()
+
+
+def test_features_from_pcm16_equal_features_from_floats(night):
+    torch, e = night["torch"], night["e"]
+    V = 768
+    F = sa.frames_for(SAMPLES, N, V)
+    got, ref = [], []
+    for fn, src in ((lambda *a: e.stft_u8_pcm16_dev(night["pcm"].data_ptr(), 1, SAMPLES, SAMPLES, 1, 0, V, 20.0, 80.0, 0, *a), got),
+                    (lambda *a: e.stft_features_dev(night["xf"].data_ptr(), 1, SAMPLES, SAMPLES, V, *a), ref)):
+        pb = torch.empty(F, dtype=torch.int16, device="cuda")
+        pm = torch.empty(F, dtype=torch.float32, device="cuda")
+        gm = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        fn(pb.data_ptr(), pm.data_ptr(), gm.data_ptr())
+        e.synchronize()
+        src.extend([pb, pm, gm])
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+    assert got[2].view(torch.float32).item() == got[1].max().item() > 0
+    # a frame that starts 2 hops into a pulse (one per 100 ms = 150 frames) peaks on the 80 -> 30 kHz sweep
+    on_sweep = got[0][2::150].to(torch.int32) & 0xFFFF
+    assert on_sweep.min().item() >= 75 and on_sweep.max().item() <= 220
+
+
+def test_fused_fast_scan_on_pcm16_and_the_run_lists(night):
+    torch, e = night["torch"], night["e"]
+    V = N // 2                                                            # 50 % overlap, js:880
+    hop = N - V
+    F = sa.frames_for(SAMPLES, N, V)
+    energy = torch.empty(F, dtype=torch.float64, device="cuda")
+    flags = torch.empty(F, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    e.stft_band_active_dev(night["xf"].data_ptr(), 1, SAMPLES, SAMPLES, V, LO, HI, 0.0, flags.data_ptr(), energy.data_ptr())
+    e.synchronize()
+    target = float(torch.quantile(energy[::97].to(torch.float32), 0.9).item())       # about one frame in ten is active
+    ref_flags = torch.empty_like(flags)
+    ref_energy = torch.empty_like(energy)
+    e.stft_band_active_dev(night["xf"].data_ptr(), 1, SAMPLES, SAMPLES, V, LO, HI, target, ref_flags.data_ptr(), ref_energy.data_ptr())
+    e.stft_band_active_pcm16_dev(night["pcm"].data_ptr(), 1, SAMPLES, SAMPLES, 1, 0, V, LO, HI, target, flags.data_ptr(),
+                                 energy.data_ptr())
+    e.synchronize()
+    assert torch.equal(flags, ref_flags) and torch.equal(energy, ref_energy)
+    active = int(flags.sum().item())
+    assert 0.02 * F < active < 0.3 * F, active / F
+    # the two-pass form on spot ranges that start on a tile boundary (so every frame meets the same partner)
+    cnt = 40000
+    mags = torch.empty(cnt * (N // 2), dtype=torch.float32, device="cuda")
+    two = torch.empty(cnt, dtype=torch.uint8, device="cuda")
+    two_energy = torch.empty(cnt, dtype=torch.float64, device="cuda")
+    for f0 in (0, 16 * 40000, F - cnt - (F - cnt) % 16):
+        n = (cnt - 1) * hop + N
+        xs = night["xf"][f0 * hop: f0 * hop + n]
+        torch.cuda.synchronize()
+        e.stft_mag_f32_dev(xs.data_ptr(), 1, n, n, V, mags.data_ptr())
+        sa._check(sa.lib().sono_detect_band_active_dev(e._handle(), mags.data_ptr(), cnt, N // 2, LO, HI, target, two.data_ptr(),
+                                                       two_energy.data_ptr(), None))
+        e.synchronize()
+        assert torch.equal(two, flags[f0:f0 + cnt]), f0
+        assert torch.equal(two_energy, energy[f0:f0 + cnt]), f0
+    # runs of active frames over the whole hour, both entry points, against the flags' own edges
+    a = flags.to(torch.int8)
+    prev = torch.cat([torch.zeros(1, dtype=torch.int8, device="cuda"), a[:-1]])
+    nxt = torch.cat([a[1:], torch.zeros(1, dtype=torch.int8, device="cuda")])
+    want_first = torch.nonzero((a == 1) & (prev == 0)).flatten()
+    want_last = torch.nonzero((a == 1) & (nxt == 0)).flatten()
+    for name in ("sono_detect_runs_dev", "sono_detect_runs_static_dev"):
+        first = torch.zeros(F // 2 + 1, dtype=torch.int64, device="cuda")
+        last = torch.zeros(F // 2 + 1, dtype=torch.int64, device="cuda")
+        count = torch.zeros(1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        sa._check(getattr(sa.lib(), name)(e._handle(), flags.data_ptr(), F, first.data_ptr(), last.data_ptr(), count.data_ptr(), None))
+        e.synchronize()
+        k = int(count.item())
+        assert k == want_first.numel() > 1000, (name, k)
+        assert torch.equal(first[:k], want_first) and torch.equal(last[:k], want_last), name

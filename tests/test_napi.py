@@ -140,12 +140,18 @@ def test_addon_whole_file_pass_equals_python_binding(tmp_path):
           d.debugMode = true;
           let seen = 0;
           const calls = await d.processFullFile(x, %d, %r, %r, {threshold_dB: %r, padding_ms: %r, progressCallback: (p) => { seen = p; }});
-          r.calls = calls; r.progress = seen; r.isBatCall = calls.every((k) => k instanceof BatCall);
+          r.calls = calls.map((k) => Object.assign({}, k, {spectrogram: k.spectrogram.map((row) => Array.from(row)),
+                                                           freqBins: Array.from(k.freqBins)}));
+          r.shared = calls.every((k) => k.freqBins === calls[0].freqBins && k.spectrogram[0] instanceof Float32Array);
+          r.plain = (await d.processFullFile(x, %d, %r, %r, {threshold_dB: %r, padding_ms: %r, keepSpectrograms: false}))
+                      .every((k) => k.spectrogram === undefined);
+          r.progress = seen; r.isBatCall = calls.every((k) => k instanceof BatCall);
           r.fallback = await new BatCallDetector(cfg, null).processFullFile(x, 1, 1, 1);
           e.free();
           console.log(JSON.stringify(r));
         })();
     """ % (str(tmp_path / "x.f32"), c["fft"], c["window"], c["hop_percent"], c["call_threshold_db"], c["min_call_duration_ms"],
+           c["sr"], c["flow_khz"], c["fhigh_khz"], c["scan_threshold_db"], c["padding_ms"],
            c["sr"], c["flow_khz"], c["fhigh_khz"], c["scan_threshold_db"], c["padding_ms"],
            c["sr"], c["flow_khz"], c["fhigh_khz"], c["scan_threshold_db"], c["padding_ms"])
     out = json.loads(node(script))
@@ -155,10 +161,14 @@ def test_addon_whole_file_pass_equals_python_binding(tmp_path):
     want = fr.process_full_file_native(e, x, c["sr"], c["flow_khz"], c["fhigh_khz"],
                                        {"threshold_dB": c["scan_threshold_db"], "padding_ms": c["padding_ms"]},
                                        {"hopPercent": c["hop_percent"], "callThreshold_dB": c["call_threshold_db"],
-                                        "minCallDuration_ms": c["min_call_duration_ms"], "debugMode": True})
+                                        "minCallDuration_ms": c["min_call_duration_ms"], "debugMode": True},
+                                       keep_spectrograms=True)
     e.free()
-    assert len(out["calls"]) == len(want) > 0
+    assert len(out["calls"]) == len(want) > 0 and out["shared"] and out["plain"]
     for got, ref in zip(out["calls"], want):
         for k, v in ref.items():
+            if k in ("spectrogram", "timeFrames", "freqBins"):           # BatCall's matrix fields, js:785-787
+                assert np.array_equal(np.asarray(got[k], v.dtype), v), k
+                continue
             assert got[k] == v, (k, got[k], v)                           # same library, doubles through JSON: bit-exact
         assert got["kneeTime_ms"] == ref["kneeFreq_ms"]
