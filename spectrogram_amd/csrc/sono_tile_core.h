@@ -400,10 +400,12 @@ struct TileLane {
         static_for<0, G::JPL>([&](auto jj_) {
             constexpr int jj = decltype(jj_)::value;
             if constexpr (PCM) {
-                unsigned long long fa = (unsigned long long)j * G::FPW + (unsigned int)(2 * (h * G::JPL + jj));
-                unsigned long long fb = fa + 1;
-                if (fa >= tr.frames) fa = 0;
-                if (fb >= tr.frames) fb = 0;
+                // A frame past the end of the stream reads the tile's frame 0, as in the f32 path below: what a
+                // frame's absent partner holds reaches the frame's own bins at the level of the last bit, so both
+                // paths must substitute the same samples for their results to agree bit for bit.
+                const unsigned int ta = (unsigned int)(2 * (h * G::JPL + jj)), tb = ta + 1u;
+                const unsigned long long f0 = (unsigned long long)j * G::FPW;
+                const unsigned long long fa = f0 + (ta < tr.rem ? ta : 0u), fb = f0 + (tb < tr.rem ? tb : 0u);
                 const unsigned long long c = a.x16_channels, row = (unsigned long long)R2 * c;
                 const int16_t *qa = a.x16 + (tr.xs_off + (unsigned int)n2 + fa * a.hop) * c + a.x16_channel;
                 const int16_t *qb = a.x16 + (tr.xs_off + (unsigned int)n2 + fb * a.hop) * c + a.x16_channel;

@@ -169,7 +169,8 @@ def test_pcm16_frames_in_hbm_equal_convert_then_stft(N, V, channels, channel):
     # against sono_pcm_to_f32_dev followed by sono_stft_u8_dev: every output bit for bit
     import torch
     H, B, S = N - V, N // 2, 3
-    per = N + 29 * H + 3                                     # sample frames per stream; the last tile is partial
+    per = N + 28 * H + 3                                     # 29 frames per stream: the last tile is partial and the
+                                                             # last frame has no partner in the kernel's frame pairs
     stride = per + 7
     rng = np.random.default_rng(N + channels)
     t = np.arange(S * stride)
@@ -223,7 +224,7 @@ def test_pcm16_fast_scan_equals_convert_then_scan(N, V, channels, channel):
     # the fused fast scan reading int16 sample frames against sono_pcm_to_f32_dev + sono_stft_band_active_dev
     import torch
     H, S = N - V, 2
-    per = N + 37 * H + 5
+    per = N + 36 * H + 5                                     # 37 frames: the last one has no partner in the kernel's pairs
     stride = per + 3
     rng = np.random.default_rng(7 * N + channels)
     t = np.arange(S * stride)
