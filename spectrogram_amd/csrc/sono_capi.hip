@@ -175,13 +175,14 @@ int sono_engine_load_filter_bank(sono_engine *e, const float *w, size_t len, uin
     e->bank.assign(w, w + len);                            // lib.rs:91-93
     e->num_filters = num_filters;
     e->use_bank = true;
+    e->bank_taps_ready = false;
     return SONO_OK;
 }
 
 int sono_engine_clear_filter_bank(sono_engine *e)
 {
     if (!e) return fail(SONO_EINVAL, "sono_engine_clear_filter_bank: NULL engine");
-    e->bank.clear(); e->num_filters = 0; e->use_bank = false;
+    e->bank.clear(); e->num_filters = 0; e->use_bank = false; e->bank_taps_ready = false;
     return SONO_OK;
 }
 
@@ -190,7 +191,7 @@ int sono_engine_release_memory(sono_engine *e)
     if (!e) return fail(SONO_EINVAL, "sono_engine_release_memory: NULL engine");
     DeviceGuard guard(e->device);
     (void)hipStreamSynchronize(e->stream);
-    e->bank.clear(); e->num_filters = 0; e->use_bank = false;       // lib.rs:683-692
+    e->bank.clear(); e->num_filters = 0; e->use_bank = false; e->bank_taps_ready = false;       // lib.rs:683-692
     e->color_map.clear();
     e->has_last = false; e->last_peak_bin.clear(); e->last_peak_mag.clear(); e->last_gmax = 0.0f;
     e->d_in.release(); e->d_out.release(); e->d_peak_bin.release(); e->d_peak_mag.release();
@@ -600,13 +601,28 @@ int sono_stft_u8(sono_engine *e, const float *x, size_t n, uint32_t noverlap, fl
         HIP_TRY(e->d_mags.reserve(F * B * sizeof(float)));
         rc = sono_stft_mag_f32_dev(e, &b, noverlap, (float *)e->d_mags.p, nullptr);
         if (rc) return rc;
-        HIP_TRY(e->d_bank.reserve((e->bank.size() ? e->bank.size() : 1) * sizeof(float)));
-        if (!e->bank.empty())
-            HIP_TRY(hipMemcpyAsync(e->d_bank.p, e->bank.data(), e->bank.size() * sizeof(float),
-                                   hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(sono::launch_filterbank_u8((const float *)e->d_mags.p, F, (int)B, (const float *)e->d_bank.p,
-                                           e->bank.size(), (int)e->num_filters, gain_db, range_db,
-                                           (uint8_t *)e->d_out.p, (uint16_t *)e->d_peak_bin.p,
+        if (!e->bank_taps_ready) {
+            // the bank's non-zero taps, listed once per loaded bank and kept on the device
+            std::vector<unsigned int> start, bin;
+            std::vector<float> w;
+            sono::bank_taps(e->bank.data(), e->bank.size(), e->num_filters, B, start, bin, w);
+            const size_t sb = start.size() * sizeof(unsigned int), tb = bin.size() * sizeof(unsigned int);
+            HIP_TRY(e->d_bank.reserve(sb + 2 * tb + 16));
+            HIP_TRY(hipStreamSynchronize(e->stream));         // an earlier launch may still be reading the old list
+            HIP_TRY(hipMemcpy(e->d_bank.p, start.data(), sb, hipMemcpyHostToDevice));
+            if (tb) {
+                HIP_TRY(hipMemcpy((char *)e->d_bank.p + sb, bin.data(), tb, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy((char *)e->d_bank.p + sb + tb, w.data(), tb, hipMemcpyHostToDevice));
+            }
+            e->bank_tap_count = bin.size();
+            e->bank_taps_ready = true;
+        }
+        const size_t sb = e->num_filters * sizeof(unsigned int), tb = e->bank_tap_count * sizeof(unsigned int);
+        HIP_TRY(sono::launch_filterbank_u8((const float *)e->d_mags.p, F, (int)B, (const unsigned int *)e->d_bank.p,
+                                           (const unsigned int *)((char *)e->d_bank.p + sb),
+                                           (const float *)((char *)e->d_bank.p + sb + tb), (unsigned int)e->bank_tap_count,
+                                           (int)e->num_filters, gain_db,
+                                           range_db, (uint8_t *)e->d_out.p, (uint16_t *)e->d_peak_bin.p,
                                            (float *)e->d_peak_mag.p, (uint32_t *)e->d_gmax.p, e->stream));
     }
     e->last_peak_bin.resize(F);

@@ -146,6 +146,8 @@ struct sono_engine {
     std::vector<float> bank;
     unsigned int num_filters = 0;
     bool use_bank = false;
+    bool bank_taps_ready = false;       // d_bank holds the current bank's non-zero taps (sono::bank_taps)
+    size_t bank_tap_count = 0;
     // state left behind by the last u8 call (lib.rs:24-26)
     bool has_last = false;
     std::vector<uint16_t> last_peak_bin;

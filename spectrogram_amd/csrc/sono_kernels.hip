@@ -110,71 +110,180 @@ hipError_t launch_power_reduce(const float *power, unsigned long long frames, in
 }
 
 // ---------------------------------------------------------------------------
-// Filter-bank path (cold: lib.rs:270-274,310-334).  One workgroup per frame;
-// thread i owns filter i and walks the magnitude row in bin order with row
-// stride `bins`, bounds-checked against the bank length, as the reference does.
-// The same kernel records the frame's peak from the unfiltered magnitudes.
+// Filter-bank path (lib.rs:270-274, 310-334).  The reference walks every
+// (filter, bin) pair of the flat bank with row stride `bins`, bounds-checked
+// against the bank's length, and sums magnitude * weight in bin order, product
+// and sum rounded separately (wasm has no fused multiply-add).  A product with a
+// zero weight adds an exact zero, so the kernel walks only the bank's NON-ZERO
+// taps (bank_taps(): per filter, bins ascending; tap k of filter i is stored at k * filters + i, so
+// that the lanes of a wave, which hold neighbouring filters, read neighbouring words) and still produces the
+// reference's sums bit for bit; the banks the application builds have two taps
+// per filter (spectrogram.esm.js:1197-1232), 256 times less work than the pairs.
+// Every wave works on its own: it takes a magnitude row (16-byte loads; the next row's are
+// requested before the current one is worked on), keeps it in the wave's part of LDS, finds the
+// row's peak from the unfiltered magnitudes on the way, and then its lanes take the filters,
+// each summing its filter's taps (staged in LDS when the list is small enough, which the
+// application's banks always are) and quantising.  No workgroup barrier inside the loop.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void filterbank_u8_kernel(
-    const float *mags, unsigned long long frames, int bins, const float *bank,
-    unsigned long long bank_len, int num_filters, float gain_db, float range_db,
+constexpr int FB_THREADS = 256, FB_ROWS = FB_THREADS / 64;
+constexpr unsigned int FB_LDS_TAPS = 4096;       // tap lists up to this many entries (and filters) are staged in LDS
+
+__device__ __forceinline__ void fb_wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// FB_MAXQ: 16-byte pieces of a row per lane (1 up to 256 bins, 2 / 4 / 8 at 512 / 1024 / 2048); a template
+// parameter so that the small rows do not pay the registers of the large ones and eight waves fit a SIMD.
+template <int FB_MAXQ>
+__global__ __launch_bounds__(FB_THREADS) void filterbank_taps_u8_kernel(
+    const float *mags, unsigned long long frames, int bins, const unsigned int *tap_start, const unsigned int *tap_bin,
+    const float *tap_w, unsigned int taps, int num_filters, int taps_in_lds, float gain_db, float range_db,
     uint8_t *out_u8, uint16_t *peak_bin, float *peak_mag, unsigned int *gmax_bits)
 {
-    extern __shared__ float row[];
-    __shared__ unsigned long long s_peak;
-    const unsigned long long f = blockIdx.x;
-    if (threadIdx.x == 0) s_peak = peak_key(0.0f, 0u);
-    __syncthreads();
-    unsigned long long best = peak_key(0.0f, 0u);
-    for (int j = threadIdx.x; j < bins; j += blockDim.x) {
-        const float m = mags[f * (unsigned long long)bins + j];
-        row[j] = m;
-        if (m > 0.0f) {
-            const unsigned long long key = peak_key(m, (unsigned int)j);
-            best = key > best ? key : best;
-        }
+    // tap_start[i] = number of taps of filter i; taps = (largest count) x filters = entries of tap_bin / tap_w
+    extern __shared__ float rows[];                        // FB_ROWS x bins, then (taps_in_lds) counts / bin / w
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // LDS copies of the tap list, at fixed places behind the rows so that every access below is an LDS
+    // instruction (a pointer that may be either kind would make them flat loads)
+    unsigned int *const l_start = (unsigned int *)(rows + (size_t)FB_ROWS * bins), *const l_bin = l_start + num_filters;
+    float *const l_w = (float *)(l_bin + taps);
+    if (taps_in_lds) {
+        for (int i = threadIdx.x; i < num_filters; i += FB_THREADS) l_start[i] = tap_start[i];
+        for (unsigned int t = threadIdx.x; t < taps; t += FB_THREADS) { l_bin[t] = tap_bin[t]; l_w[t] = tap_w[t]; }
     }
-    atomicMax(&s_peak, best);
     __syncthreads();
     const float gain_db_neg = -gain_db;
     const float range_db_reciprocal = 255.0f / range_db;
-    for (int i = threadIdx.x; i < num_filters; i += blockDim.x) {
-        float sum = 0.0f;
-        const unsigned long long r0 = (unsigned long long)i * (unsigned long long)bins;
-        if (bank_len != 0)
-            for (int j = 0; j < bins; ++j)
-                if (r0 + j < bank_len) sum += row[j] * bank[r0 + j];
-        const float safe = sum > 1e-10f ? sum : 1e-10f;
-        const float db = 20.0f * log10f(safe);
-        unsigned int code;
-        if (db < gain_db_neg - range_db) code = 0;
-        else if (db > gain_db_neg) code = 255;
-        else {
-            float v = (db - (gain_db_neg - range_db)) * range_db_reciprocal;
-            v = v > 0.0f ? v : 0.0f;
-            v = v < 255.0f ? v : 255.0f;
-            code = (unsigned int)v;
+    const int quads = bins / 4;                            // float4 per row; lane owns quads lane, lane + 64, ...
+    float *const row = rows + (size_t)wave * bins;
+    const unsigned long long n_waves = (unsigned long long)gridDim.x * FB_ROWS;
+    unsigned long long f = (unsigned long long)blockIdx.x * FB_ROWS + wave;
+    unsigned int wave_gmax = 0;
+    float4 nxt[FB_MAXQ];
+    auto request = [&](unsigned long long g) {
+        const float4 *src = (const float4 *)(mags + g * (unsigned long long)bins);
+#pragma unroll
+        for (int k = 0; k < FB_MAXQ; ++k)
+            if (64 * k < quads) {                          // the same in every lane
+                const int q = lane + 64 * k;
+                nxt[k] = q < quads ? src[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+    };
+    if (f < frames) request(f);
+    for (; f < frames; f += n_waves) {
+        fb_wave_fence();                                   // the previous row's sums have read the row
+        unsigned long long best = peak_key(0.0f, 0u);
+#pragma unroll
+        for (int k = 0; k < FB_MAXQ; ++k)
+            if (64 * k < quads) {
+                const int q = lane + 64 * k;
+                if (q < quads) {
+                    const float4 m = nxt[k];
+                    ((float4 *)row)[q] = m;
+                    const float v[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (v[c] > 0.0f) {
+                            const unsigned long long key = peak_key(v[c], (unsigned int)(4 * q + c));
+                            best = key > best ? key : best;
+                        }
+                }
+            }
+        if (f + n_waves < frames) request(f + n_waves);
+        // the row's largest magnitude, then the lowest bin among the lanes that hold it (the key's low word is the
+        // inverted bin): two reductions of 32-bit words instead of one of 64-bit keys
+        unsigned int bits = (unsigned int)(best >> 32);
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned int other = __shfl_xor(bits, o, 64);
+            bits = other > bits ? other : bits;
         }
-        out_u8[f * (unsigned long long)num_filters + i] = (uint8_t)code;
+        unsigned int inv = (unsigned int)(best >> 32) == bits ? (unsigned int)(best & 0xFFFFFFFFull) : 0u;
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned int other = __shfl_xor(inv, o, 64);
+            inv = other > inv ? other : inv;
+        }
+        if (lane == 0) {
+            if (peak_bin) peak_bin[f] = (uint16_t)(0xFFFFFFFFu - inv);
+            if (peak_mag) peak_mag[f] = __uint_as_float(bits);
+            wave_gmax = bits > wave_gmax ? bits : wave_gmax;
+        }
+        fb_wave_fence();                                   // the row is in LDS for every lane
+        for (int i = lane; i < num_filters; i += 64) {
+            float sum = 0.0f;
+            if (taps_in_lds) {
+                for (unsigned int k = 0, n = l_start[i], t = (unsigned int)i; k < n; ++k, t += (unsigned int)num_filters)
+                    sum = __fadd_rn(sum, __fmul_rn(row[l_bin[t]], l_w[t]));
+            } else {
+                size_t t = (size_t)i;
+                for (unsigned int k = 0, n = tap_start[i]; k < n; ++k, t += (size_t)num_filters)
+                    sum = __fadd_rn(sum, __fmul_rn(row[tap_bin[t]], tap_w[t]));
+            }
+            const float safe = sum > 1e-10f ? sum : 1e-10f;
+            const float db = 20.0f * log10f(safe);
+            unsigned int code;
+            if (db < gain_db_neg - range_db) code = 0;
+            else if (db > gain_db_neg) code = 255;
+            else {
+                float v = (db - (gain_db_neg - range_db)) * range_db_reciprocal;
+                v = v > 0.0f ? v : 0.0f;
+                v = v < 255.0f ? v : 255.0f;
+                code = (unsigned int)v;
+            }
+            out_u8[f * (unsigned long long)num_filters + i] = (uint8_t)code;
+        }
     }
-    if (threadIdx.x == 0) {
-        const unsigned int bits = (unsigned int)(s_peak >> 32);
-        if (peak_bin) peak_bin[f] = (uint16_t)(0xFFFFFFFFu - (unsigned int)(s_peak & 0xFFFFFFFFull));
-        if (peak_mag) peak_mag[f] = __uint_as_float(bits);
-        if (gmax_bits) atomicMax(gmax_bits, bits);
+    if (lane == 0 && gmax_bits && wave_gmax) atomicMax(gmax_bits, wave_gmax);
+}
+
+// The bank's non-zero taps.  count[i] = taps of filter i; tap k of filter i (bins ascending) sits at entry
+// k * num_filters + i of bin / w, which have (largest count) x num_filters entries (unused ones zero).
+// Weights that compare equal to zero (+0 and -0) are the ones left out; NaN and infinite weights stay.
+void bank_taps(const float *bank, size_t bank_len, size_t num_filters, size_t bins, std::vector<unsigned int> &count,
+               std::vector<unsigned int> &bin, std::vector<float> &w)
+{
+    count.assign(num_filters, 0);
+    size_t most = 0;
+    for (size_t i = 0; i < num_filters; ++i) {
+        const size_t r0 = i * bins;
+        for (size_t j = 0; j < bins && r0 + j < bank_len; ++j) count[i] += !(bank[r0 + j] == 0.0f);
+        most = count[i] > most ? count[i] : most;
+    }
+    bin.assign(most * num_filters, 0u);
+    w.assign(most * num_filters, 0.0f);
+    for (size_t i = 0; i < num_filters; ++i) {
+        const size_t r0 = i * bins;
+        size_t k = 0;
+        for (size_t j = 0; j < bins && r0 + j < bank_len; ++j)
+            if (!(bank[r0 + j] == 0.0f)) {
+                bin[k * num_filters + i] = (unsigned int)j;
+                w[k * num_filters + i] = bank[r0 + j];
+                ++k;
+            }
     }
 }
 
-hipError_t launch_filterbank_u8(const float *mags, unsigned long long frames, int bins, const float *bank,
-                                unsigned long long bank_len, int num_filters, float gain_db, float range_db,
-                                uint8_t *out_u8, uint16_t *peak_bin, float *peak_mag,
+hipError_t launch_filterbank_u8(const float *mags, unsigned long long frames, int bins, const unsigned int *tap_start,
+                                const unsigned int *tap_bin, const float *tap_w, unsigned int taps, int num_filters,
+                                float gain_db, float range_db, uint8_t *out_u8, uint16_t *peak_bin, float *peak_mag,
                                 unsigned int *gmax_bits, hipStream_t stream)
 {
     if (frames == 0) return hipSuccess;
-    if (frames > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(filterbank_u8_kernel, dim3((unsigned int)frames), dim3(256), (size_t)bins * sizeof(float),
-                       stream, mags, frames, bins, bank, bank_len, num_filters, gain_db, range_db, out_u8,
-                       peak_bin, peak_mag, gmax_bits);
+    if (bins <= 0 || bins % 4 != 0 || bins > 2048 || num_filters <= 0) return hipErrorInvalidValue;
+    const int in_lds = taps <= FB_LDS_TAPS && (unsigned int)num_filters <= FB_LDS_TAPS;
+    const size_t lds = (size_t)FB_ROWS * bins * sizeof(float) + (in_lds ? ((size_t)num_filters + 2 * (size_t)taps) * 4 : 0);
+    const unsigned long long groups = (frames + FB_ROWS - 1) / FB_ROWS;
+    const unsigned int grid = (unsigned int)(groups < 2048 ? groups : 2048);       // 8 workgroups per CU
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(FB_THREADS), lds, stream, mags, frames, bins, tap_start, tap_bin, tap_w, taps,
+                           num_filters, in_lds, gain_db, range_db, out_u8, peak_bin, peak_mag, gmax_bits);
+    };
+    if (bins <= 256) go(filterbank_taps_u8_kernel<1>);
+    else if (bins <= 512) go(filterbank_taps_u8_kernel<2>);
+    else if (bins <= 1024) go(filterbank_taps_u8_kernel<4>);
+    else go(filterbank_taps_u8_kernel<8>);
     return hipGetLastError();
 }
 

@@ -160,6 +160,49 @@ def test_filter_bank_quirk(golden):
     e.free()
 
 
+@pytest.mark.parametrize("N,nf,kind", [(1024, 64, "two_tap"), (1024, 512, "two_tap"), (512, 40, "dense"), (256, 7, "short"),
+                                        (2048, 33, "sparse_signed"), (4096, 24, "empty_rows")])
+def test_filter_bank_shapes_against_the_oracle(N, nf, kind):
+    """apply_filter_bank (lib.rs:310-334) on the bank shapes the non-zero tap list has to get right: the application's
+    two-tap banks (rows of N/2 + 1 weights used with stride N/2, spectrogram.esm.js:1197-1232), a dense bank, one shorter
+    than filters x bins (the reference's bounds check), signed and zero weights, filters without any tap.  The sums are
+    the reference's bit for bit, so the codes differ only where the magnitudes themselves do."""
+    B = N // 2
+    rng = np.random.default_rng(N + nf)
+    if kind == "two_tap":
+        bank = np.zeros((nf, B + 1), np.float32)
+        pos = np.sort(rng.uniform(0, B - 1, nf))
+        for i, p in enumerate(pos):
+            o = int(p)
+            bank[i, o], bank[i, o + 1] = 1 - (p - o), p - o
+    elif kind == "dense":
+        bank = rng.uniform(0.0, 0.02, (nf, B)).astype(np.float32)
+    elif kind == "short":
+        bank = rng.uniform(0.0, 0.05, nf * B - B - 17).astype(np.float32)
+    elif kind == "sparse_signed":
+        bank = np.where(rng.random((nf, B)) < 0.03, rng.uniform(-0.2, 1.0, (nf, B)), 0.0).astype(np.float32)
+        bank[3, 5] = -0.0
+    else:
+        bank = np.zeros((nf, B), np.float32)
+        bank[::3, 10:14] = 0.25
+    x = signal(N + 45 * (N // 4), N + nf, amp=0.7)
+    e = sa.SpectrogramEngine(N, "hann")
+    o = so.OracleEngine(N, "hann")
+    e.load_filter_bank(bank.ravel(), nf)
+    o.load_filter_bank(bank.ravel(), nf)
+    got, want = e.compute_spectrogram_u8(x, N - N // 4, 20.0, 80.0), o.compute_spectrogram_u8(x, N - N // 4, 20.0, 80.0)
+    assert got.size == want.size == 46 * nf
+    nd, nt = parity.u8_diff(got, want, f"{kind} bank")
+    assert nd <= max(2, parity.U8_MAX_FRACTION * nt)
+    assert np.array_equal(e.get_peaks(0.3), o.get_peaks(0.3))
+    # a second bank on the same engine replaces the first one's taps
+    e.load_filter_bank(np.full(B, 0.01, np.float32), 1)
+    o.load_filter_bank(np.full(B, 0.01, np.float32), 1)
+    nd, nt = parity.u8_diff(e.compute_spectrogram_u8(x, N - N // 4, 20.0, 80.0), o.compute_spectrogram_u8(x, N - N // 4, 20.0, 80.0), "one filter")
+    assert nt == 46 and nd <= 2
+    e.free()
+
+
 def test_image_path():
     e = sa.SpectrogramEngine(256, "hann")
     x = signal(256 + 40 * 64, 4)

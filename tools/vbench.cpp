@@ -76,18 +76,27 @@ int main(int argc, char **argv)
     c.name = name;
     auto stft_case = [&](uint32_t N, const char *window, int has_alpha, float alpha, uint32_t V, size_t seconds, int mode) {
         // mode 0 u8 + features, 1 features only, 2 magnitudes, 3 band flags, 4 u8 from 16-bit PCM,
-        // 5 filter bank (64 filters) through the host-pointer call: only that form applies a loaded bank, so the
+        // 5 filter bank (the application's mel bank) through the host-pointer call: only that form applies a loaded bank, so the
         // event time includes both PCIe copies and the kernels' own times have to be read from the profiler
         if (seconds_arg) seconds = seconds_arg;
         const size_t n = seconds * (size_t)SR, F = sono_frames_for(n, N, V), hop = N - V, bins = N / 2;
         float *x = dalloc<float>(n);
         fill_noise<<<4096, 256, 0, s>>>(x, n);
         SONO(sono_engine_create(N, window, has_alpha, alpha, -1, &e));
-        const uint32_t nf = 64;
+        // the application's bank (spectrogram.esm.js:415-418, 1197-1232): N/2 filters on the mel scale, two taps each,
+        // rows of N/2 + 1 weights flattened -- which the engine then reads with stride N/2 (lib.rs:317-326)
+        const uint32_t nf = bins;
         if (mode == 5) {
-            std::vector<float> w((size_t)nf * bins, 0.0f);
-            for (uint32_t f = 0; f < nf; ++f)
-                for (uint32_t b = f * bins / nf; b < (f + 2) * bins / nf && b < bins; ++b) w[(size_t)f * bins + b] = 0.5f;
+            const size_t rowlen = bins + 1;
+            std::vector<float> w((size_t)nf * rowlen, 0.0f);
+            const double mel_max = 2595.0 * std::log10(1.0 + (SR / 2) / 700.0), hz_per_bin = SR / N;
+            for (uint32_t f = 0; f < nf; ++f) {
+                const double hz = 700.0 * (std::pow(10.0, (double)f / nf * mel_max / 2595.0) - 1.0);
+                const size_t o = (size_t)std::floor(hz / hz_per_bin);
+                const double c = (hz - o * hz_per_bin) / hz_per_bin;
+                if (o < rowlen) w[f * rowlen + o] = (float)(1 - c);
+                if (o + 1 < rowlen) w[f * rowlen + o + 1] = (float)c;
+            }
             SONO(sono_engine_load_filter_bank(e, w.data(), w.size(), nf));
         }
         uint8_t *out = mode == 0 || mode == 4 ? dalloc<uint8_t>(F * bins) : nullptr;
