@@ -300,9 +300,8 @@ def main():
         if detect:
             # processFullFile (batCallDetector.js:584-840) in one library call: fast scan at 50 % overlap, regions,
             # analysis spectrograms at hop 32, framing and measurement of every call; then the table's rows
-            calls = framing.process_full_file_native(engine, x_host, sr, 10.0, 128.0, {"threshold_dB": -60, "padding_ms": 5},
-                                                     {"debugMode": True})
-            det_rows[:] = [sharding.calls_to_rows(calls, file_id=rank, channel=0)]
+            det_rows[:] = [framing.process_full_file_table(engine, x_host, sr, 10.0, 128.0, {"threshold_dB": -60, "padding_ms": 5},
+                                                           {"debugMode": True}, file_id=rank, channel=0)]
             return
         engine.stft_band_active_dev(x.data_ptr(), 1, per, per, scan_v, min_bin, max_bin, target, active.data_ptr(), 0,
                                     stream.cuda_stream)

@@ -147,6 +147,8 @@ void sono_engine_destroy(sono_engine *e)
     e->d_db.release(); e->d_flags.release(); e->d_edges.release(); e->d_runs.release();
     e->d_count.release(); e->d_select_tmp.release();
     e->h_in.release(); e->h_out.release();
+    for (auto &slot : e->measure_slot) slot.release();
+    for (auto &slot : e->upload_slot) slot.release();
     for (auto &slot : e->ragged) {
         if (slot.done) { (void)hipEventSynchronize(slot.done); (void)hipEventDestroy(slot.done); }
         slot.buf.release();
@@ -198,6 +200,7 @@ int sono_engine_release_memory(sono_engine *e)
     e->d_mags.release(); e->d_bank.release();
     e->d_db.release(); e->d_flags.release(); e->d_edges.release(); e->d_runs.release(); e->d_select_tmp.release();
     e->h_in.release(); e->h_out.release(); e->full_file_calls.clear(); e->full_file_calls.shrink_to_fit();
+    for (auto &slot : e->measure_slot) slot.release();
     e->full_file_slices.clear(); e->full_file_slices.shrink_to_fit();
     if (e->pipe) { sono::stream_pipe_destroy(e->pipe); e->pipe = nullptr; }
     return SONO_OK;

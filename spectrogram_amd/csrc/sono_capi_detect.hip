@@ -151,10 +151,10 @@ int sono_fast_scan_segments(sono_engine *e, const float *x, size_t n, double sam
     DeviceGuard guard(e->device);
     const size_t used = (F - 1) * (size_t)hop + N;
     HIP_TRY(e->d_in.reserve(used * sizeof(float)));
-    HIP_TRY(hipMemcpyAsync(e->d_in.p, x, used * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    int rc = sono::upload_host_array(e, e->d_in.p, x, used * sizeof(float), e->stream);
+    if (rc) return rc;
     HIP_TRY(e->d_flags.reserve(F));
     sono_batch b{(const float *)e->d_in.p, 1, used, used};
-    int rc;
     if (max_bin < bins) {
         // the usual case: one fused launch, the magnitudes never leave the chip
         rc = sono_stft_band_active_dev(e, &b, noverlap, min_bin, max_bin, target, (uint8_t *)e->d_flags.p, nullptr, nullptr);

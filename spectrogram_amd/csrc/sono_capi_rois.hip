@@ -68,6 +68,27 @@ struct StageTimer {
     }
 };
 
+// Many memcpys at once, shared out over host threads piece by piece: one thread moves about 10 GB/s and pays every
+// first-touch page fault of a fresh destination alone; the passes below move gigabytes between the recording and the
+// staging areas.
+struct CopyJob { void *dst; const void *src; size_t bytes; };
+void parallel_copy(const std::vector<CopyJob> &jobs)
+{
+    size_t total = 0;
+    for (const CopyJob &j : jobs) total += j.bytes;
+    unsigned int threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (total < ((size_t)8 << 20)) threads = 1;
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t i = next.fetch_add(1); i < jobs.size(); i = next.fetch_add(1))
+            std::memcpy(jobs[i].dst, jobs[i].src, jobs[i].bytes);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned int t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread &th : pool) th.join();
+}
+
 // Where region r's samples are read from after sono_analyze_rois: its x_filtered holds the regions that went through the
 // automatic high-pass (cutoff > 0 and below Nyquist, js:4058) and nothing else.
 const float *region_audio(const float *x, const float *x_filtered, const sono_roi_table *t, size_t r, double sample_rate)
@@ -180,9 +201,22 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
 
     DeviceGuard guard(e->device);
     hipStream_t s = e->stream;
+    StageTimer timer("sono_analyze_rois");
+    // All regions' samples stay in HBM for the whole call (packed, region after region): the first pass works through
+    // them in batches of at most kBatchFrames frames, the automatic high-pass then filters every region that needs it
+    // in ONE launch -- the filter is a serial recurrence per region, one lane each, so its time is that of the longest
+    // region however many regions run beside it --, and the second pass goes through the filtered regions in batches.
+    size_t total_samples = 0;
+    std::vector<uint64_t> src_off(n_rois);
+    for (size_t r = 0; r < n_rois; ++r) { src_off[r] = total_samples; total_samples += (size_t)(rois[r].end - rois[r].start); }
+    HIP_TRY(e->d_in.reserve((total_samples ? total_samples : 1) * sizeof(float)));
+    float *d_all = (float *)e->d_in.p;
+    std::vector<sono::HighpassJob> jobs;                     // every region that gets the high-pass
+    std::vector<size_t> job_region;
+    size_t filtered_samples = 0;
     size_t r0 = 0;
     while (r0 < n_rois) {
-        // ---- one batch: regions r0 .. r1-1 ------------------------------------------------------
+        // ---- first pass, one batch: regions r0 .. r1-1 -------------------------------------------
         size_t r1 = r0, frames = 0, samples = 0;
         while (r1 < n_rois && (r1 == r0 || frames + (out->row0[r1 + 1] - out->row0[r1]) <= kBatchFrames)) {
             frames += (size_t)(out->row0[r1 + 1] - out->row0[r1]);
@@ -190,23 +224,31 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
             ++r1;
         }
         const size_t cnt = r1 - r0;
-        if (frames == 0) { for (size_t r = r0; r < r1; ++r) for (size_t z = 0; z < SONO_MAX_ZONES; ++z) out->zonal[r * SONO_MAX_ZONES + z] = -102.0; r0 = r1; continue; }
         // pack the batch's samples and upload them in one copy
         if (!e->h_in.reserve((samples ? samples : 1) * sizeof(float)))
             return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
         float *packed = (float *)e->h_in.p;
         std::vector<uint64_t> off(cnt), len(cnt), rows(cnt), first_row(cnt);
         size_t pos = 0;
+        std::vector<CopyJob> copies(cnt);
         for (size_t i = 0; i < cnt; ++i) {
             const sono_segment &g = rois[r0 + i];
-            off[i] = pos; len[i] = g.end - g.start; rows[i] = out->row0[r0 + i];
-            std::memcpy(packed + pos, x + g.start, (size_t)len[i] * sizeof(float));
+            off[i] = src_off[r0 + i]; len[i] = g.end - g.start; rows[i] = out->row0[r0 + i];
+            copies[i] = {packed + pos, x + g.start, (size_t)len[i] * sizeof(float)};
             pos += (size_t)len[i];
         }
-        HIP_TRY(e->d_in.reserve((samples ? samples : 1) * sizeof(float)));
-        HIP_TRY(hipMemcpyAsync(e->d_in.p, packed, samples * sizeof(float), hipMemcpyHostToDevice, s));
-        rc = peaks_pass(e, (const float *)e->d_in.p, off, len, rows, b, frames, out, &first_row);
+        parallel_copy(copies);
+        timer.lap("pack samples");
+        HIP_TRY(hipMemcpyAsync(d_all + src_off[r0], packed, samples * sizeof(float), hipMemcpyHostToDevice, s));
+        if (frames == 0) {
+            HIP_TRY(hipStreamSynchronize(s));                // the staging area is reused by the next batch
+            for (size_t r = r0; r < r1; ++r) for (size_t z = 0; z < SONO_MAX_ZONES; ++z) out->zonal[r * SONO_MAX_ZONES + z] = -102.0;
+            r0 = r1;
+            continue;
+        }
+        rc = peaks_pass(e, d_all, off, len, rows, b, frames, out, &first_row);
         if (rc) return rc;
+        timer.lap("upload, STFT, dB, peaks");
         // ---- noise floors of every region's first six frames (js:622-627), from the unfiltered spectrogram ----
         {
             std::vector<unsigned long long> fr(cnt);
@@ -231,59 +273,78 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
                                                      SONO_MAX_ZONES, d_floors, s));
             HIP_TRY(hipMemcpyAsync(out->zonal + r0 * SONO_MAX_ZONES, d_floors, fb, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
+            timer.lap("zonal floors");
         }
         // ---- automatic high-pass (js:631-671): regions whose loudest bin lies at 30 kHz or above ----
-        if (auto_highpass) {
-            std::vector<sono::HighpassJob> jobs;
-            std::vector<size_t> job_region;                  // index of each job's region inside the batch
-            std::vector<uint64_t> off2, len2, rows2;
-            size_t fpos = 0, frames2 = 0;
-            for (size_t i = 0; i < cnt; ++i) {
-                const size_t F = (size_t)(out->row0[r0 + i + 1] - out->row0[r0 + i]);
-                if (F == 0) continue;
-                float best = -INFINITY;
-                int32_t bin = 0;
-                for (size_t f = 0; f < F; ++f)                                     // first maximum in frame order (js:635-644)
-                    if (out->peak_db[rows[i] + f] > best) { best = out->peak_db[rows[i] + f]; bin = out->peak_bin[rows[i] + f]; }
-                if (bin < 0) bin = 0;
-                const double cutoff = sono::host_auto_highpass_khz((double)freq_bins[bin] / 1000);      // js:646-647
-                out->highpass_khz[r0 + i] = (float)cutoff;
-                if (!(cutoff > 0)) continue;
-                const int c = cutoff == 20.0 ? 0 : cutoff == 25.0 ? 1 : 2;
-                if (!corner_ok[c]) continue;
-                jobs.push_back({off[i], fpos, len[i], (unsigned int)c, 0u});
-                job_region.push_back(i);
-                off2.push_back(fpos); len2.push_back(len[i]); rows2.push_back(rows[i]);
-                fpos += (size_t)len[i];
-                frames2 += F;
-            }
-            if (!jobs.empty()) {
-                const size_t jb = jobs.size() * sizeof(sono::HighpassJob);
-                HIP_TRY(e->d_runs.reserve(fpos * sizeof(float)));
-                HIP_TRY(e->d_flags.reserve(jb + sizeof(coefs)));
-                sono::HighpassJob *d_jobs = (sono::HighpassJob *)e->d_flags.p;
-                sono::HighpassCoef *d_coefs = (sono::HighpassCoef *)((char *)e->d_flags.p + jb);
-                HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jb, hipMemcpyHostToDevice, s));
-                HIP_TRY(hipMemcpyAsync(d_coefs, coefs, sizeof(coefs), hipMemcpyHostToDevice, s));
-                HIP_TRY(sono::launch_highpass_regions((const float *)e->d_in.p, (float *)e->d_runs.p, d_jobs, jobs.size(), d_coefs, s));
-                if (x_filtered) {
-                    if (!e->h_in.reserve(fpos * sizeof(float)))        // the packed input has been uploaded and used by now
-                        return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
-                    const float *filt = (const float *)e->h_in.p;
-                    HIP_TRY(hipMemcpyAsync(e->h_in.p, e->d_runs.p, fpos * sizeof(float), hipMemcpyDeviceToHost, s));
-                    HIP_TRY(hipStreamSynchronize(s));
-                    for (size_t k = 0; k < jobs.size(); ++k)
-                        std::memcpy(x_filtered + rois[r0 + job_region[k]].start, filt + jobs[k].dst,
-                                    (size_t)jobs[k].len * sizeof(float));
-                }
-                rc = peaks_pass(e, (const float *)e->d_runs.p, off2, len2, rows2, b, frames2, out, nullptr);
-                if (rc) return rc;
-            }
+        for (size_t i = 0; auto_highpass && i < cnt; ++i) {
+            const size_t F = (size_t)(out->row0[r0 + i + 1] - out->row0[r0 + i]);
+            if (F == 0) continue;
+            float best = -INFINITY;
+            int32_t bin = 0;
+            for (size_t f = 0; f < F; ++f)                                         // first maximum in frame order (js:635-644)
+                if (out->peak_db[rows[i] + f] > best) { best = out->peak_db[rows[i] + f]; bin = out->peak_bin[rows[i] + f]; }
+            if (bin < 0) bin = 0;
+            const double cutoff = sono::host_auto_highpass_khz((double)freq_bins[bin] / 1000);          // js:646-647
+            out->highpass_khz[r0 + i] = (float)cutoff;
+            if (!(cutoff > 0)) continue;
+            const int c = cutoff == 20.0 ? 0 : cutoff == 25.0 ? 1 : 2;
+            if (!corner_ok[c]) continue;
+            jobs.push_back({off[i], filtered_samples, len[i], (unsigned int)c, 0u});
+            job_region.push_back(r0 + i);
+            filtered_samples += (size_t)len[i];
         }
         r0 = r1;
     }
+    if (jobs.empty()) return SONO_OK;
+    // ---- the high-pass of all regions that need it, one launch; the filtered samples packed job after job ----
+    const size_t jb = jobs.size() * sizeof(sono::HighpassJob);
+    HIP_TRY(e->d_runs.reserve(filtered_samples * sizeof(float)));
+    HIP_TRY(e->d_flags.reserve(jb + sizeof(coefs)));
+    sono::HighpassJob *d_jobs = (sono::HighpassJob *)e->d_flags.p;
+    sono::HighpassCoef *d_coefs = (sono::HighpassCoef *)((char *)e->d_flags.p + jb);
+    HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_coefs, coefs, sizeof(coefs), hipMemcpyHostToDevice, s));
+    HIP_TRY(sono::launch_highpass_regions(d_all, (float *)e->d_runs.p, d_jobs, jobs.size(), d_coefs, s));
+    if (x_filtered) {
+        // back to the host in pieces of whole regions through the pinned staging area, then to their places
+        const size_t piece = (size_t)16 << 20;               // samples per piece (a region longer than that goes alone)
+        size_t k0 = 0;
+        while (k0 < jobs.size()) {
+            size_t k1 = k0, count = 0;
+            while (k1 < jobs.size() && (k1 == k0 || count + jobs[k1].len <= piece)) count += (size_t)jobs[k1++].len;
+            if (!e->h_in.reserve(count * sizeof(float)))
+                return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
+            const float *filt = (const float *)e->h_in.p;
+            HIP_TRY(hipMemcpyAsync(e->h_in.p, (const float *)e->d_runs.p + jobs[k0].dst, count * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            std::vector<CopyJob> copies(k1 - k0);
+            for (size_t k = k0; k < k1; ++k)
+                copies[k - k0] = {x_filtered + rois[job_region[k]].start, filt + (jobs[k].dst - jobs[k0].dst), (size_t)jobs[k].len * sizeof(float)};
+            parallel_copy(copies);
+            k0 = k1;
+        }
+    }
+    timer.lap("high-pass, filtered samples");
+    // ---- second pass over the filtered regions, in batches ----
+    size_t k0 = 0;
+    while (k0 < jobs.size()) {
+        size_t k1 = k0, frames2 = 0;
+        std::vector<uint64_t> off2, len2, rows2;
+        while (k1 < jobs.size()) {
+            const size_t r = job_region[k1], F = (size_t)(out->row0[r + 1] - out->row0[r]);
+            if (k1 > k0 && frames2 + F > kBatchFrames) break;
+            off2.push_back(jobs[k1].dst); len2.push_back(jobs[k1].len); rows2.push_back(out->row0[r]);
+            frames2 += F;
+            ++k1;
+        }
+        rc = peaks_pass(e, (const float *)e->d_runs.p, off2, len2, rows2, b, frames2, out, nullptr);
+        if (rc) return rc;
+        k0 = k1;
+    }
+    timer.lap("second pass");
     return SONO_OK;
 }
+
 
 int sono_frame_roi_calls(const float *x, const float *x_filtered, size_t n, const sono_segment *rois, size_t n_rois, const sono_roi_table *t,
                          double sample_rate, uint32_t fft_size, double call_threshold_db, double min_call_duration_ms,
@@ -426,44 +487,54 @@ static int measure_roi_calls(sono_engine *e, const float *x, const float *x_filt
     hipStream_t s = e->stream;
     if (threads == 0) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     StageTimer timer("sono_measure_roi_calls");
-    size_t c0 = 0;
-    while (c0 < n_calls) {
-        size_t c1 = c0, frames = 0, samples = 0;
-        while (c1 < n_calls && (c1 == c0 || frames + slices[c1].count <= kMeasureFrames)) {
-            frames += (size_t)slices[c1].count;
-            samples += (size_t)(slices[c1].count - 1) * b.hop + N;
-            ++c1;
+    // Batches of at most kMeasureFrames frames go through two slots of staging memory: while the host threads measure
+    // the calls of one batch, the next one is packed, uploaded, transformed and copied back.
+    struct Batch {
+        size_t c0 = 0, c1 = 0, frames = 0, samples = 0;
+        std::vector<uint64_t> off, len, row;
+    };
+    for (sono_engine::MeasureSlot &slot : e->measure_slot)
+        if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    auto prepare = [&](Batch &bt, size_t c0, sono_engine::MeasureSlot &slot) -> int {
+        bt.c0 = bt.c1 = c0; bt.frames = bt.samples = 0;
+        while (bt.c1 < n_calls && (bt.c1 == c0 || bt.frames + slices[bt.c1].count <= kMeasureFrames)) {
+            bt.frames += (size_t)slices[bt.c1].count;
+            bt.samples += (size_t)(slices[bt.c1].count - 1) * b.hop + N;
+            ++bt.c1;
         }
-        const size_t cnt = c1 - c0;
-        if (!e->h_in.reserve(samples * sizeof(float)) || !e->h_out.reserve(frames * b.nb * sizeof(float)))
+        const size_t cnt = bt.c1 - c0;
+        if (!slot.h_in.reserve(bt.samples * sizeof(float)) || !slot.h_out.reserve(bt.frames * b.nb * sizeof(float)))
             return fail(SONO_ENOMEM, "sono_measure_roi_calls: cannot allocate host staging memory");
-        float *packed = (float *)e->h_in.p;
-        std::vector<uint64_t> off(cnt), len(cnt), row(cnt);
+        float *packed = (float *)slot.h_in.p;
+        bt.off.resize(cnt); bt.len.resize(cnt); bt.row.resize(cnt);
         size_t pos = 0, rows = 0;
+        std::vector<CopyJob> copies(cnt);
         for (size_t i = 0; i < cnt; ++i) {
             const sono_roi_call &k = calls[c0 + i];
             const Slice &sl = slices[c0 + i];
-            off[i] = pos; len[i] = (sl.count - 1) * b.hop + N; row[i] = rows;
-            std::memcpy(packed + pos, region_audio(x, x_filtered, t, (size_t)k.roi, sample_rate) + rois[k.roi].start + sl.first * b.hop,
-                        (size_t)len[i] * sizeof(float));
-            pos += (size_t)len[i];
+            bt.off[i] = pos; bt.len[i] = (sl.count - 1) * b.hop + N; bt.row[i] = rows;
+            copies[i] = {packed + pos, region_audio(x, x_filtered, t, (size_t)k.roi, sample_rate) + rois[k.roi].start + sl.first * b.hop,
+                         (size_t)bt.len[i] * sizeof(float)};
+            pos += (size_t)bt.len[i];
             rows += (size_t)sl.count;
         }
-        timer.lap("pack samples");
-        HIP_TRY(e->d_in.reserve(samples * sizeof(float)));
-        HIP_TRY(e->d_mags.reserve(frames * bins * sizeof(float)));
-        HIP_TRY(e->d_db.reserve(frames * b.nb * sizeof(float)));
-        HIP_TRY(hipMemcpyAsync(e->d_in.p, packed, samples * sizeof(float), hipMemcpyHostToDevice, s));
-        sono_ragged_batch rb{(const float *)e->d_in.p, cnt, off.data(), len.data()};
+        parallel_copy(copies);
+        HIP_TRY(slot.d_in.reserve(bt.samples * sizeof(float)));
+        HIP_TRY(e->d_mags.reserve(bt.frames * bins * sizeof(float)));
+        HIP_TRY(slot.d_db.reserve(bt.frames * b.nb * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(slot.d_in.p, packed, bt.samples * sizeof(float), hipMemcpyHostToDevice, s));
+        sono_ragged_batch rb{(const float *)slot.d_in.p, cnt, bt.off.data(), bt.len.data()};
         int rc = sono_stft_mag_f32_ragged_dev(e, &rb, b.noverlap, (float *)e->d_mags.p, nullptr);
         if (rc) return rc;
-        rc = sono_detect_power_db_dev(e, (const float *)e->d_mags.p, frames, bins, b.min_bin, b.nb, (float *)e->d_db.p, nullptr);
+        rc = sono_detect_power_db_dev(e, (const float *)e->d_mags.p, bt.frames, bins, b.min_bin, b.nb, (float *)slot.d_db.p, nullptr);
         if (rc) return rc;
-        float *db = (float *)e->h_out.p;
-        HIP_TRY(hipMemcpyAsync(db, e->d_db.p, frames * b.nb * sizeof(float), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        timer.lap("STFT, dB, copy to host");
-        // ---- measureFrequencyParameters per call (js:786-797), calls shared out over host threads ----
+        HIP_TRY(hipMemcpyAsync(slot.h_out.p, slot.d_db.p, bt.frames * b.nb * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(slot.done, s));
+        return SONO_OK;
+    };
+    // measureFrequencyParameters per call (js:786-797), the batch's calls shared out over host threads
+    auto measure = [&](const Batch &bt, const float *db) {
+        const size_t c0 = bt.c0, cnt = bt.c1 - bt.c0;
         std::atomic<size_t> next{0};
         auto work = [&]() {
             std::vector<double> tf;
@@ -475,7 +546,7 @@ static int measure_roi_calls(sono_engine *e, const float *x, const float *x_filt
                 tf.resize(times);
                 for (size_t f = 0; f < times; ++f)
                     tf[f] = ((double)(k.start_frame + f) * (double)b.hop + (double)N / 2) / sample_rate;     // js:1350-1351
-                const sono::CallMatrix m{db + (row[i] + (size_t)slices[c0 + i].lead) * b.nb, call_frames, b.nb, freq_bins.data(),
+                const sono::CallMatrix m{db + (bt.row[i] + (size_t)slices[c0 + i].lead) * b.nb, call_frames, b.nb, freq_bins.data(),
                                          t->zonal + (size_t)k.roi * SONO_MAX_ZONES, t->num_zones, (debug_mode & SONO_DEBUG_MODE) != 0,
                                          (debug_mode & SONO_TIME_EXPANSION) != 0};
                 sono::CallMeasure cm;
@@ -502,8 +573,24 @@ static int measure_roi_calls(sono_engine *e, const float *x, const float *x_filt
         for (unsigned int w = 1; w < nt; ++w) pool.emplace_back(work);
         work();
         for (std::thread &th : pool) th.join();
+    };
+    Batch batch[2];
+    int rc = prepare(batch[0], 0, e->measure_slot[0]);
+    if (rc) return rc;
+    timer.lap("first batch queued");
+    for (unsigned int cur = 0;; cur ^= 1u) {
+        const Batch &bt = batch[cur];
+        const bool more = bt.c1 < n_calls;
+        if (more) {
+            rc = prepare(batch[cur ^ 1u], bt.c1, e->measure_slot[cur ^ 1u]);
+            if (rc) { (void)hipStreamSynchronize(s); return rc; }
+            timer.lap("next batch packed and queued");
+        }
+        HIP_TRY(hipEventSynchronize(e->measure_slot[cur].done));
+        timer.lap("wait for the batch's dB");
+        measure(bt, (const float *)e->measure_slot[cur].h_out.p);
         timer.lap("measure on host threads");
-        c0 = c1;
+        if (!more) break;
     }
     return SONO_OK;
 }

@@ -42,20 +42,29 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-// Host staging memory that grows and is kept: fresh pages cost a fault each on first touch, so the large
-// per-call staging areas of the whole-file passes are reused instead of allocated per call.
+// Host staging memory that grows and is kept between calls: fresh pages cost a fault each on first touch, so the
+// large staging areas of the whole-file passes are reused instead of allocated per call.  Pinned (hipHostMalloc): a copy between it and the device runs
+// at the link's rate, about four times that of pageable memory, and the stages that use it are copy-bound.  Falls back
+// to malloc when pinning fails (a host without a GPU never gets here: the callers need one).
 struct HostBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool pinned = false;
     bool reserve(size_t bytes)
     {
         if (bytes <= cap) return true;
-        std::free(p);
-        p = std::malloc(bytes);
+        release();
+        bytes += bytes / 8;                      // a little headroom: the next call is rarely exactly as large
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) pinned = true;
+        else { (void)hipGetLastError(); p = std::malloc(bytes); pinned = false; }
         cap = p ? bytes : 0;
         return p != nullptr;
     }
-    void release() { std::free(p); p = nullptr; cap = 0; }
+    void release()
+    {
+        if (p) { if (pinned) (void)hipHostFree(p); else std::free(p); }
+        p = nullptr; cap = 0; pinned = false;
+    }
 };
 
 struct Tables {
@@ -109,6 +118,12 @@ private:
     int prev_;
 };
 
+// hipMemcpyAsync(d_dst, h_src, bytes, host to device, s) for LARGE arrays in pageable host memory: pieces go through
+// three pinned buffers the engine keeps, copied in by several host threads while the previous piece is on the bus
+// (a plain copy from pageable memory runs at less than half the link's rate).  Returns once the last piece is queued;
+// h_src may be changed after the call returns.  Small arrays take the plain copy.
+int upload_host_array(sono_engine *e, void *d_dst, const void *h_src, size_t bytes, hipStream_t s);
+
 int stream_stft_u8(sono_engine *e, StreamPipe **pipe, const float *x, size_t frames, uint32_t noverlap, float gain_db,
                    float range_db, uint8_t *out, uint16_t *peak_bin, float *peak_mag, uint32_t *gmax_bits);
 
@@ -127,6 +142,31 @@ struct sono_engine {
     // device scratch of the detector front end (sono_capi_detect.hip)
     sono::DevBuf d_db, d_flags, d_edges, d_runs, d_count, d_select_tmp;
     sono::HostBuf h_in, h_out;              // staging of the whole-file passes (packed samples; records / dB matrices)
+    // The measurement stage's two slots: one batch is measured on host threads while the next is on the GPU.
+    struct MeasureSlot {
+        sono::HostBuf h_in, h_out;          // packed samples of the batch's calls; their dB matrices
+        sono::DevBuf d_in, d_db;
+        hipEvent_t done = nullptr;          // recorded behind the copy of the dB matrices to h_out
+        void release()
+        {
+            h_in.release(); h_out.release(); d_in.release(); d_db.release();
+            if (done) { (void)hipEventDestroy(done); done = nullptr; }
+        }
+    };
+    MeasureSlot measure_slot[2];
+    // pinned pieces of upload_host_array, each guarded by an event recorded behind its copy to the device
+    struct UploadSlot {
+        sono::HostBuf buf;
+        hipEvent_t done = nullptr;
+        bool used = false;
+        void release()
+        {
+            buf.release();
+            if (done) { (void)hipEventDestroy(done); done = nullptr; }
+            used = false;
+        }
+    };
+    UploadSlot upload_slot[3];
     // Tables of ragged-batch launches.  A launch returns before its kernel has run, so its tables must stay
     // untouched until then: two slots are used in turn, each guarded by an event recorded behind its kernel.
     struct RaggedSlot {

@@ -99,6 +99,12 @@ private:
 
 }  // namespace
 
+bool no_pinned_upload()
+{
+    const char *v = std::getenv("SONO_NO_PINNED_UPLOAD");
+    return v && *v && *v != '0';
+}
+
 struct StreamPipe {
     struct Slot {
         float *h_in = nullptr, *d_in = nullptr;
@@ -166,6 +172,32 @@ struct StreamPipe {
 };
 
 void stream_pipe_destroy(StreamPipe *p) { delete p; }
+
+int upload_host_array(sono_engine *e, void *d_dst, const void *h_src, size_t bytes, hipStream_t s)
+{
+    constexpr size_t kPiece = (size_t)64 << 20;
+    if (bytes < 2 * kPiece || no_pinned_upload()) {
+        HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s));
+        if (bytes >= 2 * kPiece) HIP_TRY(hipStreamSynchronize(s));
+        return SONO_OK;
+    }
+    unsigned int threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (const char *v = std::getenv("SONO_COPY_THREADS")) threads = (unsigned int)std::max(1, atoi(v));
+    CopyPool pool(threads);
+    size_t piece = 0;
+    for (size_t off = 0; off < bytes; off += kPiece, ++piece) {
+        sono_engine::UploadSlot &slot = e->upload_slot[piece % 3];
+        if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+        if (slot.used) HIP_TRY(hipEventSynchronize(slot.done));          // its last piece has left the buffer
+        if (!slot.buf.reserve(kPiece)) return fail(SONO_ENOMEM, "upload_host_array: cannot allocate pinned staging memory");
+        const size_t count = std::min(kPiece, bytes - off);
+        pool.copy(slot.buf.p, (const char *)h_src + off, count);
+        HIP_TRY(hipMemcpyAsync((char *)d_dst + off, slot.buf.p, count, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(slot.done, s));
+        slot.used = true;
+    }
+    return SONO_OK;
+}
 
 // Frames per chunk at this hop: a multiple of 16, about kChunkInputBytes of samples.
 size_t stream_chunk_frames(uint32_t hop)

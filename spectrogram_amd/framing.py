@@ -367,14 +367,8 @@ _CALL_TYPES = ("CF", "FM", "CF-FM")
 _QUALITIES = ("Very Poor", "Poor", "Normal", "Good", "Excellent")
 
 
-def process_full_file_native(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options=None, config=None, threads=0,
-                             keep_spectrograms=False):
-    """processFullFile (batCallDetector.js:584-840) as ONE library call (sono_process_full_file): same calls, order and
-    values as process_full_file_batched(..., measure=True), without the per-region tables (zonalNoiseMap).  Raises
-    measure.ReferenceThrows where the reference's promise rejects (config['debugMode'] False and a call on which the
-    reference raises outside its debug mode).  keep_spectrograms=True adds what the reference leaves on every BatCall
-    beside the numbers (js:785-787): 'spectrogram' (the call's rows of its region's dB matrix), 'timeFrames' (their centre
-    times from the region's start, and one more) and 'freqBins' (Hz)."""
+def _full_file_call_array(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options, config, threads, keep_spectrograms):
+    """sono_process_full_file -> (ctypes array of sono_full_file_call, number of calls)."""
     from . import FullFileCall as _Call, FullFileOptions as _Opt, SonoError, measure as _ms
     opt = dict({"threshold_dB": -60, "padding_ms": 5}, **(options or {}))
     cfg = dict(DEFAULT_FRAMING_CONFIG, **(config or {}))
@@ -396,8 +390,51 @@ def process_full_file_native(engine, full_audio_data, sample_rate, flow_khz, fhi
         cap = got.value
         out = (_Call * cap)()
         _check(lib().sono_full_file_results(engine._handle(), out, cap, C.byref(got)))
+    return out, got.value
+
+
+# sharding.COLUMNS -> field of sono_full_file_call ("m." = inside its sono_call_measurement)
+_TABLE_FIELDS = {"startTime_s": "m.start_time_s", "endTime_s": "m.end_time_s", "duration_ms": "m.duration_ms",
+                 "bandwidth_kHz": "m.bandwidth_khz", "startFreq_kHz": "m.start_freq_khz", "startFreq_ms": "m.start_freq_ms",
+                 "endFreq_kHz": "m.end_freq_khz", "endFreq_ms": "m.end_freq_ms", "highFreq_kHz": "m.high_freq_khz",
+                 "highFreq_ms": "m.high_freq_ms", "lowFreq_kHz": "m.low_freq_khz", "lowFreq_ms": "m.low_freq_ms",
+                 "peakFreq_kHz": "m.peak_freq_khz", "peakFreq_ms": "m.peak_freq_ms",
+                 "characteristicFreq_kHz": "m.characteristic_freq_khz", "characteristicFreq_ms": "m.characteristic_freq_ms",
+                 "kneeFreq_kHz": "m.knee_freq_khz", "kneeFreq_ms": "m.knee_freq_ms", "heelFreq_kHz": "m.heel_freq_khz",
+                 "heelFreq_ms": "m.heel_freq_ms", "peakPower_dB": "m.peak_power_db", "snr_dB": "snr_db"}
+
+
+def process_full_file_table(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options=None, config=None, threads=0,
+                            file_id=0, channel=0):
+    """process_full_file_native straight into the call-summary table's rows (sharding.COLUMNS order, float64, NaN where
+    the reference leaves null): equal to sharding.calls_to_rows(process_full_file_native(...), file_id, channel) without
+    a Python object per call -- what a survey over many recordings wants."""
+    from . import FullFileCall as _Call, sharding as _sh
+    out, count = _full_file_call_array(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options, config, threads, False)
+    rows = np.full((count, len(_sh.COLUMNS)), np.nan, np.float64)
+    if count == 0:
+        return rows
+    rec = np.frombuffer(out, dtype=np.dtype(_Call), count=count)
+    rows[:, 0], rows[:, 1] = file_id, channel
+    for j, name in enumerate(_sh.COLUMNS[2:], start=2):
+        field = _TABLE_FIELDS[name]
+        rows[:, j] = rec["m"][field[2:]] if field.startswith("m.") else rec[field]
+    return rows
+
+
+def process_full_file_native(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options=None, config=None, threads=0,
+                             keep_spectrograms=False):
+    """processFullFile (batCallDetector.js:584-840) as ONE library call (sono_process_full_file): same calls, order and
+    values as process_full_file_batched(..., measure=True), without the per-region tables (zonalNoiseMap).  Raises
+    measure.ReferenceThrows where the reference's promise rejects (config['debugMode'] False and a call on which the
+    reference raises outside its debug mode).  keep_spectrograms=True adds what the reference leaves on every BatCall
+    beside the numbers (js:785-787): 'spectrogram' (the call's rows of its region's dB matrix), 'timeFrames' (their centre
+    times from the region's start, and one more) and 'freqBins' (Hz)."""
+    from . import measure as _ms
+    out, count = _full_file_call_array(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options, config, threads,
+                                       keep_spectrograms)
     calls = []
-    for i in range(got.value):
+    for i in range(count):
         k, m = out[i], out[i].m
         call = {name: (None if v != v else v) for name, v in ((nm, getattr(m, f)) for nm, (f, _) in zip(_ms.CALL_FIELDS, type(m)._fields_))}
         call.update({name: (None if getattr(m, f) < 0 else int(getattr(m, f))) for name, f in zip(_ms._FRAME_FIELDS, type(m)._frames)})

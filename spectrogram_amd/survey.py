@@ -38,12 +38,10 @@ def detect_units(units, sample_rate, flow_khz=10.0, fhigh_khz=128.0, options=Non
         for i in sharding.files_of_rank(len(units), rank, world):
             file_id, channel, unit = units[i]
             try:
-                calls = framing.process_full_file_native(e, _samples(unit), sample_rate, flow_khz, fhigh_khz, options, config,
-                                                         threads=threads)
+                rows.append(framing.process_full_file_table(e, _samples(unit), sample_rate, flow_khz, fhigh_khz, options, config,
+                                                            threads=threads, file_id=file_id, channel=channel))
             except _ms.ReferenceThrows:
                 rejected.append((file_id, channel))
-                continue
-            rows.append(sharding.calls_to_rows(calls, file_id, channel))
     finally:
         if own:
             e.free()

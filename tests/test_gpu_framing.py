@@ -219,6 +219,9 @@ def test_full_file_with_the_measurement_stage(golden):
     assert len(native) == len(batched)
     for a, b in zip(native, batched):
         assert a == {k: v for k, v in b.items() if k != "zonalNoiseMap"}
+    # ... and straight into the call-summary table's rows
+    table = fr.process_full_file_table(*args, dict(cfg, debugMode=True), file_id=1)
+    assert np.array_equal(table, rows, equal_nan=True)
     # call.spectrogram / timeFrames / freqBins (js:785-787): the native run's re-transform of every call's frames
     # against the rows of the region's own matrix that the region-by-region form measured
     with_rows = fr.process_full_file_native(*args, dict(cfg, debugMode=True), keep_spectrograms=True)
