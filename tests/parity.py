@@ -84,6 +84,22 @@ def run_stft_case(engine, g, c):
         assert pk.dtype == np.uint16 and pm.dtype == np.float32
         if n not in ARGMAX_ILL_CONDITIONED:
             assert np.array_equal(pk, rpk), f"{n}: peak bins differ at ratio {r}"
+        else:
+            # Hundreds of bins tie for the maximum in the reference's own magnitudes here, and it reports the first of
+            # them (lib.rs:370-378).  Which of the tied bins comes out on top in ANOTHER FFT is rounding noise, so the
+            # rule is checked as far as it can be: frames in which every bin ties exactly (silence: all magnitudes 0)
+            # must give the first bin like the reference, the kept / dropped pattern (0xFFFF) must be the reference's,
+            # and any other reported bin must be one of the reference's near-maximal bins -- and the first maximum of
+            # this engine's own magnitude row.
+            rmag, own = g[n + "/mag"].reshape(-1, B), mag.reshape(-1, B)
+            assert np.array_equal(pk == 0xFFFF, rpk == 0xFFFF), f"{n}: kept / dropped frames differ at ratio {r}"
+            for f in np.flatnonzero(pk != 0xFFFF):
+                if rmag[f].max() == rmag[f].min():
+                    assert pk[f] == rpk[f] == 0, f"{n}: frame {f}: all bins tie, the first one is the peak"
+                    continue
+                assert rmag[f, pk[f]] >= rmag[f].max() * (1 - MAG_RTOL), f"{n}: frame {f}: bin {pk[f]} is not a near-maximal bin of the reference"
+                first = int(np.argmax(own[f]))
+                assert pk[f] == first or own[f, pk[f]] >= own[f, first] * (1 - 1e-6), f"{n}: frame {f}: bin {pk[f]} vs own first maximum {first}"
         if rpm.size:
             assert np.all(np.abs(pm - rpm) <= 1e-6 * max(gmax_ref, 1e-30) + 1e-6 * np.abs(rpm)), \
                 f"{n}: peak magnitudes differ at ratio {r}"

@@ -95,6 +95,26 @@ def test_against_oracle(kernel_path, N, V):
     e.free()
 
 
+@pytest.mark.parametrize("N,V", [(256, 192), (1024, 768), (2048, 1536), (4096, 3891)])
+@pytest.mark.parametrize("window,alpha", [("bartlett", None), ("bartlettHann", None), ("blackman", None), ("blackman", 0.05),
+                                          ("cosine", None), ("gauss", None), ("gauss", 0.4), ("hamming", None),
+                                          ("rectangular", None), ("triangular", None), ("no such window", None)])
+def test_every_window_at_every_size_against_oracle(N, V, window, alpha):
+    """The ten windows of lib.rs:698-776 (and the fallback to Hann for an unknown name) at the small, the headline and
+    both wide sizes: the window tables are bit-identical to the reference's (test_windows_bit_exact), here the whole
+    transform runs with each of them against the C oracle, which the golden vectors pin."""
+    H = N - V
+    x = signal(N + 21 * H + 5, N + len(window), amp=0.5)
+    o = so.OracleEngine(N, window, alpha)
+    e = sa.SpectrogramEngine(N, window, alpha)
+    assert np.array_equal(e.get_window_values().view(np.uint32), np.asarray(o.get_window_values()).view(np.uint32))
+    parity.check_mag(e.compute_spectrogram(x, V), o.compute_spectrogram(x, V), N // 2, f"{window} N={N}")
+    nd, nt = parity.u8_diff(e.compute_spectrogram_u8(x, V, 20.0, 80.0), o.compute_spectrogram_u8(x, V, 20.0, 80.0), f"{window} N={N}")
+    assert nd <= max(2, parity.U8_MAX_FRACTION * nt)
+    assert np.array_equal(e.get_peaks(0.0), o.get_peaks(0.0))
+    e.free()
+
+
 def test_empty_inputs_and_errors(kernel_path):
     e = sa.SpectrogramEngine(1024, "hann")
     assert len(e.get_peaks(0.4)) == 0 and len(e.get_peak_magnitudes(0.0)) == 0      # before any u8 call
