@@ -143,7 +143,7 @@ void sono_engine_destroy(sono_engine *e)
     if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
     e->tables.release();
     e->d_in.release(); e->d_out.release(); e->d_peak_bin.release(); e->d_peak_mag.release();
-    e->d_gmax.release(); e->d_mags.release(); e->d_bank.release();
+    e->d_gmax.release(); e->d_mags.release(); e->d_bank.release(); e->d_rec.release();
     e->d_db.release(); e->d_flags.release(); e->d_edges.release(); e->d_runs.release();
     e->d_count.release(); e->d_select_tmp.release();
     e->h_in.release(); e->h_out.release();
@@ -197,7 +197,7 @@ int sono_engine_release_memory(sono_engine *e)
     e->color_map.clear();
     e->has_last = false; e->last_peak_bin.clear(); e->last_peak_mag.clear(); e->last_gmax = 0.0f;
     e->d_in.release(); e->d_out.release(); e->d_peak_bin.release(); e->d_peak_mag.release();
-    e->d_mags.release(); e->d_bank.release();
+    e->d_mags.release(); e->d_bank.release(); e->d_rec.release();
     e->d_db.release(); e->d_flags.release(); e->d_edges.release(); e->d_runs.release(); e->d_select_tmp.release();
     e->h_in.release(); e->h_out.release(); e->full_file_calls.clear(); e->full_file_calls.shrink_to_fit();
     for (auto &slot : e->measure_slot) slot.release();

@@ -139,6 +139,24 @@ int sono_fast_scan_segments(sono_engine *e, const float *x, size_t n, double sam
 {
     if (count) *count = 0;
     if (!e || (!x && n)) return fail(SONO_EINVAL, "sono_fast_scan_segments: NULL argument");
+    const uint32_t N = e->N, hop = N / 2, noverlap = N - hop;                    // js:882-886
+    const size_t F = sono_frames_for(n, N, noverlap);
+    if (F == 0) return SONO_OK;
+    DeviceGuard guard(e->device);
+    const size_t used = (F - 1) * (size_t)hop + N;
+    HIP_TRY(e->d_in.reserve(used * sizeof(float)));
+    const int rc = sono::upload_host_array(e, e->d_in.p, x, used * sizeof(float), e->stream);
+    if (rc) return rc;
+    return sono::fast_scan_resident(e, (const float *)e->d_in.p, n, sample_rate, flow_khz, fhigh_khz, threshold_db, out, cap, count);
+}
+
+}  // extern "C"
+
+// fastScanSegmentsWasm (batCallDetector.js:878-949) on a recording that already lies in HBM at d_x (n samples).
+int sono::fast_scan_resident(sono_engine *e, const float *d_x, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
+                             double threshold_db, sono_segment *out, size_t cap, size_t *count)
+{
+    if (count) *count = 0;
     const uint32_t N = e->N, hop = N / 2, noverlap = N - hop, bins = N / 2;      // js:882-886
     const double freq_res = sample_rate / (double)N;                             // js:889
     const double lo = std::floor(flow_khz * 1000.0 / freq_res), hi = std::ceil(fhigh_khz * 1000.0 / freq_res);
@@ -150,11 +168,9 @@ int sono_fast_scan_segments(sono_engine *e, const float *x, size_t n, double sam
     const double target = std::pow(10.0, threshold_db / 10.0) * (double)N * 0.25;   // js:906-909
     DeviceGuard guard(e->device);
     const size_t used = (F - 1) * (size_t)hop + N;
-    HIP_TRY(e->d_in.reserve(used * sizeof(float)));
-    int rc = sono::upload_host_array(e, e->d_in.p, x, used * sizeof(float), e->stream);
-    if (rc) return rc;
     HIP_TRY(e->d_flags.reserve(F));
-    sono_batch b{(const float *)e->d_in.p, 1, used, used};
+    sono_batch b{d_x, 1, used, used};
+    int rc;
     if (max_bin < bins) {
         // the usual case: one fused launch, the magnitudes never leave the chip
         rc = sono_stft_band_active_dev(e, &b, noverlap, min_bin, max_bin, target, (uint8_t *)e->d_flags.p, nullptr, nullptr);
@@ -179,6 +195,8 @@ int sono_fast_scan_segments(sono_engine *e, const float *x, size_t n, double sam
     if (count) *count = first.size();
     return SONO_OK;
 }
+
+extern "C" {
 
 int sono_generate_spectrogram(sono_engine *e, const float *x, size_t n, double sample_rate, double flow_khz,
                               double fhigh_khz, double hop_percent, float *out, size_t cap, size_t *frames,

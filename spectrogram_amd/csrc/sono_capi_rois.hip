@@ -154,9 +154,15 @@ int sono_roi_rows(const sono_segment *rois, size_t n_rois, uint32_t fft_size, do
     return SONO_OK;
 }
 
-int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segment *rois, size_t n_rois, double sample_rate,
-                      double flow_khz, double fhigh_khz, double hop_percent, int auto_highpass, sono_roi_table *out,
-                      size_t frames_cap, float *x_filtered)
+}  // extern "C"
+
+// sono_analyze_rois.  d_rec: the whole recording in HBM (sono_process_full_file keeps it there from the fast scan on), or
+// nullptr.  With it the regions are transformed where they lie -- nothing is packed or uploaded -- and the automatic
+// high-pass ALSO replaces the samples of the regions it filters in d_rec, so that whatever reads a region there
+// afterwards gets what region_audio() would pick on the host.
+static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segment *rois, size_t n_rois, double sample_rate,
+                        double flow_khz, double fhigh_khz, double hop_percent, int auto_highpass, sono_roi_table *out,
+                        size_t frames_cap, float *x_filtered, float *d_rec)
 {
     if (!e || !out || (n && !x) || (n_rois && !rois)) return fail(SONO_EINVAL, "sono_analyze_rois: NULL argument");
     if (!(sample_rate > 0)) return fail(SONO_EINVAL, "sono_analyze_rois: sample_rate must be positive");
@@ -208,9 +214,12 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
     // region however many regions run beside it --, and the second pass goes through the filtered regions in batches.
     size_t total_samples = 0;
     std::vector<uint64_t> src_off(n_rois);
-    for (size_t r = 0; r < n_rois; ++r) { src_off[r] = total_samples; total_samples += (size_t)(rois[r].end - rois[r].start); }
-    HIP_TRY(e->d_in.reserve((total_samples ? total_samples : 1) * sizeof(float)));
-    float *d_all = (float *)e->d_in.p;
+    for (size_t r = 0; r < n_rois; ++r) {
+        src_off[r] = d_rec ? rois[r].start : total_samples;
+        total_samples += (size_t)(rois[r].end - rois[r].start);
+    }
+    if (!d_rec) HIP_TRY(e->d_in.reserve((total_samples ? total_samples : 1) * sizeof(float)));
+    float *d_all = d_rec ? d_rec : (float *)e->d_in.p;
     std::vector<sono::HighpassJob> jobs;                     // every region that gets the high-pass
     std::vector<size_t> job_region;
     size_t filtered_samples = 0;
@@ -224,22 +233,26 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
             ++r1;
         }
         const size_t cnt = r1 - r0;
-        // pack the batch's samples and upload them in one copy
-        if (!e->h_in.reserve((samples ? samples : 1) * sizeof(float)))
-            return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
-        float *packed = (float *)e->h_in.p;
         std::vector<uint64_t> off(cnt), len(cnt), rows(cnt), first_row(cnt);
-        size_t pos = 0;
-        std::vector<CopyJob> copies(cnt);
         for (size_t i = 0; i < cnt; ++i) {
             const sono_segment &g = rois[r0 + i];
             off[i] = src_off[r0 + i]; len[i] = g.end - g.start; rows[i] = out->row0[r0 + i];
-            copies[i] = {packed + pos, x + g.start, (size_t)len[i] * sizeof(float)};
-            pos += (size_t)len[i];
         }
-        parallel_copy(copies);
-        timer.lap("pack samples");
-        HIP_TRY(hipMemcpyAsync(d_all + src_off[r0], packed, samples * sizeof(float), hipMemcpyHostToDevice, s));
+        if (!d_rec) {
+            // pack the batch's samples and upload them in one copy
+            if (!e->h_in.reserve((samples ? samples : 1) * sizeof(float)))
+                return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
+            float *packed = (float *)e->h_in.p;
+            size_t pos = 0;
+            std::vector<CopyJob> copies(cnt);
+            for (size_t i = 0; i < cnt; ++i) {
+                copies[i] = {packed + pos, x + rois[r0 + i].start, (size_t)len[i] * sizeof(float)};
+                pos += (size_t)len[i];
+            }
+            parallel_copy(copies);
+            timer.lap("pack samples");
+            HIP_TRY(hipMemcpyAsync(d_all + src_off[r0], packed, samples * sizeof(float), hipMemcpyHostToDevice, s));
+        }
         if (frames == 0) {
             HIP_TRY(hipStreamSynchronize(s));                // the staging area is reused by the next batch
             for (size_t r = r0; r < r1; ++r) for (size_t z = 0; z < SONO_MAX_ZONES; ++z) out->zonal[r * SONO_MAX_ZONES + z] = -102.0;
@@ -304,7 +317,7 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
     sono::HighpassCoef *d_coefs = (sono::HighpassCoef *)((char *)e->d_flags.p + jb);
     HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jb, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_coefs, coefs, sizeof(coefs), hipMemcpyHostToDevice, s));
-    HIP_TRY(sono::launch_highpass_regions(d_all, (float *)e->d_runs.p, d_jobs, jobs.size(), d_coefs, s));
+    HIP_TRY(sono::launch_highpass_regions(d_all, (float *)e->d_runs.p, d_jobs, jobs.size(), d_coefs, d_rec != nullptr, s));
     if (x_filtered) {
         // back to the host in pieces of whole regions through the pinned staging area, then to their places
         const size_t piece = (size_t)16 << 20;               // samples per piece (a region longer than that goes alone)
@@ -343,6 +356,16 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
     }
     timer.lap("second pass");
     return SONO_OK;
+}
+
+extern "C" {
+
+int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segment *rois, size_t n_rois, double sample_rate,
+                      double flow_khz, double fhigh_khz, double hop_percent, int auto_highpass, sono_roi_table *out,
+                      size_t frames_cap, float *x_filtered)
+{
+    return analyze_rois(e, x, n, rois, n_rois, sample_rate, flow_khz, fhigh_khz, hop_percent, auto_highpass, out, frames_cap,
+                        x_filtered, nullptr);
 }
 
 
@@ -449,10 +472,12 @@ int sono_frame_roi_calls(const float *x, const float *x_filtered, size_t n, cons
 
 // sono_measure_roi_calls; `keep` (or nullptr) receives, for every call that processFullFile goes on to keep (not
 // discarded, longer than 1 ms: js:802-810), the call's own rows of the dB matrix and the number of its centre times.
+// d_rec (or nullptr): the recording in HBM with the filtered regions already in place (analyze_rois): the calls' frames
+// are then transformed where they lie instead of being packed on the host and uploaded.
 static int measure_roi_calls(sono_engine *e, const float *x, const float *x_filtered, size_t n, const sono_segment *rois, size_t n_rois,
                              const sono_roi_table *t, const sono_roi_call *calls, size_t n_calls, double sample_rate, double flow_khz,
                              double fhigh_khz, double hop_percent, int debug_mode, unsigned int threads, sono_call_measurement *out,
-                             std::vector<sono::FullFileSlice> *keep)
+                             std::vector<sono::FullFileSlice> *keep, const float *d_rec)
 {
     if (!e || !t || (n && !x) || (n_rois && (!rois || !t->row0 || !t->zonal)) || (n_calls && (!calls || !out)))
         return fail(SONO_EINVAL, "sono_measure_roi_calls: NULL argument");
@@ -503,27 +528,33 @@ static int measure_roi_calls(sono_engine *e, const float *x, const float *x_filt
             ++bt.c1;
         }
         const size_t cnt = bt.c1 - c0;
-        if (!slot.h_in.reserve(bt.samples * sizeof(float)) || !slot.h_out.reserve(bt.frames * b.nb * sizeof(float)))
+        if (!slot.h_out.reserve(bt.frames * b.nb * sizeof(float)) || (!d_rec && !slot.h_in.reserve(bt.samples * sizeof(float))))
             return fail(SONO_ENOMEM, "sono_measure_roi_calls: cannot allocate host staging memory");
-        float *packed = (float *)slot.h_in.p;
         bt.off.resize(cnt); bt.len.resize(cnt); bt.row.resize(cnt);
         size_t pos = 0, rows = 0;
-        std::vector<CopyJob> copies(cnt);
+        std::vector<CopyJob> copies(d_rec ? 0 : cnt);
         for (size_t i = 0; i < cnt; ++i) {
             const sono_roi_call &k = calls[c0 + i];
             const Slice &sl = slices[c0 + i];
-            bt.off[i] = pos; bt.len[i] = (sl.count - 1) * b.hop + N; bt.row[i] = rows;
-            copies[i] = {packed + pos, region_audio(x, x_filtered, t, (size_t)k.roi, sample_rate) + rois[k.roi].start + sl.first * b.hop,
-                         (size_t)bt.len[i] * sizeof(float)};
+            bt.len[i] = (sl.count - 1) * b.hop + N; bt.row[i] = rows;
+            if (d_rec) bt.off[i] = rois[k.roi].start + sl.first * b.hop;
+            else {
+                bt.off[i] = pos;
+                copies[i] = {(float *)slot.h_in.p + pos,
+                             region_audio(x, x_filtered, t, (size_t)k.roi, sample_rate) + rois[k.roi].start + sl.first * b.hop,
+                             (size_t)bt.len[i] * sizeof(float)};
+            }
             pos += (size_t)bt.len[i];
             rows += (size_t)sl.count;
         }
-        parallel_copy(copies);
-        HIP_TRY(slot.d_in.reserve(bt.samples * sizeof(float)));
         HIP_TRY(e->d_mags.reserve(bt.frames * bins * sizeof(float)));
         HIP_TRY(slot.d_db.reserve(bt.frames * b.nb * sizeof(float)));
-        HIP_TRY(hipMemcpyAsync(slot.d_in.p, packed, bt.samples * sizeof(float), hipMemcpyHostToDevice, s));
-        sono_ragged_batch rb{(const float *)slot.d_in.p, cnt, bt.off.data(), bt.len.data()};
+        if (!d_rec) {
+            parallel_copy(copies);
+            HIP_TRY(slot.d_in.reserve(bt.samples * sizeof(float)));
+            HIP_TRY(hipMemcpyAsync(slot.d_in.p, slot.h_in.p, bt.samples * sizeof(float), hipMemcpyHostToDevice, s));
+        }
+        sono_ragged_batch rb{d_rec ? d_rec : (const float *)slot.d_in.p, cnt, bt.off.data(), bt.len.data()};
         int rc = sono_stft_mag_f32_ragged_dev(e, &rb, b.noverlap, (float *)e->d_mags.p, nullptr);
         if (rc) return rc;
         rc = sono_detect_power_db_dev(e, (const float *)e->d_mags.p, bt.frames, bins, b.min_bin, b.nb, (float *)slot.d_db.p, nullptr);
@@ -600,7 +631,7 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filter
                            double hop_percent, int debug_mode, unsigned int threads, sono_call_measurement *out)
 {
     return measure_roi_calls(e, x, x_filtered, n, rois, n_rois, t, calls, n_calls, sample_rate, flow_khz, fhigh_khz, hop_percent,
-                             debug_mode, threads, out, nullptr);
+                             debug_mode, threads, out, nullptr, nullptr);
 }
 
 int sono_process_full_file(sono_engine *e, const float *x, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
@@ -615,11 +646,20 @@ int sono_process_full_file(sono_engine *e, const float *x, size_t n, double samp
     StageTimer timer("sono_process_full_file");
     auto lap = [&](const char *what) { timer.lap(what); };
     // fast scan -> merge & pad (batCallDetector.js:594-601)
+    // The recording goes to HBM once and stays there: the fast scan, the regions' and the calls' transforms all read it
+    // where it lies (sono_fast_scan_segments, sono_analyze_rois and sono_measure_roi_calls, called one by one, each
+    // upload what they need).
     std::vector<sono_segment> raw(n / std::max<size_t>(N / 2, 1) + 2);
     size_t n_raw = 0;
-    int rc = sono_fast_scan_segments(e, x, n, sample_rate, flow_khz, fhigh_khz, opt->threshold_db, raw.data(), raw.size(), &n_raw);
+    if (n < N) return SONO_OK;                                                      // no frame, no segment (js:595-598)
+    DeviceGuard guard(e->device);
+    HIP_TRY(e->d_rec.reserve(n * sizeof(float)));
+    float *d_rec = (float *)e->d_rec.p;
+    int rc = sono::upload_host_array(e, d_rec, x, n * sizeof(float), e->stream);
     if (rc) return rc;
-    lap("fast scan");
+    rc = sono::fast_scan_resident(e, d_rec, n, sample_rate, flow_khz, fhigh_khz, opt->threshold_db, raw.data(), raw.size(), &n_raw);
+    if (rc) return rc;
+    lap("upload, fast scan");
     if (n_raw == 0) return SONO_OK;                                                 // js:595-598
     std::vector<sono_segment> rois(n_raw);
     size_t n_rois = 0;
@@ -641,7 +681,7 @@ int sono_process_full_file(sono_engine *e, const float *x, size_t n, double samp
     float *xf = xf_own.get();
     if (!xf) return fail(SONO_ENOMEM, "sono_process_full_file: cannot allocate the filtered recording");
     lap("merge, tables");
-    rc = sono_analyze_rois(e, x, n, rois.data(), n_rois, sample_rate, flow_khz, fhigh_khz, opt->hop_percent, 1, &t, total, xf);
+    rc = analyze_rois(e, x, n, rois.data(), n_rois, sample_rate, flow_khz, fhigh_khz, opt->hop_percent, 1, &t, total, xf, d_rec);
     if (rc) return rc;
     lap("region analysis (GPU)");
     // framing (js:677-794), measurement (js:797) and what follows it (js:802-827)
@@ -655,7 +695,7 @@ int sono_process_full_file(sono_engine *e, const float *x, size_t n, double samp
     const bool keep_slices = (opt->debug_mode & SONO_KEEP_CALL_SPECTROGRAMS) != 0;
     std::vector<sono::FullFileSlice> slices(keep_slices ? n_calls : 0);
     rc = measure_roi_calls(e, x, xf, n, rois.data(), n_rois, &t, framed.data(), n_calls, sample_rate, flow_khz, fhigh_khz,
-                           opt->hop_percent, opt->debug_mode, opt->threads, meas.data(), keep_slices ? &slices : nullptr);
+                           opt->hop_percent, opt->debug_mode, opt->threads, meas.data(), keep_slices ? &slices : nullptr, d_rec);
     if (rc) return rc;
     e->full_file_axes = {t.hop, t.min_bin, t.num_bins, sample_rate};
     lap("measurement (GPU + threads)");

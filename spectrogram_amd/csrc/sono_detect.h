@@ -73,8 +73,9 @@ struct HighpassJob {
     unsigned long long src, dst, len;   // sample offsets into d_src / d_dst, number of samples
     unsigned int coef, pad;             // index into the coefficient table
 };
+// in_place: the filtered samples also overwrite the regions' own samples in d_src (disjoint regions only).
 hipError_t launch_highpass_regions(const float *d_src, float *d_dst, const HighpassJob *d_jobs, size_t jobs,
-                                   const HighpassCoef *d_coefs, hipStream_t s);
+                                   const HighpassCoef *d_coefs, bool in_place, hipStream_t s);
 
 // calculateRMSbasedSNR's matrix passes (batCallDetector.js:436-538).  Box = rows t0..t1 (inclusive) x bins with
 // d_bin_in_box[b] != 0.  Pass 1: largest / smallest dB value inside the box, as detect_key()s in d_keys[0..1]

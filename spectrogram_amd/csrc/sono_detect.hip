@@ -348,8 +348,10 @@ __global__ __launch_bounds__(kThreads) void zone_floors_regions_kernel(const flo
     }
 }
 
+// in_place != 0: the filtered samples also replace the region's own samples in src (regions are disjoint, and a
+// sample is read before it is written).
 __global__ __launch_bounds__(64) void highpass_regions_kernel(const float *src, float *dst, const HighpassJob *jobs,
-                                                              size_t n_jobs, const HighpassCoef *coefs)
+                                                              size_t n_jobs, const HighpassCoef *coefs, int in_place)
 {
     const size_t k = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (k >= n_jobs) return;
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(64) void highpass_regions_kernel(const float *src, 
     const HighpassCoef c = coefs[job.coef];
     const float *x = src + job.src;
     float *y = dst + job.dst;
+    float *z = in_place ? const_cast<float *>(src) + job.src : nullptr;
     double ax1 = 0, ax2 = 0, ay1 = 0, ay2 = 0;      // first section
     double bx1 = 0, bx2 = 0, by1 = 0, by2 = 0;      // second section
     for (unsigned long long i = 0; i < job.len; ++i) {
@@ -374,6 +377,7 @@ __global__ __launch_bounds__(64) void highpass_regions_kernel(const float *src, 
         s2 = __dsub_rn(s2, __dmul_rn(c.a2, by2));
         bx2 = bx1; bx1 = m; by2 = by1; by1 = s2;
         y[i] = (float)s2;
+        if (z) z[i] = (float)s2;
     }
 }
 
@@ -426,11 +430,11 @@ hipError_t launch_band_linear_sum(const float *d_db, size_t frames, uint32_t nb,
 }
 
 hipError_t launch_highpass_regions(const float *d_src, float *d_dst, const HighpassJob *d_jobs, size_t jobs,
-                                   const HighpassCoef *d_coefs, hipStream_t s)
+                                   const HighpassCoef *d_coefs, bool in_place, hipStream_t s)
 {
     if (jobs == 0) return hipSuccess;
     hipLaunchKernelGGL(highpass_regions_kernel, dim3((unsigned int)((jobs + 63) / 64)), dim3(64), 0, s, d_src, d_dst, d_jobs,
-                       jobs, d_coefs);
+                       jobs, d_coefs, in_place ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -124,6 +124,10 @@ private:
 // h_src may be changed after the call returns.  Small arrays take the plain copy.
 int upload_host_array(sono_engine *e, void *d_dst, const void *h_src, size_t bytes, hipStream_t s);
 
+// fastScanSegmentsWasm (batCallDetector.js:878-949) on a recording that already lies in HBM (sono_capi_detect.hip).
+int fast_scan_resident(sono_engine *e, const float *d_x, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
+                       double threshold_db, sono_segment *out, size_t cap, size_t *count);
+
 int stream_stft_u8(sono_engine *e, StreamPipe **pipe, const float *x, size_t frames, uint32_t noverlap, float gain_db,
                    float range_db, uint8_t *out, uint16_t *peak_bin, float *peak_mag, uint32_t *gmax_bits);
 
@@ -141,6 +145,7 @@ struct sono_engine {
     sono::DevBuf d_in, d_out, d_peak_bin, d_peak_mag, d_gmax, d_mags, d_bank;
     // device scratch of the detector front end (sono_capi_detect.hip)
     sono::DevBuf d_db, d_flags, d_edges, d_runs, d_count, d_select_tmp;
+    sono::DevBuf d_rec;                     // sono_process_full_file: the whole recording, resident from the fast scan on
     sono::HostBuf h_in, h_out;              // staging of the whole-file passes (packed samples; records / dB matrices)
     // The measurement stage's two slots: one batch is measured on host threads while the next is on the GPU.
     struct MeasureSlot {
