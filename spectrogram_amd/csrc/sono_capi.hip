@@ -149,6 +149,7 @@ void sono_engine_destroy(sono_engine *e)
     e->h_in.release(); e->h_out.release();
     for (auto &slot : e->measure_slot) slot.release();
     for (auto &slot : e->upload_slot) slot.release();
+    std::free(e->filtered); e->filtered = nullptr; e->filtered_cap = 0;
     for (auto &slot : e->ragged) {
         if (slot.done) { (void)hipEventSynchronize(slot.done); (void)hipEventDestroy(slot.done); }
         slot.buf.release();
@@ -201,6 +202,9 @@ int sono_engine_release_memory(sono_engine *e)
     e->d_db.release(); e->d_flags.release(); e->d_edges.release(); e->d_runs.release(); e->d_select_tmp.release();
     e->h_in.release(); e->h_out.release(); e->full_file_calls.clear(); e->full_file_calls.shrink_to_fit();
     for (auto &slot : e->measure_slot) slot.release();
+    for (auto &slot : e->upload_slot) slot.release();
+    std::free(e->filtered); e->filtered = nullptr; e->filtered_cap = 0;
+    e->frame_tables.clear(); e->frame_tables.shrink_to_fit();
     e->full_file_slices.clear(); e->full_file_slices.shrink_to_fit();
     if (e->pipe) { sono::stream_pipe_destroy(e->pipe); e->pipe = nullptr; }
     return SONO_OK;

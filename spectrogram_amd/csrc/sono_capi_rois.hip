@@ -318,29 +318,46 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
     HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jb, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_coefs, coefs, sizeof(coefs), hipMemcpyHostToDevice, s));
     HIP_TRY(sono::launch_highpass_regions(d_all, (float *)e->d_runs.p, d_jobs, jobs.size(), d_coefs, d_rec != nullptr, s));
+    // The filtered samples go back to the host (in pieces of whole regions through the pinned staging area, then to
+    // their places in x_filtered) on a thread and a stream of their own while this thread runs the second pass.
+    std::thread copier;
+    int copy_status = SONO_OK;
+    hipStream_t down = nullptr;
+    hipEvent_t filtered = nullptr;
     if (x_filtered) {
-        // back to the host in pieces of whole regions through the pinned staging area, then to their places
-        const size_t piece = (size_t)16 << 20;               // samples per piece (a region longer than that goes alone)
-        size_t k0 = 0;
-        while (k0 < jobs.size()) {
-            size_t k1 = k0, count = 0;
-            while (k1 < jobs.size() && (k1 == k0 || count + jobs[k1].len <= piece)) count += (size_t)jobs[k1++].len;
-            if (!e->h_in.reserve(count * sizeof(float)))
-                return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
-            const float *filt = (const float *)e->h_in.p;
-            HIP_TRY(hipMemcpyAsync(e->h_in.p, (const float *)e->d_runs.p + jobs[k0].dst, count * sizeof(float), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            std::vector<CopyJob> copies(k1 - k0);
-            for (size_t k = k0; k < k1; ++k)
-                copies[k - k0] = {x_filtered + rois[job_region[k]].start, filt + (jobs[k].dst - jobs[k0].dst), (size_t)jobs[k].len * sizeof(float)};
-            parallel_copy(copies);
-            k0 = k1;
-        }
+        HIP_TRY(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&filtered, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(filtered, s));
+        HIP_TRY(hipStreamWaitEvent(down, filtered, 0));
+        const int device = e->device;
+        copier = std::thread([&, device]() {
+            if (hipSetDevice(device) != hipSuccess) { copy_status = SONO_EDEVICE; return; }
+            const size_t piece = (size_t)16 << 20;               // samples per piece (a region longer than that goes alone)
+            size_t k0 = 0;
+            while (k0 < jobs.size()) {
+                size_t k1 = k0, count = 0;
+                while (k1 < jobs.size() && (k1 == k0 || count + jobs[k1].len <= piece)) count += (size_t)jobs[k1++].len;
+                if (!e->h_in.reserve(count * sizeof(float))) { copy_status = SONO_ENOMEM; return; }
+                const float *filt = (const float *)e->h_in.p;
+                if (hipMemcpyAsync(e->h_in.p, (const float *)e->d_runs.p + jobs[k0].dst, count * sizeof(float), hipMemcpyDeviceToHost,
+                                   down) != hipSuccess || hipStreamSynchronize(down) != hipSuccess) {
+                    (void)hipGetLastError();
+                    copy_status = SONO_EDEVICE;
+                    return;
+                }
+                std::vector<CopyJob> copies(k1 - k0);
+                for (size_t k = k0; k < k1; ++k)
+                    copies[k - k0] = {x_filtered + rois[job_region[k]].start, filt + (jobs[k].dst - jobs[k0].dst),
+                                      (size_t)jobs[k].len * sizeof(float)};
+                parallel_copy(copies);
+                k0 = k1;
+            }
+        });
     }
-    timer.lap("high-pass, filtered samples");
     // ---- second pass over the filtered regions, in batches ----
     size_t k0 = 0;
-    while (k0 < jobs.size()) {
+    rc = SONO_OK;
+    while (k0 < jobs.size() && rc == SONO_OK) {
         size_t k1 = k0, frames2 = 0;
         std::vector<uint64_t> off2, len2, rows2;
         while (k1 < jobs.size()) {
@@ -351,10 +368,16 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
             ++k1;
         }
         rc = peaks_pass(e, (const float *)e->d_runs.p, off2, len2, rows2, b, frames2, out, nullptr);
-        if (rc) return rc;
         k0 = k1;
     }
     timer.lap("second pass");
+    if (copier.joinable()) copier.join();
+    if (filtered) (void)hipEventDestroy(filtered);
+    if (down) (void)hipStreamDestroy(down);
+    timer.lap("filtered samples on the host");
+    if (rc) return rc;
+    if (copy_status == SONO_ENOMEM) return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
+    if (copy_status) return fail(copy_status, "sono_analyze_rois: copying the filtered samples to the host failed");
     return SONO_OK;
 }
 
@@ -670,15 +693,22 @@ int sono_process_full_file(sono_engine *e, const float *x, size_t n, double samp
     rc = sono_roi_rows(rois.data(), n_rois, N, opt->hop_percent, row0.data());
     if (rc) return rc;
     const size_t total = (size_t)row0[n_rois];
-    std::vector<float> peak_db(total + 1), left(total + 1), right(total + 1), hp(n_rois + 1);
-    std::vector<int32_t> peak_bin(total + 1), ilo(total + 1), ihi(total + 1);
+    // six per-frame arrays, every entry of which the analysis writes: one block the engine keeps (fresh pages again)
+    if (e->frame_tables.size() < 6 * (total + 1)) e->frame_tables.resize(6 * (total + 1));
+    float *peak_db = (float *)e->frame_tables.data(), *left = peak_db + (total + 1), *right = left + (total + 1);
+    int32_t *peak_bin = (int32_t *)(right + (total + 1)), *ilo = peak_bin + (total + 1), *ihi = ilo + (total + 1);
+    std::vector<float> hp(n_rois + 1);
     std::vector<double> zonal((n_rois + 1) * SONO_MAX_ZONES);
-    sono_roi_table t{row0.data(), peak_db.data(), peak_bin.data(), left.data(), right.data(), ilo.data(), ihi.data(),
-                     zonal.data(), hp.data(), 0, 0, 0, 0};
-    // the samples of the regions that get the automatic high-pass land here; calloc leaves every other page untouched
-    struct Freer { void operator()(float *p) const { std::free(p); } };
-    std::unique_ptr<float, Freer> xf_own((float *)std::calloc(n ? n : 1, sizeof(float)));
-    float *xf = xf_own.get();
+    sono_roi_table t{row0.data(), peak_db, peak_bin, left, right, ilo, ihi, zonal.data(), hp.data(), 0, 0, 0, 0};
+    // The samples of the regions that get the automatic high-pass land here, at their places in the recording; nothing
+    // else of it is ever read (region_audio), so it needs no clearing, and the engine keeps it from call to call: the
+    // first touch of a fresh page costs more than the copy into it.
+    if (e->filtered_cap < n) {
+        std::free(e->filtered);
+        e->filtered = (float *)std::malloc((n ? n : 1) * sizeof(float));
+        e->filtered_cap = e->filtered ? n : 0;
+    }
+    float *xf = e->filtered;
     if (!xf) return fail(SONO_ENOMEM, "sono_process_full_file: cannot allocate the filtered recording");
     lap("merge, tables");
     rc = analyze_rois(e, x, n, rois.data(), n_rois, sample_rate, flow_khz, fhigh_khz, opt->hop_percent, 1, &t, total, xf, d_rec);
