@@ -119,20 +119,33 @@ int peaks_pass(sono_engine *e, const float *d_src, const std::vector<uint64_t> &
     const sono::FramePeak *feat = (const sono::FramePeak *)e->h_out.p;
     HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, frames * sizeof(sono::FramePeak), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    size_t row = 0;
+    // records -> the table's six arrays, the regions shared out over host threads
+    std::vector<size_t> first(off.size() + 1, 0);
     for (size_t i = 0; i < off.size(); ++i) {
-        const size_t F = sono_frames_for((size_t)len[i], N, b.noverlap);
-        if (first_row_out) (*first_row_out)[i] = row;
-        for (size_t f = 0; f < F; ++f) {
-            t->peak_db[feat_rows[i] + f] = feat[row + f].db;
-            t->peak_bin[feat_rows[i] + f] = feat[row + f].bin;
-            t->peak_left_db[feat_rows[i] + f] = feat[row + f].left;
-            t->peak_right_db[feat_rows[i] + f] = feat[row + f].right;
-            t->inst_lo_bin[feat_rows[i] + f] = feat[row + f].lo12;
-            t->inst_hi_bin[feat_rows[i] + f] = feat[row + f].hi12;
-        }
-        row += F;
+        first[i + 1] = first[i] + sono_frames_for((size_t)len[i], N, b.noverlap);
+        if (first_row_out) (*first_row_out)[i] = first[i];
     }
+    std::atomic<size_t> next{0};
+    const size_t step = 64;                                  // regions per grab
+    auto work = [&]() {
+        for (size_t i0 = next.fetch_add(step); i0 < off.size(); i0 = next.fetch_add(step))
+            for (size_t i = i0; i < std::min(i0 + step, off.size()); ++i) {
+                const size_t row = first[i], F = first[i + 1] - first[i];
+                for (size_t f = 0; f < F; ++f) {
+                    t->peak_db[feat_rows[i] + f] = feat[row + f].db;
+                    t->peak_bin[feat_rows[i] + f] = feat[row + f].bin;
+                    t->peak_left_db[feat_rows[i] + f] = feat[row + f].left;
+                    t->peak_right_db[feat_rows[i] + f] = feat[row + f].right;
+                    t->inst_lo_bin[feat_rows[i] + f] = feat[row + f].lo12;
+                    t->inst_hi_bin[feat_rows[i] + f] = feat[row + f].hi12;
+                }
+            }
+    };
+    const unsigned int threads = frames < 100000 ? 1u : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool;
+    for (unsigned int w = 1; w < threads; ++w) pool.emplace_back(work);
+    work();
+    for (std::thread &th : pool) th.join();
     return SONO_OK;
 }
 

@@ -6,6 +6,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cstring>
+#include <type_traits>
 
 namespace sono {
 
@@ -18,6 +19,32 @@ __device__ __forceinline__ double wave_sum(double v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// One workgroup per kRowsPerBlock rows (band_active_kernel), or -- for the kernels that loop over rows -- at most 8192.
+unsigned int rows_grid(size_t frames) { return (unsigned int)((frames + kRowsPerBlock - 1) / kRowsPerBlock); }
+unsigned int rows_grid_capped(size_t frames) { const unsigned int g = rows_grid(frames); return g < 8192u ? g : 8192u; }
+
+// The row kernels below let a wave take row after row (a grid-stride loop over rows instead of one short-lived
+// workgroup per four rows) and, for rows of up to 64 * kRowRegs bins, fetch a lane's whole share of the row with
+// kRowRegs loads issued together before anything looks at the values; wider rows take the strided loop.
+constexpr int kRowRegs = 8;
+
+template <typename F>
+__device__ __forceinline__ void for_each_row(size_t frames, F &&body)
+{
+    const size_t waves = (size_t)gridDim.x * kRowsPerBlock;
+    for (size_t f = (size_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6); f < frames; f += waves) body(f);
+}
+
+// v[k] = row[lane + 64 k] (fill where the row has ended)
+__device__ __forceinline__ void load_row(const float *row, uint32_t nb, int lane, float fill, float (&v)[kRowRegs])
+{
+#pragma unroll
+    for (int k = 0; k < kRowRegs; ++k) {
+        const uint32_t b = (uint32_t)lane + 64u * k;
+        v[k] = b < nb ? row[b] : fill;
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void band_active_kernel(const float *mags, size_t frames, uint32_t bins,
@@ -43,16 +70,32 @@ __global__ __launch_bounds__(kThreads) void band_active_kernel(const float *mags
     }
 }
 
+// 10 log10(max(m^2 / N, 1e-16)) of the band's bins in double, as the JavaScript computes it (batCallDetector.js:1353-1360),
+// rounded to f32 where it stores into a Float32Array.  A wave per row: no division finds the row of an element.
 __global__ __launch_bounds__(kThreads) void power_db_kernel(const float *mags, size_t frames, uint32_t bins,
                                                             uint32_t min_bin, uint32_t nb, double fft_size, float *db)
 {
-    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i >= frames * (size_t)nb) return;
-    const size_t f = i / nb;
-    const uint32_t b = (uint32_t)(i - f * nb);
-    const double m = (double)mags[f * bins + min_bin + b];
-    const double psd = (m * m) / fft_size;
-    db[i] = (float)(10.0 * log10(psd > 1e-16 ? psd : 1e-16));
+    const int lane = threadIdx.x & 63;
+    auto to_db = [&](float mag) {
+        const double m = (double)mag;
+        const double psd = (m * m) / fft_size;
+        return (float)(10.0 * log10(psd > 1e-16 ? psd : 1e-16));
+    };
+    for_each_row(frames, [&](size_t f) {
+        const float *src = mags + f * bins + min_bin;
+        float *dst = db + f * nb;
+        if (nb <= 64u * kRowRegs) {
+            float v[kRowRegs];
+            load_row(src, nb, lane, 0.0f, v);
+#pragma unroll
+            for (int k = 0; k < kRowRegs; ++k) {
+                const uint32_t b = (uint32_t)lane + 64u * k;
+                if (b < nb) dst[b] = to_db(v[k]);
+            }
+        } else {
+            for (uint32_t b = lane; b < nb; b += 64) dst[b] = to_db(src[b]);
+        }
+    });
 }
 
 __global__ __launch_bounds__(kThreads) void db_max_kernel(const float *db, size_t count, uint32_t *max_key)
@@ -75,14 +118,21 @@ __global__ __launch_bounds__(kThreads) void db_max_kernel(const float *db, size_
 __global__ __launch_bounds__(kThreads) void db_active_kernel(const float *db, size_t frames, uint32_t nb,
                                                              double threshold, uint8_t *active)
 {
-    const size_t f = (size_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (f >= frames) return;
-    const float *row = db + f * nb;
-    bool any = false;
-    for (uint32_t b = lane; b < nb; b += 64) any = any || ((double)row[b] > threshold);
-    const unsigned long long m = __ballot(any);
-    if (lane == 0) active[f] = m ? 1 : 0;
+    for_each_row(frames, [&](size_t f) {
+        const float *row = db + f * nb;
+        bool any = false;
+        if (nb <= 64u * kRowRegs) {
+            float v[kRowRegs];
+            load_row(row, nb, lane, -INFINITY, v);
+#pragma unroll
+            for (int k = 0; k < kRowRegs; ++k) any = any || ((double)v[k] > threshold);
+        } else {
+            for (uint32_t b = lane; b < nb; b += 64) any = any || ((double)row[b] > threshold);
+        }
+        const unsigned long long m = __ballot(any);
+        if (lane == 0) active[f] = m ? 1 : 0;
+    });
 }
 
 __global__ __launch_bounds__(kThreads) void frame_features_kernel(const float *db, size_t frames, uint32_t nb,
@@ -91,78 +141,102 @@ __global__ __launch_bounds__(kThreads) void frame_features_kernel(const float *d
                                                                   uint32_t high_min_bin, double high_thr,
                                                                   sono_frame_features *out)
 {
-    const size_t f = (size_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (f >= frames) return;
-    const float *row = db + f * nb;
-    // peak: first bin holding the largest value (strict > from -infinity, NaN never wins)
-    float best = -INFINITY;
-    int best_bin = -1;
-    int low = 0x7FFFFFFF, high = -1;
-    for (uint32_t b = lane; b < nb; b += 64) {
-        const float v = row[b];
-        if (b >= peak_b0 && b <= peak_b1 && v > best) { best = v; best_bin = (int)b; }
-        if (b <= low_max_bin && (double)v > low_thr && (int)b < low) low = (int)b;
-        if (b >= high_min_bin && (double)v > high_thr) high = (int)b;       // b ascends: keeps the last
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int ob = __shfl_xor(best_bin, o, 64);
-        const bool take = ob >= 0 && (best_bin < 0 || ov > best || (ov == best && ob < best_bin));
-        if (take) { best = ov; best_bin = ob; }
-        const int ol = __shfl_xor(low, o, 64), oh = __shfl_xor(high, o, 64);
-        low = ol < low ? ol : low;
-        high = oh > high ? oh : high;
-    }
-    if (lane == 0) {
-        sono_frame_features r;
-        r.peak_bin = best_bin;
-        r.peak_db = best;
-        r.low_bin = low == 0x7FFFFFFF ? -1 : low;
-        r.high_bin = high;
-        out[f] = r;
-    }
+    for_each_row(frames, [&](size_t f) {
+        const float *row = db + f * nb;
+        // peak: first bin holding the largest value (strict > from -infinity, NaN never wins)
+        float best = -INFINITY;
+        int best_bin = -1;
+        int low = 0x7FFFFFFF, high = -1;
+        auto look = [&](uint32_t b, float v) {
+            if (b >= peak_b0 && b <= peak_b1 && v > best) { best = v; best_bin = (int)b; }
+            if (b <= low_max_bin && (double)v > low_thr && (int)b < low) low = (int)b;
+            if (b >= high_min_bin && (double)v > high_thr) high = (int)b;       // b ascends: keeps the last
+        };
+        if (nb <= 64u * kRowRegs) {
+            float v[kRowRegs];
+            load_row(row, nb, lane, NAN, v);
+#pragma unroll
+            for (int k = 0; k < kRowRegs; ++k) {
+                const uint32_t b = (uint32_t)lane + 64u * k;
+                if (b < nb) look(b, v[k]);
+            }
+        } else {
+            for (uint32_t b = lane; b < nb; b += 64) look(b, row[b]);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int ob = __shfl_xor(best_bin, o, 64);
+            const bool take = ob >= 0 && (best_bin < 0 || ov > best || (ov == best && ob < best_bin));
+            if (take) { best = ov; best_bin = ob; }
+            const int ol = __shfl_xor(low, o, 64), oh = __shfl_xor(high, o, 64);
+            low = ol < low ? ol : low;
+            high = oh > high ? oh : high;
+        }
+        if (lane == 0) {
+            sono_frame_features r;
+            r.peak_bin = best_bin;
+            r.peak_db = best;
+            r.low_bin = low == 0x7FFFFFFF ? -1 : low;
+            r.high_bin = high;
+            out[f] = r;
+        }
+    });
 }
 
 __global__ __launch_bounds__(kThreads) void frame_peaks_kernel(const float *db, size_t frames, uint32_t nb, FramePeak *out)
 {
-    const size_t f = (size_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (f >= frames) return;
-    const float *row = db + f * nb;
-    float best = -INFINITY;
-    int best_bin = -1;
-    for (uint32_t b = lane; b < nb; b += 64) {
-        const float v = row[b];
-        if (v > best) { best = v; best_bin = (int)b; }              // strict >, b ascends: the first maximum of the lane
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int ob = __shfl_xor(best_bin, o, 64);
-        const bool take = ob >= 0 && (best_bin < 0 || ov > best || (ov == best && ob < best_bin));
-        if (take) { best = ov; best_bin = ob; }
-    }
-    // second sweep: extent of the bins above peak - 12 dB (js:3061-3073)
-    const double thr = (double)best - 12;
-    int lo = 0x7FFFFFFF, hi = -1;
-    for (uint32_t b = lane; b < nb; b += 64) {
-        if ((double)row[b] > thr) { if ((int)b < lo) lo = (int)b; hi = (int)b; }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        const int ol = __shfl_xor(lo, o, 64), oh = __shfl_xor(hi, o, 64);
-        lo = ol < lo ? ol : lo;
-        hi = oh > hi ? oh : hi;
-    }
-    if (lane == 0) {
-        FramePeak r;
-        r.lo12 = lo == 0x7FFFFFFF ? -1 : lo;
-        r.hi12 = hi;
-        r.bin = best_bin;
-        r.db = best;
-        r.left = best_bin > 0 ? row[best_bin - 1] : NAN;
-        r.right = best_bin >= 0 && (uint32_t)best_bin + 1 < nb ? row[best_bin + 1] : NAN;
-        out[f] = r;
-    }
+    for_each_row(frames, [&](size_t f) {
+        const float *row = db + f * nb;
+        const bool in_regs = nb <= 64u * kRowRegs;
+        float v[kRowRegs];
+        if (in_regs) load_row(row, nb, lane, NAN, v);
+        float best = -INFINITY;
+        int best_bin = -1;
+        if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < kRowRegs; ++k)
+                if (v[k] > best) { best = v[k]; best_bin = lane + 64 * k; }     // strict >, b ascends: the first maximum of the lane; NaN (also the fill) never wins
+        } else {
+            for (uint32_t b = lane; b < nb; b += 64) {
+                const float x = row[b];
+                if (x > best) { best = x; best_bin = (int)b; }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int ob = __shfl_xor(best_bin, o, 64);
+            const bool take = ob >= 0 && (best_bin < 0 || ov > best || (ov == best && ob < best_bin));
+            if (take) { best = ov; best_bin = ob; }
+        }
+        // second sweep: extent of the bins above peak - 12 dB (js:3061-3073)
+        const double thr = (double)best - 12;
+        int lo = 0x7FFFFFFF, hi = -1;
+        if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < kRowRegs; ++k)
+                if ((double)v[k] > thr) { const int b = lane + 64 * k; if (b < lo) lo = b; hi = b; }
+        } else {
+            for (uint32_t b = lane; b < nb; b += 64)
+                if ((double)row[b] > thr) { if ((int)b < lo) lo = (int)b; hi = (int)b; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int ol = __shfl_xor(lo, o, 64), oh = __shfl_xor(hi, o, 64);
+            lo = ol < lo ? ol : lo;
+            hi = oh > hi ? oh : hi;
+        }
+        if (lane == 0) {
+            FramePeak r;
+            r.lo12 = lo == 0x7FFFFFFF ? -1 : lo;
+            r.hi12 = hi;
+            r.bin = best_bin;
+            r.db = best;
+            r.left = best_bin > 0 ? row[best_bin - 1] : NAN;
+            r.right = best_bin >= 0 && (uint32_t)best_bin + 1 < nb ? row[best_bin + 1] : NAN;
+            out[f] = r;
+        }
+    });
 }
 
 __global__ __launch_bounds__(kThreads) void run_edges_kernel(const uint8_t *active, size_t frames, uint8_t *is_start,
@@ -177,32 +251,53 @@ __global__ __launch_bounds__(kThreads) void run_edges_kernel(const uint8_t *acti
     is_end[f] = a && !next;
 }
 
-__global__ __launch_bounds__(kThreads) void pcm_to_f32_kernel(const uint8_t *pcm, size_t frames, uint32_t channels,
-                                                              uint32_t channel, uint32_t bytes_per_sample, int is_float,
-                                                              float *out)
+// One sample of the WAV data chunk -> f32 (integer PCM divided by 2^(bits-1), 8-bit PCM offset binary, float as it is).
+// ALIGNED: the chunk starts on a multiple of the sample size, so a sample is one load; otherwise byte by byte.
+template <int BPS, bool IS_FLOAT, bool ALIGNED>
+__device__ __forceinline__ float pcm_sample(const uint8_t *p)
 {
-    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i >= frames) return;
-    const uint8_t *p = pcm + (i * channels + channel) * (size_t)bytes_per_sample;
-    float v;
-    if (is_float) {
-        uint32_t b = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-        v = __uint_as_float(b);
-    } else if (bytes_per_sample == 1) {
-        v = ((float)p[0] - 128.0f) * (1.0f / 128.0f);
-    } else if (bytes_per_sample == 2) {
-        v = (float)(int16_t)((uint16_t)p[0] | ((uint16_t)p[1] << 8)) * (1.0f / 32768.0f);
-    } else if (bytes_per_sample == 3) {
-        const int32_t s = (int32_t)(((uint32_t)p[0] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 24)) >> 8;
-        v = (float)s * (1.0f / 8388608.0f);
+    if constexpr (BPS == 1) return ((float)p[0] - 128.0f) * (1.0f / 128.0f);
+    else if constexpr (BPS == 2) {
+        const int16_t v = ALIGNED ? *(const int16_t *)p : (int16_t)((uint16_t)p[0] | ((uint16_t)p[1] << 8));
+        return (float)v * (1.0f / 32768.0f);
+    } else if constexpr (BPS == 3) {
+        const int32_t v = (int32_t)(((uint32_t)p[0] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 24)) >> 8;
+        return (float)v * (1.0f / 8388608.0f);
     } else {
-        const int32_t s = (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
-        v = (float)s * (1.0f / 2147483648.0f);
+        const uint32_t b = ALIGNED ? *(const uint32_t *)p
+                                   : (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        return IS_FLOAT ? __uint_as_float(b) : (float)(int32_t)b * (1.0f / 2147483648.0f);
     }
-    out[i] = v;
 }
 
-unsigned int rows_grid(size_t frames) { return (unsigned int)((frames + kRowsPerBlock - 1) / kRowsPerBlock); }
+// Eight consecutive sample frames per thread: eight loads in flight, two 16-byte stores (d_out comes from hipMalloc or
+// is checked to be 16-byte aligned by the launcher; the tail and unaligned outputs take the scalar stores).
+constexpr int kPcmPerThread = 8;
+template <int BPS, bool IS_FLOAT, bool ALIGNED, bool WIDE_STORES>
+__global__ __launch_bounds__(kThreads) void pcm_to_f32_kernel(const uint8_t *pcm, size_t frames, uint32_t channels,
+                                                              uint32_t channel, float *out)
+{
+    const size_t stride = (size_t)channels * BPS;
+    for (size_t i0 = ((size_t)blockIdx.x * kThreads + threadIdx.x) * kPcmPerThread; i0 < frames;
+         i0 += (size_t)gridDim.x * kThreads * kPcmPerThread) {
+        const uint8_t *p = pcm + (i0 * channels + channel) * (size_t)BPS;
+        if (i0 + kPcmPerThread <= frames) {
+            float v[kPcmPerThread];
+#pragma unroll
+            for (int k = 0; k < kPcmPerThread; ++k) v[k] = pcm_sample<BPS, IS_FLOAT, ALIGNED>(p + k * stride);
+            if (WIDE_STORES) {
+                *(float4 *)(out + i0) = make_float4(v[0], v[1], v[2], v[3]);
+                *(float4 *)(out + i0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < kPcmPerThread; ++k) out[i0 + k] = v[k];
+            }
+        } else {
+            for (size_t i = i0; i < frames; ++i) out[i] = pcm_sample<BPS, IS_FLOAT, ALIGNED>(pcm + (i * channels + channel) * (size_t)BPS);
+        }
+    }
+}
+
 
 // One LDS histogram per workgroup, merged into the global one at the end.
 __global__ __launch_bounds__(kThreads) void zone_hist_kernel(const float *db, size_t count, uint32_t nb,
@@ -469,7 +564,7 @@ hipError_t launch_power_db(const float *d_mags, size_t frames, uint32_t bins, ui
 {
     const size_t count = frames * (size_t)nb;
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(power_db_kernel, dim3((unsigned int)((count + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+    hipLaunchKernelGGL(power_db_kernel, dim3(rows_grid_capped(frames)), dim3(kThreads), 0, s,
                        d_mags, frames, bins, min_bin, nb, (double)fft_size, d_db);
     return hipGetLastError();
 }
@@ -487,7 +582,7 @@ hipError_t launch_db_active(const float *d_db, size_t frames, uint32_t nb, doubl
                             hipStream_t s)
 {
     if (frames == 0) return hipSuccess;
-    hipLaunchKernelGGL(db_active_kernel, dim3(rows_grid(frames)), dim3(kThreads), 0, s, d_db, frames, nb, threshold_db,
+    hipLaunchKernelGGL(db_active_kernel, dim3(rows_grid_capped(frames)), dim3(kThreads), 0, s, d_db, frames, nb, threshold_db,
                        d_active);
     return hipGetLastError();
 }
@@ -497,7 +592,7 @@ hipError_t launch_frame_features(const float *d_db, size_t frames, uint32_t nb, 
                                  sono_frame_features *d_out, hipStream_t s)
 {
     if (frames == 0) return hipSuccess;
-    hipLaunchKernelGGL(frame_features_kernel, dim3(rows_grid(frames)), dim3(kThreads), 0, s, d_db, frames, nb, peak_b0,
+    hipLaunchKernelGGL(frame_features_kernel, dim3(rows_grid_capped(frames)), dim3(kThreads), 0, s, d_db, frames, nb, peak_b0,
                        peak_b1, low_max_bin, low_thr, high_min_bin, high_thr, d_out);
     return hipGetLastError();
 }
@@ -505,7 +600,7 @@ hipError_t launch_frame_features(const float *d_db, size_t frames, uint32_t nb, 
 hipError_t launch_frame_peaks(const float *d_db, size_t frames, uint32_t nb, FramePeak *d_out, hipStream_t s)
 {
     if (frames == 0) return hipSuccess;
-    hipLaunchKernelGGL(frame_peaks_kernel, dim3(rows_grid(frames)), dim3(kThreads), 0, s, d_db, frames, nb, d_out);
+    hipLaunchKernelGGL(frame_peaks_kernel, dim3(rows_grid_capped(frames)), dim3(kThreads), 0, s, d_db, frames, nb, d_out);
     return hipGetLastError();
 }
 
@@ -518,12 +613,62 @@ hipError_t launch_run_edges(const uint8_t *d_active, size_t frames, uint8_t *d_i
     return hipGetLastError();
 }
 
+// The common recording: mono 16-bit PCM whose data chunk starts on a multiple of four bytes (the 44-byte header of a
+// plain WAV file does).  Eight samples per thread as four dword loads, two 16-byte stores.
+__global__ __launch_bounds__(kThreads) void pcm16_mono_to_f32_kernel(const uint32_t *pcm2, size_t frames, float *out)
+{
+    const size_t groups = frames / kPcmPerThread;            // whole groups of eight; the tail goes to the generic kernel
+    for (size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x; g < groups; g += (size_t)gridDim.x * kThreads) {
+        const uint32_t *p = pcm2 + g * (kPcmPerThread / 2);
+        uint32_t w[kPcmPerThread / 2];
+#pragma unroll
+        for (int k = 0; k < kPcmPerThread / 2; ++k) w[k] = p[k];
+        float v[kPcmPerThread];
+#pragma unroll
+        for (int k = 0; k < kPcmPerThread / 2; ++k) {
+            v[2 * k] = (float)(int16_t)(w[k] & 0xFFFFu) * (1.0f / 32768.0f);
+            v[2 * k + 1] = (float)(int16_t)(w[k] >> 16) * (1.0f / 32768.0f);
+        }
+        float *o = out + g * kPcmPerThread;
+        *(float4 *)o = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4 *)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 hipError_t launch_pcm_to_f32(const void *d_pcm, size_t frames, uint32_t channels, uint32_t channel, uint32_t bits,
                              int is_float, float *d_out, hipStream_t s)
 {
     if (frames == 0) return hipSuccess;
-    hipLaunchKernelGGL(pcm_to_f32_kernel, dim3((unsigned int)((frames + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                       (const uint8_t *)d_pcm, frames, channels, channel, bits / 8, is_float, d_out);
+    const uint32_t bps = bits / 8;
+    if (!is_float && bps == 2 && channels == 1 && (uintptr_t)d_pcm % 4 == 0 && (uintptr_t)d_out % 16 == 0 && frames >= 4096) {
+        const size_t groups = frames / kPcmPerThread, blocks = (groups + kThreads - 1) / kThreads;
+        hipLaunchKernelGGL(pcm16_mono_to_f32_kernel, dim3((unsigned int)(blocks < 65536 ? blocks : 65536)), dim3(kThreads), 0, s,
+                           (const uint32_t *)d_pcm, frames, d_out);
+        const size_t done = groups * kPcmPerThread;
+        if (done == frames) return hipGetLastError();
+        // the last few samples: the generic kernel on the tail
+        return launch_pcm_to_f32((const uint8_t *)d_pcm + done * 2, frames - done, 1, 0, 16, 0, d_out + done, s);
+    }
+    const size_t per_block = (size_t)kThreads * kPcmPerThread;
+    const size_t blocks = (frames + per_block - 1) / per_block;
+    const dim3 grid((unsigned int)(blocks < 65536 ? blocks : 65536)), block(kThreads);
+    const bool aligned = ((uintptr_t)d_pcm % (bps == 3 ? 1 : bps)) == 0, wide = ((uintptr_t)d_out % 16) == 0;
+    const uint8_t *p = (const uint8_t *)d_pcm;
+    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, 0, s, p, frames, channels, channel, d_out); };
+    auto pick = [&](auto bps_, auto flt_) {
+        constexpr int B = decltype(bps_)::value;
+        constexpr bool F = decltype(flt_)::value;
+        if (aligned && wide) go(pcm_to_f32_kernel<B, F, true, true>);
+        else if (aligned) go(pcm_to_f32_kernel<B, F, true, false>);
+        else if (wide) go(pcm_to_f32_kernel<B, F, false, true>);
+        else go(pcm_to_f32_kernel<B, F, false, false>);
+    };
+    using std::integral_constant;
+    if (is_float) pick(integral_constant<int, 4>{}, integral_constant<bool, true>{});
+    else if (bps == 1) pick(integral_constant<int, 1>{}, integral_constant<bool, false>{});
+    else if (bps == 2) pick(integral_constant<int, 2>{}, integral_constant<bool, false>{});
+    else if (bps == 3) pick(integral_constant<int, 3>{}, integral_constant<bool, false>{});
+    else pick(integral_constant<int, 4>{}, integral_constant<bool, false>{});
     return hipGetLastError();
 }
 

@@ -147,6 +147,28 @@ def test_decode_wav_channel(bits, is_float):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("frames,byte_offset,out_offset", [(4096, 0, 0), (40003, 0, 0), (40003, 4, 0), (40003, 2, 0), (40003, 0, 1),
+                                                            (1234567, 44, 0)])
+def test_pcm16_mono_conversion_paths(frames, byte_offset, out_offset):
+    # mono 16-bit PCM in HBM: the eight-samples-per-thread path (data on a multiple of four bytes, output on 16), its tail,
+    # and the general path for the other alignments -- all equal to value / 32768
+    import torch
+    rng = np.random.default_rng(frames + byte_offset)
+    a = rng.integers(-32768, 32768, frames + 8, dtype=np.int64).astype(np.int16)
+    a[:3] = [-32768, 32767, 0]
+    raw = torch.from_numpy(np.frombuffer(b"\0" * byte_offset + a.tobytes(), np.uint8).copy()).cuda()
+    out = torch.full((frames + out_offset + 4,), 7.0, dtype=torch.float32, device="cuda")
+    e = sa.SpectrogramEngine(256, "hann")
+    sa._check(sa.lib().sono_pcm_to_f32_dev(e._handle(), raw.data_ptr() + byte_offset, frames, 1, 0, 16, 0,
+                                           out.data_ptr() + 4 * out_offset, None))
+    e.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got[out_offset:out_offset + frames], a[:frames].astype(np.float32) / 32768)
+    assert (got[:out_offset] == 7.0).all() and (got[out_offset + frames:] == 7.0).all()         # nothing written outside
+    e.free()
+
+
+@pytest.mark.gpu
 def test_wav_to_u8_frames_equals_float_input():
     # int16 WAV -> decode -> compute_spectrogram_u8 equals feeding the same samples as floats
     rng = np.random.default_rng(1)
