@@ -48,6 +48,59 @@ double zone_floor(const double *zonal, size_t zones, double freq_khz)
     return -100;                                                                 // the map has no such key
 }
 
+// Running maxima of a call matrix's rows, built row by row on first use.  The threshold searches ask, a hundred
+// thresholds per call and for frame after frame, "which is the first bin of this row above the threshold, counting from
+// the bottom (or from the top)": with the running maximum from that end -- which exceeds the threshold exactly from that
+// bin on -- the answer is a binary search instead of a walk along the row.  Same bins as the reference's loops, which
+// walk (batCallDetector.js:2509-2522, 2002-2038); a NaN is never above a threshold and never raises a maximum.
+class RowMaxima {
+public:
+    RowMaxima(const CallMatrix &m, bool from_bottom) : m_(m), from_bottom_(from_bottom), run_(m.frames * m.bins), built_(m.frames, 0) {}
+    // lowest bin b <= top with db[f][b] > thr, or -1 (from_bottom)
+    int64_t first_above(int64_t f, int64_t top, double thr)
+    {
+        const float *r = row(f);
+        if (top < 0 || !((double)r[top] > thr)) return -1;
+        int64_t lo = 0, hi = top;                            // r[hi] > thr; find the first such
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) / 2;
+            if ((double)r[mid] > thr) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    }
+    // highest bin b >= bottom with db[f][b] > thr, or -1 (from the top)
+    int64_t last_above(int64_t f, int64_t bottom, double thr)
+    {
+        const float *r = row(f);
+        const int64_t nb = (int64_t)m_.bins;
+        if (bottom >= nb || !((double)r[bottom] > thr)) return -1;
+        int64_t lo = bottom, hi = nb - 1;                    // r[lo] > thr; find the last such
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) / 2;
+            if ((double)r[mid] > thr) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    }
+
+private:
+    const float *row(int64_t f)
+    {
+        float *r = run_.data() + (size_t)f * m_.bins;
+        if (!built_[(size_t)f]) {
+            const float *src = m_.db + (size_t)f * m_.bins;
+            float cur = -INFINITY;
+            if (from_bottom_) for (size_t b = 0; b < m_.bins; ++b) { if (src[b] > cur) cur = src[b]; r[b] = cur; }
+            else for (size_t b = m_.bins; b-- > 0;) { if (src[b] > cur) cur = src[b]; r[b] = cur; }
+            built_[(size_t)f] = 1;
+        }
+        return r;
+    }
+    const CallMatrix &m_;
+    bool from_bottom_;
+    std::vector<float> run_;
+    std::vector<char> built_;
+};
+
 struct LowM { double threshold; double low_hz; bool found; int64_t end_frame; int64_t bin; };
 struct HighM { double threshold; double high_hz; int64_t bin, frame; double power; bool found; };
 
@@ -73,6 +126,7 @@ LowResult find_optimal_low_threshold(const CallMatrix &m, double peak, int64_t p
     double opt_threshold = -24;
     int opt = -1;                                                                // index into meas
     std::vector<LowM> meas;
+    RowMaxima rows(m, true);
     int64_t start_frame = valid_peak, max_bin = nb - 1;                          // js:2449, 2453
     auto last_valid = [&]() { for (int i = (int)meas.size() - 1; i >= 0; --i) if (meas[i].found) return i; return -1; };
 
@@ -85,10 +139,9 @@ LowResult find_optimal_low_threshold(const CallMatrix &m, double peak, int64_t p
         int64_t active_end = start_frame;
         int silence = 0;
         for (int64_t f = start_frame; f <= search_end; ++f) {                    // js:2509-2546
-            bool has = false;
-            double lowest = 0;
-            for (int64_t b = 0; b <= max_bin; ++b)
-                if (at(f, b) > thr) { has = true; lowest = fb(b); break; }
+            const int64_t b0 = rows.first_above(f, max_bin, thr);              // the frame's lowest bin above the threshold
+            const bool has = b0 >= 0;
+            const double lowest = has ? fb(b0) : 0;
             if (has) {
                 active_end = f;
                 silence = 0;
@@ -102,8 +155,7 @@ LowResult find_optimal_low_threshold(const CallMatrix &m, double peak, int64_t p
         bool found = false;
         double low_hz = 0, low_power = -INFINITY;
         int64_t found_bin = -1;
-        for (int64_t b = 0; b <= max_bin; ++b) {                                 // js:2560-2612
-            if (!(at(active_end, b) > thr)) continue;
+        for (int64_t b = rows.first_above(active_end, max_bin, thr); b >= 0;) {   // js:2560-2612: the first bin above the threshold
             double cand = fb(b);
             if (b > 0) {
                 const double p1 = at(active_end, b), p0 = at(active_end, b - 1);
@@ -219,6 +271,7 @@ HighResult find_optimal_high_threshold(const CallMatrix &m, const double *tf, do
     int opt = -1, stable = 0;
     int64_t min_bin = 0;
     std::vector<HighM> meas;
+    RowMaxima rows(m, false);
     auto last_valid = [&]() { for (int i = (int)meas.size() - 1; i >= 0; --i) if (meas[i].found) return i; return -1; };
     // upper edge of one frame above a threshold, interpolated towards the bin above (js:2009-2020, 2340-2349)
     auto edge = [&](int64_t f, int64_t b, double thr) {
@@ -241,7 +294,9 @@ HighResult find_optimal_high_threshold(const CallMatrix &m, const double *tf, do
         int silence = 0;
         for (int64_t f = limit; f >= 0; --f) {                                   // js:2002-2048: from the peak back to the call's start
             bool in_frame = false;
-            for (int64_t b = nb - 1; b >= min_bin; --b) {
+            // the frame's bins above the threshold from the top down: the highest by search, any further ones (below a
+            // harmonic that is skipped) by walking on
+            for (int64_t b = rows.last_above(f, min_bin, thr); b >= min_bin; --b) {
                 if (!(at(f, b) > thr)) continue;
                 const double cand = edge(f, b, thr);
                 if (has_ref && cand / 1000 - ref_khz > 10.0) continue;           // js:2022-2026: a harmonic, look further down
