@@ -223,6 +223,34 @@ def test_filter_bank_shapes_against_the_oracle(N, nf, kind):
     e.free()
 
 
+@pytest.mark.parametrize("N,V,width,height", [(256, 192, 40, 30), (1024, 768, 33, 64), (512, 0, 7, 5)])
+def test_image_against_the_restatement(N, V, width, height):
+    """compute_spectrogram_image (lib.rs:494-616) pixel by pixel against oracle/image_oracle.py on the C oracle's
+    magnitudes.  A red channel that equals the colour index shows how far a pixel's index is off: the indices agree
+    except where a frame's u8 code sits on a rounding boundary (the two FFTs differ in the last bits), and then by one.
+    Parity unpinned: the reference has neither a caller nor a fixture for this export."""
+    from oracle import image_oracle as io
+    x = signal(N + 57 * (N - V) + 3, N + width, amp=0.6)
+    cmap = np.zeros((256, 4), np.uint8)
+    cmap[:, 0] = np.arange(256)
+    cmap[:, 1] = 255 - np.arange(256)
+    cmap[:, 2] = (np.arange(256) * 7) % 256
+    cmap[:, 3] = 255
+    e = sa.SpectrogramEngine(N, "hann")
+    e.set_color_map(cmap.ravel())
+    o = so.OracleEngine(N, "hann")
+    mags = np.asarray(o.compute_spectrogram(x, V)).reshape(-1, N // 2)
+    for gain, rng in ((20.0, 80.0), (0.0, 60.0)):
+        got = e.compute_spectrogram_image(x, width, height, V, gain, rng).reshape(height, width, 4)
+        want = io.spectrogram_image(mags, cmap.ravel(), width, height, gain, rng).reshape(height, width, 4)
+        d = np.abs(got[..., 0].astype(int) - want[..., 0].astype(int))
+        assert d.max() <= 1 and (d > 0).mean() <= 0.02, (d.max(), (d > 0).mean())
+        same = d == 0
+        assert np.array_equal(got[same], want[same]) and (got[..., 3] == 255).all()
+        assert want[..., 0].max() > 50                          # the picture is not blank
+    e.free()
+
+
 def test_image_path():
     e = sa.SpectrogramEngine(256, "hann")
     x = signal(256 + 40 * 64, 4)
