@@ -97,7 +97,7 @@ def test_against_oracle(kernel_path, N, V):
 
 @pytest.mark.parametrize("N,V", [(256, 192), (1024, 768), (2048, 1536), (4096, 3891)])
 @pytest.mark.parametrize("window,alpha", [("bartlett", None), ("bartlettHann", None), ("blackman", None), ("blackman", 0.05),
-                                          ("cosine", None), ("gauss", None), ("gauss", 0.4), ("hamming", None),
+                                          ("cosine", None), ("gauss", None), ("gauss", 0.4), ("hamming", None), ("lanczos", None),
                                           ("rectangular", None), ("triangular", None), ("no such window", None)])
 def test_every_window_at_every_size_against_oracle(N, V, window, alpha):
     """The ten windows of lib.rs:698-776 (and the fallback to Hann for an unknown name) at the small, the headline and
