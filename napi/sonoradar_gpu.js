@@ -13,7 +13,8 @@
 'use strict';
 const path = require('path');
 
-const addon = require(path.join(__dirname, 'sonostft.node'));
+// SONO_ADDON_PATH: another build of the addon (the sanitizer build of tools/asan_tests.sh)
+const addon = require(process.env.SONO_ADDON_PATH || path.join(__dirname, 'sonostft.node'));
 
 class SpectrogramEngine extends addon.SpectrogramEngine {}
 class WaveformEngine extends addon.WaveformEngine {}

@@ -15,3 +15,14 @@ export SONO_LIB_PATH="$ROOT/spectrogram_amd/lib/libsonostft_asan.so" SONO_EMUL_L
 export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1
 LD_PRELOAD="$RT${LD_PRELOAD:+:$LD_PRELOAD}" python -m pytest -x -q tests/test_measure_host.py tests/test_framing_host.py tests/test_host_emul.py \
     tests/test_abi_cpu.py tests/test_wav.py tests/test_guano.py tests/test_plugin_host.py -m "not gpu" "$@"
+
+# the Node addon (napi/sonostft_napi.c) the same way: built with clang and the sanitizers against the sanitizer build of
+# the library, loaded into node with the same runtime preloaded; its CPU tests cover the export surface, argument
+# marshalling and the error path of a machine without a GPU
+if [ -f /usr/include/node/node_api.h ] && command -v node > /dev/null; then
+    /opt/rocm/lib/llvm/bin/clang -O1 -g -fPIC -shared -std=c99 -fsanitize=address -fsanitize=undefined -shared-libsan -fno-omit-frame-pointer \
+        -mllvm -asan-globals=0 -DNODE_GYP_MODULE_NAME=sonostft -DNAPI_VERSION=4 -I /usr/include/node napi/sonostft_napi.c -o napi/sonostft_asan.node \
+        -L spectrogram_amd/lib -l:libsonostft_asan.so -Wl,-rpath,"$ROOT/spectrogram_amd/lib"
+    # (globals are left uninstrumented: node maps the module twice, and the second registration reads as an ODR violation)
+    SONO_ADDON_PATH="$ROOT/napi/sonostft_asan.node" LD_PRELOAD="$RT${LD_PRELOAD:+:$LD_PRELOAD}" python -m pytest -x -q tests/test_napi.py -m "not gpu" "$@"
+fi
