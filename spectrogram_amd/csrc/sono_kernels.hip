@@ -272,8 +272,10 @@ hipError_t launch_filterbank_u8(const float *mags, unsigned long long frames, in
 {
     if (frames == 0) return hipSuccess;
     if (bins <= 0 || bins % 4 != 0 || bins > 2048 || num_filters <= 0) return hipErrorInvalidValue;
-    const int in_lds = taps <= FB_LDS_TAPS && (unsigned int)num_filters <= FB_LDS_TAPS;
-    const size_t lds = (size_t)FB_ROWS * bins * sizeof(float) + (in_lds ? ((size_t)num_filters + 2 * (size_t)taps) * 4 : 0);
+    // the tap list goes to LDS beside the rows when it is small and the workgroup stays within 60 KB
+    const size_t row_bytes = (size_t)FB_ROWS * bins * sizeof(float), tap_bytes = ((size_t)num_filters + 2 * (size_t)taps) * 4;
+    const int in_lds = taps <= FB_LDS_TAPS && (unsigned int)num_filters <= FB_LDS_TAPS && row_bytes + tap_bytes <= 60 * 1024;
+    const size_t lds = row_bytes + (in_lds ? tap_bytes : 0);
     const unsigned long long groups = (frames + FB_ROWS - 1) / FB_ROWS;
     const unsigned int grid = (unsigned int)(groups < 2048 ? groups : 2048);       // 8 workgroups per CU
     auto go = [&](auto kernel) {

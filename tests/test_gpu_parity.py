@@ -181,7 +181,8 @@ def test_filter_bank_quirk(golden):
 
 
 @pytest.mark.parametrize("N,nf,kind", [(1024, 64, "two_tap"), (1024, 512, "two_tap"), (512, 40, "dense"), (256, 7, "short"),
-                                        (2048, 33, "sparse_signed"), (4096, 24, "empty_rows")])
+                                        (2048, 33, "sparse_signed"), (4096, 24, "empty_rows"), (4096, 2048, "two_tap"),
+                                        (4096, 1500, "sparse_signed")])
 def test_filter_bank_shapes_against_the_oracle(N, nf, kind):
     """apply_filter_bank (lib.rs:310-334) on the bank shapes the non-zero tap list has to get right: the application's
     two-tap banks (rows of N/2 + 1 weights used with stride N/2, spectrogram.esm.js:1197-1232), a dense bank, one shorter
