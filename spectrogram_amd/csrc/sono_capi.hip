@@ -605,9 +605,6 @@ int sono_stft_u8(sono_engine *e, const float *x, size_t n, uint32_t noverlap, fl
                               (uint32_t *)e->d_gmax.p, nullptr);
         if (rc) return rc;
     } else {
-        HIP_TRY(e->d_mags.reserve(F * B * sizeof(float)));
-        rc = sono_stft_mag_f32_dev(e, &b, noverlap, (float *)e->d_mags.p, nullptr);
-        if (rc) return rc;
         if (!e->bank_taps_ready) {
             // the bank's non-zero taps, listed once per loaded bank and kept on the device
             std::vector<unsigned int> start, bin;
@@ -625,12 +622,24 @@ int sono_stft_u8(sono_engine *e, const float *x, size_t n, uint32_t noverlap, fl
             e->bank_taps_ready = true;
         }
         const size_t sb = e->num_filters * sizeof(unsigned int), tb = e->bank_tap_count * sizeof(unsigned int);
-        HIP_TRY(sono::launch_filterbank_u8((const float *)e->d_mags.p, F, (int)B, (const unsigned int *)e->d_bank.p,
-                                           (const unsigned int *)((char *)e->d_bank.p + sb),
-                                           (const float *)((char *)e->d_bank.p + sb + tb), (unsigned int)e->bank_tap_count,
-                                           (int)e->num_filters, gain_db,
-                                           range_db, (uint8_t *)e->d_out.p, (uint16_t *)e->d_peak_bin.p,
-                                           (float *)e->d_peak_mag.p, (uint32_t *)e->d_gmax.p, e->stream));
+        // The magnitudes only exist between the two kernels: they are formed for one piece of the recording at a time
+        // (pieces start on multiples of 16 frames, so every frame meets the partner it has in the whole transform) in a
+        // scratch of at most 2 GiB, whatever the recording's length.
+        const size_t piece = std::max<size_t>(16, (((size_t)2 << 30) / (B * sizeof(float))) / 16 * 16);
+        HIP_TRY(e->d_mags.reserve(std::min(F, piece) * B * sizeof(float)));
+        const size_t hop = e->N - noverlap;
+        for (size_t f0 = 0; f0 < F; f0 += piece) {
+            const size_t cnt = std::min(piece, F - f0), span = (cnt - 1) * hop + e->N;
+            sono_batch part{(const float *)e->d_in.p + f0 * hop, 1, span, span};
+            rc = sono_stft_mag_f32_dev(e, &part, noverlap, (float *)e->d_mags.p, nullptr);
+            if (rc) return rc;
+            HIP_TRY(sono::launch_filterbank_u8((const float *)e->d_mags.p, cnt, (int)B, (const unsigned int *)e->d_bank.p,
+                                               (const unsigned int *)((char *)e->d_bank.p + sb),
+                                               (const float *)((char *)e->d_bank.p + sb + tb), (unsigned int)e->bank_tap_count,
+                                               (int)e->num_filters, gain_db, range_db,
+                                               (uint8_t *)e->d_out.p + f0 * e->num_filters, (uint16_t *)e->d_peak_bin.p + f0,
+                                               (float *)e->d_peak_mag.p + f0, (uint32_t *)e->d_gmax.p, e->stream));
+        }
     }
     e->last_peak_bin.resize(F);
     e->last_peak_mag.resize(F);

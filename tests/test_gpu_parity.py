@@ -180,6 +180,39 @@ def test_filter_bank_quirk(golden):
     e.free()
 
 
+def test_filter_bank_on_a_recording_longer_than_the_magnitude_scratch():
+    """With a bank loaded the magnitudes are formed piece by piece (2 GiB of them at a time: 262 144 frames at fft 4096).
+    A recording of 300 000 frames gives what its two parts give when each is transformed alone: codes, peaks and the
+    global maximum."""
+    N, hop, nf = 4096, 64, 24
+    piece, total = 262144, 300000
+    rng = np.random.default_rng(11)
+    n = (total - 1) * hop + N
+    t = np.arange(n, dtype=np.float64)
+    x = (0.4 * np.sin(2 * np.pi * (0.03 + 0.2 * t / n) * t) * (0.2 + 0.8 * (t / n))).astype(np.float32)
+    x += rng.normal(0, 0.01, n).astype(np.float32)
+    bank = np.zeros((nf, N // 2 + 1), np.float32)
+    pos = np.sort(rng.uniform(0, N // 2 - 1, nf))
+    for i, q in enumerate(pos):
+        o = int(q)
+        bank[i, o], bank[i, o + 1] = 1 - (q - o), q - o
+    e = sa.SpectrogramEngine(N, "hann")
+    e.load_filter_bank(bank.ravel(), nf)
+    whole = e.compute_spectrogram_u8(x, N - hop, 20.0, 80.0).copy()
+    whole_bins, whole_mags, whole_max = e.get_peaks(0.0).copy(), e.get_peak_magnitudes(0.0).copy(), e.get_global_max()
+    assert whole.size == total * nf
+    first = e.compute_spectrogram_u8(x[:(piece - 1) * hop + N], N - hop, 20.0, 80.0).copy()
+    first_bins, first_mags, first_max = e.get_peaks(0.0).copy(), e.get_peak_magnitudes(0.0).copy(), e.get_global_max()
+    second = e.compute_spectrogram_u8(x[piece * hop:], N - hop, 20.0, 80.0).copy()
+    second_bins, second_mags, second_max = e.get_peaks(0.0).copy(), e.get_peak_magnitudes(0.0).copy(), e.get_global_max()
+    assert first.size == piece * nf and second.size == (total - piece) * nf
+    assert np.array_equal(whole, np.concatenate([first, second]))
+    assert np.array_equal(whole_bins, np.concatenate([first_bins, second_bins]))
+    assert np.array_equal(whole_mags, np.concatenate([first_mags, second_mags]))
+    assert whole_max == max(first_max, second_max) and whole.max() > 100
+    e.free()
+
+
 @pytest.mark.parametrize("N,nf,kind", [(1024, 64, "two_tap"), (1024, 512, "two_tap"), (512, 40, "dense"), (256, 7, "short"),
                                         (2048, 33, "sparse_signed"), (4096, 24, "empty_rows"), (4096, 2048, "two_tap"),
                                         (4096, 1500, "sparse_signed")])
