@@ -8,10 +8,31 @@ namespace sono {
 
 // Device table private to the tiled kernel: the inter-pass twiddle rows of
 // make_tile_twiddles(N) (empty for fft sizes the kernel does not cover).
+// What an engine knows about how fast the chip's XCDs get through their ranges of a launch.  The tiled kernel cuts
+// a launch into one contiguous range of tiles per XCD; the XCDs of one chip do not run at one speed (with equal ranges
+// they end up to 9 % apart, the same ones ahead launch after launch), and a launch is only over when the slowest is.
+// Every workgroup of a large launch therefore reports when it began and ended, into host memory that the device
+// writes directly, and the next large launch's ranges are cut in proportion to what each XCD managed.  Results do
+// not depend on the cut: a tile's output is the same whoever transforms it.
+struct TileBalance {
+    static constexpr unsigned int kMaxGroups = 1024;      // workgroups of a launch (one or two per CU)
+    unsigned long long *feedback = nullptr;               // kMaxGroups x tile::kFeedbackWords, hipHostMalloc
+    double share[8] = {1, 1, 1, 1, 1, 1, 1, 1};            // relative size of each part's range (mean 1)
+    unsigned long long stamp = 0;                         // stamps handed to launches so far
+    unsigned long long seen = 0;                          // stamp of the reports taken up last
+};
+
 struct TileTables {
     unsigned int N = 0;
     void *d_blob = nullptr;
+    mutable TileBalance balance;
 };
+
+namespace tile { struct TileIter; }
+// Fills it.parts / part_begin / feedback / stamp for a launch of it.n_tiles tiles by `blocks` workgroups of `waves_per_block`
+// waves, `resident` of which the chip holds at once; takes up the reports of the last large launch first.  Small
+// launches, and all launches under SONO_FIXED_TILES=1 (read per launch), get equal ranges and report nothing.
+void tile_balance_plan(TileBalance *b, unsigned long long blocks, unsigned long long resident, unsigned int waves_per_block, tile::TileIter &it);
 
 hipError_t tile_tables_build(unsigned int N, TileTables &t);
 void tile_tables_release(TileTables &t);

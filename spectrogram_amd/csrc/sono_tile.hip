@@ -2,6 +2,9 @@
 // serves, dispatch to the per-mode translation units.
 #include "sono_tile.h"
 
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "sono_tables.h"
@@ -9,9 +12,9 @@
 
 namespace sono {
 
-hipError_t launch_tile_u8(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, hipStream_t stream);
-hipError_t launch_tile_mag(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, hipStream_t stream);
-hipError_t launch_tile_band(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, hipStream_t stream);
+hipError_t launch_tile_u8(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, TileBalance *balance, hipStream_t stream);
+hipError_t launch_tile_mag(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, TileBalance *balance, hipStream_t stream);
+hipError_t launch_tile_band(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, TileBalance *balance, hipStream_t stream);
 
 namespace {
 
@@ -23,9 +26,10 @@ constexpr int tile_log_r2(unsigned int N) { return N >= SONO_WIDE_FROM ? 6 : 5; 
 hipError_t launch_any(int mode, const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream)
 {
     const float2 *tw_rows = (const float2 *)t.d_blob;
-    return mode == MODE_MAG ? launch_tile_mag(a, tw_rows, plan, stream)
-         : mode == MODE_BAND ? launch_tile_band(a, tw_rows, plan, stream)
-                             : launch_tile_u8(a, tw_rows, plan, stream);
+    TileBalance *bal = t.balance.feedback ? &t.balance : nullptr;
+    return mode == MODE_MAG ? launch_tile_mag(a, tw_rows, plan, bal, stream)
+         : mode == MODE_BAND ? launch_tile_band(a, tw_rows, plan, bal, stream)
+                             : launch_tile_u8(a, tw_rows, plan, bal, stream);
 }
 
 }  // namespace
@@ -38,10 +42,94 @@ hipError_t tile_tables_build(unsigned int N, TileTables &t)
     const std::vector<float2> rows = make_tile_twiddles(N, 1u << (N == 256 ? 5 : tile_log_r2(N)));
     hipError_t e = hipMalloc(&t.d_blob, rows.size() * sizeof(float2));
     if (e != hipSuccess) { t.d_blob = nullptr; return e; }
+    t.balance = TileBalance();
+    const size_t fb_bytes = (size_t)TileBalance::kMaxGroups * tile::kFeedbackWords * sizeof(unsigned long long);
+    e = hipHostMalloc((void **)&t.balance.feedback, fb_bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { t.balance.feedback = nullptr; return e; }
+    std::memset(t.balance.feedback, 0, fb_bytes);
     return hipMemcpy(t.d_blob, rows.data(), rows.size() * sizeof(float2), hipMemcpyHostToDevice);
 }
 
-void tile_tables_release(TileTables &t) { if (t.d_blob) (void)hipFree(t.d_blob); t.d_blob = nullptr; }
+void tile_tables_release(TileTables &t)
+{
+    if (t.d_blob) (void)hipFree(t.d_blob);
+    if (t.balance.feedback) (void)hipHostFree(t.balance.feedback);
+    t.d_blob = nullptr;
+    t.balance.feedback = nullptr;
+}
+
+void tile_balance_plan(TileBalance *b, unsigned long long blocks, unsigned long long resident, unsigned int waves_per_block, tile::TileIter &it)
+{
+    it.parts = 0;
+    it.feedback = nullptr;
+    it.stamp = 0;
+    for (unsigned int &v : it.part_begin) v = 0;
+    // Large launches only: the whole chip is busy, the workgroups divide evenly among the parts, every wave has
+    // at least kMinTilesPerWave tiles, tile numbers fit 32 bits.
+    constexpr unsigned long long kMinTilesPerWave = 64;
+    constexpr unsigned int P = tile::kTileParts;
+    const char *fixed = std::getenv("SONO_FIXED_TILES");
+    if (!b || !b->feedback || (fixed && fixed[0] && fixed[0] != '0')) return;
+    if (blocks != resident || blocks % P != 0 || blocks > TileBalance::kMaxGroups) return;
+    if (it.n_tiles >= (1ull << 32) || it.n_tiles < blocks * waves_per_block * kMinTilesPerWave) return;
+    // Reports of the last large launch that has finished: usable when every workgroup's record carries one stamp,
+    // newer than the one taken up last (a launch still running, or records of two launches mixed, are left alone).
+    const volatile unsigned long long *fb = b->feedback;
+    const unsigned long long s0 = fb[3];
+    bool whole = s0 > b->seen && s0 <= b->stamp;
+    unsigned long long first[P], last[P], tiles[P];
+    for (unsigned int p = 0; p < P; ++p) { first[p] = ~0ull; last[p] = 0; tiles[p] = 0; }
+    for (unsigned long long g = 0; whole && g < blocks; ++g) {
+        const volatile unsigned long long *r = fb + g * tile::kFeedbackWords;
+        const unsigned long long t0 = r[0], t1 = r[1], n = r[2];
+        if (r[3] != s0 || t1 <= t0) { whole = false; break; }
+        const unsigned int p = (unsigned int)(g % P);
+        if (t0 < first[p]) first[p] = t0;
+        if (t1 > last[p]) last[p] = t1;
+        tiles[p] = n;
+    }
+    if (whole) {
+        double speed[P], sum = 0.0;
+        for (unsigned int p = 0; p < P; ++p) {
+            speed[p] = tiles[p] > 0 ? (double)tiles[p] / (double)(last[p] - first[p]) : 0.0;
+            sum += speed[p];
+        }
+        bool sane = sum > 0.0;
+        for (unsigned int p = 0; sane && p < P; ++p) sane = speed[p] * P > 0.5 * sum && speed[p] * P < 2.0 * sum;
+        if (sane) {
+            // half way from the old cut to the one these speeds ask for, no part's range more than a fifth off the mean
+            double total = 0.0;
+            for (unsigned int p = 0; p < P; ++p) {
+                double s = 0.5 * b->share[p] + 0.5 * (speed[p] * P / sum);
+                s = s < 0.8 ? 0.8 : s > 1.2 ? 1.2 : s;
+                b->share[p] = s;
+                total += s;
+            }
+            for (unsigned int p = 0; p < P; ++p) b->share[p] *= P / total;
+        }
+        b->seen = s0;
+        if (const char *dbg = std::getenv("SONO_BALANCE_DEBUG"); dbg && dbg[0] == '1') {
+            std::fprintf(stderr, "tile balance, launch %llu: part times (us)", s0);
+            for (unsigned int p = 0; p < P; ++p) std::fprintf(stderr, " %.1f", (double)(last[p] - first[p]) * 0.01);
+            std::fprintf(stderr, "; next shares");
+            for (unsigned int p = 0; p < P; ++p) std::fprintf(stderr, " %.4f", b->share[p]);
+            std::fprintf(stderr, "\n");
+        }
+    }
+    double cum = 0.0;
+    it.part_begin[0] = 0;
+    for (unsigned int p = 0; p + 1 < P; ++p) {
+        cum += b->share[p];
+        unsigned long long edge = (unsigned long long)((double)it.n_tiles * cum / P + 0.5);
+        if (edge < it.part_begin[p]) edge = it.part_begin[p];
+        if (edge > it.n_tiles) edge = it.n_tiles;
+        it.part_begin[p + 1] = (unsigned int)edge;
+    }
+    it.part_begin[P] = (unsigned int)it.n_tiles;
+    it.parts = P;
+    it.feedback = b->feedback;
+    it.stamp = ++b->stamp;
+}
 
 bool tile_supports(int mode, const StftArgs &a, const TileTables &t)
 {

@@ -323,7 +323,18 @@ struct TileIter {
     unsigned long long n_tiles;        // tiles of the launch
     const RaggedStream *streams;       // ragged: one per stream (device memory); nullptr for a uniform batch
     const unsigned int *tile_stream;   // ragged: stream of every tile (device memory)
+    // The launch is cut into one contiguous range of tiles per XCD ("part": workgroup b belongs to part b % parts).
+    // part_begin[p] .. part_begin[p + 1] is part p's range when `parts` is not 0 (then it is the number of parts the
+    // kernel will find, kTileParts, and n_tiles fits 32 bits); parts = 0: equal ranges, n_tiles * p / parts.
+    unsigned int parts;
+    unsigned int part_begin[9];
+    // Where every workgroup leaves {first start, last end (100 MHz ticks), tiles of its part, `stamp`} when its last
+    // wave is done (host memory the device can write; nullptr: nowhere): what the next launch's ranges are cut by.
+    unsigned long long *feedback;
+    unsigned long long stamp;
 };
+constexpr unsigned int kTileParts = 8;      // XCDs of the chip
+constexpr unsigned int kFeedbackWords = 4;  // 64-bit words per workgroup in TileIter::feedback
 // Where one tile reads and writes.
 struct TileRef {
     const float *xs;                   // sample 0 of the tile's stream (f32 input)

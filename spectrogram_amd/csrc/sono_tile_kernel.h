@@ -50,7 +50,6 @@ struct Occupancy {
     static constexpr int kWavesPerSimd = LOG_R2 == 6 ? SONO_WIDE_WPS : SONO_WPS;
     static constexpr int kBlocksPerCU = 4 * kWavesPerSimd / kWavesPerBlock;
 };
-constexpr int kXcds = 8;
 
 // Values per lane and pass (log2) of the geometry that serves fft size N.
 #ifndef SONO_WIDE_FROM
@@ -62,6 +61,7 @@ constexpr int tile_log_r2(unsigned int N) { return N >= SONO_WIDE_FROM ? 6 : 5; 
 // shader-clock cycles it spends in each phase; tools/kbench prints the totals.
 #ifdef SONO_EXP_STAMPS
 __device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_wg_ends[4 * 2048];     // per workgroup: first start, last end (100 MHz clock), XCC id, tiles done
 #define STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc[i] += now_ - last; last = now_; } while (0)
 #else
 #define STAMP(i) do { } while (0)
@@ -171,14 +171,15 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
     __shared__ __align__(16) float s_img[kWavesPerBlock * G::REGION];
     __shared__ __align__(16) float2 s_tw[G::TW_ROWS * R2];
     __shared__ __align__(16) float s_win[G::N];
-    __shared__ unsigned int s_next;
+    __shared__ unsigned int s_next, s_done;
     __shared__ float s_meta[kWavesPerBlock * tile::kMetaFloats];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = threadIdx.x; i < G::TW_ROWS * R2; i += blockDim.x) s_tw[i] = tw_rows[i];
     for (int i = threadIdx.x; i < G::N; i += blockDim.x) s_win[i] = PCM ? a.window[i] * (1.0f / 32768.0f) : a.window[i];
-    if (threadIdx.x == 0) s_next = 0u;
+    if (threadIdx.x == 0) { s_next = 0u; s_done = 0u; }
+    const unsigned long long wg_start = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
 
     float *img = s_img + wave * G::REGION;
@@ -191,11 +192,12 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
     // claims the next unclaimed tile from an LDS counter: the SIMD favours its
     // oldest wave, and with a fixed split the youngest waves would still be
     // working long after the oldest had left.
-    const unsigned int parts = gridDim.x < (unsigned int)kXcds ? gridDim.x : (unsigned int)kXcds;
+    const unsigned int parts = gridDim.x < tile::kTileParts ? gridDim.x : tile::kTileParts;
     const unsigned int part = blockIdx.x % parts, lb = blockIdx.x / parts;
     const unsigned int blocks_in_part = (gridDim.x - part + parts - 1) / parts;
-    const unsigned long long t_first = it.n_tiles * part / parts;
-    const unsigned long long t_count = it.n_tiles * (part + 1) / parts - t_first;
+    // The ranges are equal unless the launcher has cut them by what the parts managed last time (TileIter::part_begin).
+    const unsigned long long t_first = it.parts == parts ? (unsigned long long)it.part_begin[part] : it.n_tiles * part / parts;
+    const unsigned long long t_count = (it.parts == parts ? (unsigned long long)it.part_begin[part + 1] : it.n_tiles * (part + 1) / parts) - t_first;
     tile::TileLane<LOG_R1, LOG_R2, MODE, HOPQ, PCM> L(a, lane);
     auto claim = [&]() -> unsigned long long {          // -> index of the claimed tile inside the range
         unsigned int c = 0;
@@ -210,6 +212,7 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime(), rt_begin = __builtin_amdgcn_s_memrealtime();
     unsigned long long last = t_begin;
+    unsigned int tiles_done = 0;
 #endif
     while (cur < t_count) {
         const unsigned long long t = t_first + cur;
@@ -265,6 +268,9 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
         wave_lds_fence();
         __builtin_amdgcn_s_setprio(0);
         STAMP(4);
+#ifdef SONO_EXP_STAMPS
+        ++tiles_done;
+#endif
         cur = nxt;
     }
 #ifdef SONO_EXP_STAMPS
@@ -278,8 +284,28 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
         atomicMin(&g_stamps[13], rt_begin);
         atomicMax(&g_stamps[14], rt_begin);
         atomicMin(&g_stamps[15], __builtin_amdgcn_s_memrealtime());
+        if (blockIdx.x < 2048) {
+            unsigned int xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            atomicMin(&g_wg_ends[4 * blockIdx.x], rt_begin);
+            atomicMax(&g_wg_ends[4 * blockIdx.x + 1], __builtin_amdgcn_s_memrealtime());
+            g_wg_ends[4 * blockIdx.x + 2] = xcc & 15;
+            atomicAdd(&g_wg_ends[4 * blockIdx.x + 3], (unsigned long long)tiles_done);
+        }
     }
 #endif
+    if (it.feedback) {
+        // The workgroup's last wave reports when the workgroup began and ended (TileIter::feedback).
+        unsigned int done = 0;
+        if (lane == 0) done = atomicAdd(&s_done, 1u);
+        if (lane == 0 && done == (unsigned int)kWavesPerBlock - 1u) {
+            unsigned long long *fb = it.feedback + (size_t)blockIdx.x * tile::kFeedbackWords;
+            __hip_atomic_store(fb + 0, wg_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(fb + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(fb + 2, t_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(fb + 3, it.stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     if (MODE == MODE_U8 && a.gmax_bits) {
         // wave-wide maximum of |2X|^2, then one atomic per wave on the magnitude's bit pattern
         float m = L.run_max;
@@ -289,7 +315,7 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
 }
 
 template <int LOG_R1, int LOG_R2, int MODE>
-hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, hipStream_t stream)
+hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, TileBalance *balance, hipStream_t stream)
 {
     using G = tile::Geo<LOG_R1, LOG_R2>;
     constexpr int kWavesPerBlock = Occupancy<LOG_R1, LOG_R2>::kWavesPerBlock;
@@ -317,6 +343,7 @@ hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, const RaggedPlan
     const unsigned long long resident = (unsigned long long)cus * kBlocksPerCU;
     if (blocks > resident) blocks = resident;
     const dim3 grid((unsigned int)blocks), block(64 * kWavesPerBlock);
+    tile_balance_plan(balance, blocks, resident, kWavesPerBlock, it);
     // The hops that let frame B reuse frame A's loads: a quarter frame (75 % overlap) for
     // the row and magnitude modes, half a frame (the fast scan's 50 %) for the band mode.
     // SONO_FORCE_ANY_HOP=1 (read per launch) takes the any-hop form regardless: the tests compare the two.
@@ -342,16 +369,16 @@ hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, const RaggedPlan
 }
 
 template <int MODE>
-hipError_t launch_mode(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, hipStream_t stream)
+hipError_t launch_mode(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, TileBalance *balance, hipStream_t stream)
 {
     switch (a.N) {
 #ifndef SONO_EXP_ONLY_1024      // tools/expbuild.sh: quicker experimental builds
-    case 4096: return launch_one<6, 6, MODE>(a, tw_rows, plan, stream);
-    case 2048: return launch_one<5, 6, MODE>(a, tw_rows, plan, stream);
-    case 512: return launch_one<9 - tile_log_r2(512), tile_log_r2(512), MODE>(a, tw_rows, plan, stream);
-    case 256: return launch_one<3, 5, MODE>(a, tw_rows, plan, stream);
+    case 4096: return launch_one<6, 6, MODE>(a, tw_rows, plan, balance, stream);
+    case 2048: return launch_one<5, 6, MODE>(a, tw_rows, plan, balance, stream);
+    case 512: return launch_one<9 - tile_log_r2(512), tile_log_r2(512), MODE>(a, tw_rows, plan, balance, stream);
+    case 256: return launch_one<3, 5, MODE>(a, tw_rows, plan, balance, stream);
 #endif
-    case 1024: return launch_one<10 - tile_log_r2(1024), tile_log_r2(1024), MODE>(a, tw_rows, plan, stream);
+    case 1024: return launch_one<10 - tile_log_r2(1024), tile_log_r2(1024), MODE>(a, tw_rows, plan, balance, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -56,6 +56,36 @@ def test_spot_frames_against_oracle(hour):
     assert nd <= max(2, parity.U8_MAX_FRACTION * nt)
 
 
+def test_adaptive_ranges_change_nothing(hour, monkeypatch):
+    # A launch of this size is cut into one range of tiles per XCD, and the engine sizes the ranges by how fast each XCD
+    # got through the launch before (the workgroups report their times); SONO_FIXED_TILES=1 (read per launch) keeps
+    # the ranges equal.  Where the cuts fall must not show anywhere: rows, peaks and the global maximum equal bit for
+    # bit, for the whole hour and for a ragged count of frames, launch after launch while the cut adapts.
+    torch = hour["torch"]
+    for frames in (hour["F"], 1234567):
+        n = (frames - 1) * H + N
+        res = []
+        for fixed in (True, False, False, False):
+            if fixed:
+                monkeypatch.setenv("SONO_FIXED_TILES", "1")
+            else:
+                monkeypatch.delenv("SONO_FIXED_TILES", raising=False)
+            out = torch.zeros(frames * 512, dtype=torch.uint8, device="cuda")
+            pb = torch.zeros(frames, dtype=torch.int16, device="cuda")
+            pm = torch.zeros(frames, dtype=torch.float32, device="cuda")
+            gm = torch.zeros(1, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            hour["e"].stft_u8_dev(hour["x"].data_ptr(), 1, n, n, V, 20.0, 80.0, out.data_ptr(), pb.data_ptr(), pm.data_ptr(), gm.data_ptr())
+            hour["e"].synchronize()
+            res.append((out, pb, pm, gm))
+        monkeypatch.delenv("SONO_FIXED_TILES", raising=False)
+        for other in res[1:]:
+            for a, b in zip(res[0], other):
+                assert torch.equal(a, b)
+        assert torch.equal(res[0][0][: 512 * 1000], hour["out"].reshape(-1)[: 512 * 1000])
+        del res
+
+
 def test_global_max_is_max_of_frame_peaks(hour):
     torch = hour["torch"]
     gmax = hour["gm"].view(torch.float32)[0].item()

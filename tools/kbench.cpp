@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 #include "../include/sonostft.h"
@@ -49,13 +50,19 @@ int main(int argc, char **argv)
     hipStream_t s; CHECK(hipStreamCreate(&s));
     sono_batch b{x, 1, n, n};
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) if (u8dev(e, &b, V, 20.0f, 80.0f, out, pb, pm, gm, s)) { printf("launch: %s\n", last_error()); return 1; }
-    CHECK(hipStreamSynchronize(s));
+    // warm-up launches, each waited for: an engine that adapts to what it measured on the launch before gets to do so
+    for (int i = 0; i < 4; ++i) {
+        if (u8dev(e, &b, V, 20.0f, 80.0f, out, pb, pm, gm, s)) { printf("launch: %s\n", last_error()); return 1; }
+        CHECK(hipStreamSynchronize(s));
+    }
     std::vector<float> ms(reps);
     typedef void (*stamps_fn0)(unsigned long long *);
     stamps_fn0 st0 = (stamps_fn0)dlsym(h, "sono_debug_stamps");
+    typedef void (*wg_fn)(unsigned long long *, int);
+    wg_fn wg = (wg_fn)dlsym(h, "sono_debug_wg_ends");
+    std::vector<unsigned long long> wgv(4 * 2048);
     for (int i = 0; i < reps; ++i) {
-        if (st0 && i == reps - 1) { unsigned long long junk[16]; st0(junk); }
+        if (st0 && i == reps - 1) { unsigned long long junk[16]; st0(junk); if (wg) wg(wgv.data(), 2048); }
         CHECK(hipEventRecord(e0, s));
         u8dev(e, &b, V, 20.0f, 80.0f, out, pb, pm, gm, s);
         CHECK(hipEventRecord(e1, s));
@@ -72,6 +79,21 @@ int main(int argc, char **argv)
         printf("  last launch: longest wave %.0f cycles; first start -> last start %.1f us, first end -> last end %.1f us, first start -> last end %.1f us\n",
                (double)v[11], (v[14] - v[13]) * 0.01, (v[12] - v[15]) * 0.01, (v[12] - v[13]) * 0.01);
         (void)launches;
+    }
+    if (wg) {
+        // the last launch, workgroup by workgroup: when each ended relative to the first start, by XCC
+        wg(wgv.data(), 2048);
+        unsigned long long t0 = ~0ull;
+        int groups = 0;
+        for (int i = 0; i < 2048; ++i) if (wgv[4 * i + 1]) { ++groups; if (wgv[4 * i] < t0) t0 = wgv[4 * i]; }
+        printf("workgroups %d; per XCC: groups, tiles, end of the earliest / median / latest workgroup (us after the first start)\n", groups);
+        for (unsigned long long x = 0; x < 16; ++x) {
+            std::vector<double> ends; unsigned long long tiles = 0;
+            for (int i = 0; i < 2048; ++i) if (wgv[4 * i + 1] && wgv[4 * i + 2] == x) { ends.push_back((wgv[4 * i + 1] - t0) * 0.01); tiles += wgv[4 * i + 3]; }
+            if (ends.empty()) continue;
+            std::sort(ends.begin(), ends.end());
+            printf("  xcc %llu: %zu groups %llu tiles  ends %.1f / %.1f / %.1f\n", x, ends.size(), tiles, ends.front(), ends[ends.size() / 2], ends.back());
+        }
     }
     float best = ms[0], sum = 0;
     for (float m : ms) { best = m < best ? m : best; sum += m; }
