@@ -28,6 +28,11 @@ for f in find("trace/**/*kernel_trace.csv"):
     if d:
         r0 = rows[0]
         print(f"dispatches {len(d)}  avg {sum(d)/len(d)/1e6:.4f} ms  min {min(d)/1e6:.4f} ms  max {max(d)/1e6:.4f} ms")
+        # bench.py's ms_per_step is the mean of the steps after the warm-up: the trace pass runs 3 + 20
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        t = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows][3:]
+        if t:
+            print(f"the {len(t)} dispatches after the first three (bench.py's timed steps): avg {sum(t)/len(t)/1e6:.4f} ms")
         print({k: r0[k] for k in r0 if k in ("Kernel_Name", "Workgroup_Size_X", "Grid_Size_X", "VGPR_Count", "Accum_VGPR_Count",
                                             "SGPR_Count", "LDS_Block_Size", "Scratch_Size")})
 print()
