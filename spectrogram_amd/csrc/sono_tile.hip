@@ -171,3 +171,30 @@ hipError_t launch_stft_tile_ragged(int mode, const StftArgs &a, const TileTables
 }
 
 }  // namespace sono
+
+// Test hook (not part of the C ABI of include/sonostft.h): runs tile_balance_plan on records the caller supplies, so that
+// the host logic -- which reports are taken up, how the cut moves, that the ranges tile the launch -- can be checked
+// without a GPU.  records: blocks x 4 words {start, end, tiles, stamp} as the kernel leaves them; share: 8 values in and
+// out; stamp / seen: the engine's counters in and out; part_begin: 9 values out.  Returns the number of parts (0: equal ranges).
+extern "C" unsigned int sono_debug_tile_balance(const unsigned long long *records, unsigned int blocks, unsigned int resident,
+                                                unsigned int waves_per_block, unsigned long long n_tiles, double *share,
+                                                unsigned long long *stamp, unsigned long long *seen, unsigned int *part_begin)
+{
+    std::vector<unsigned long long> fb((size_t)sono::TileBalance::kMaxGroups * sono::tile::kFeedbackWords, 0ull);
+    if (blocks <= sono::TileBalance::kMaxGroups)
+        std::memcpy(fb.data(), records, (size_t)blocks * sono::tile::kFeedbackWords * sizeof(unsigned long long));
+    sono::TileBalance b;
+    b.feedback = fb.data();
+    for (int p = 0; p < 8; ++p) b.share[p] = share[p];
+    b.stamp = *stamp;
+    b.seen = *seen;
+    sono::tile::TileIter it;
+    it.n_tiles = n_tiles;
+    sono::tile_balance_plan(&b, blocks, resident, waves_per_block, it);
+    for (int p = 0; p < 8; ++p) share[p] = b.share[p];
+    for (int p = 0; p < 9; ++p) part_begin[p] = it.part_begin[p];
+    *stamp = b.stamp;
+    *seen = b.seen;
+    return it.parts;
+}
+
