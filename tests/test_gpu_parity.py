@@ -115,6 +115,73 @@ def test_every_window_at_every_size_against_oracle(N, V, window, alpha):
     e.free()
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_random_configurations_against_oracle(seed):
+    """Seeded random draws of everything the entry points take -- fft size, overlap (0 ... N-1), length (shorter than a
+    frame, exactly one frame, ragged ends), window and alpha, gain and range, signal level (down to 1e-6 and up to 30),
+    signal kind -- each against the C oracle with the project's tolerances.  A peak bin may differ from the oracle's only
+    where the oracle's own magnitudes at the two bins agree to 1e-6: two FFTs then rank them by rounding noise."""
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice([256, 512, 1024, 2048, 4096]))
+    V = int(rng.choice([0, N // 2, N - N // 4, N - 32, int(N * 0.95), int(rng.integers(0, N)), N - 1]))
+    H = N - V
+    frames = int(rng.integers(0, 40)) if H >= 8 else int(rng.integers(0, 400))
+    n = 0 if frames == 0 and rng.random() < 0.3 else max(0, N + (frames - 1) * H + int(rng.integers(0, H))) if frames else int(rng.integers(1, N))
+    window = str(rng.choice(["hann", "hamming", "blackman", "bartlett", "bartlettHann", "cosine", "gauss", "lanczos", "rectangular", "triangular"]))
+    alpha = None if rng.random() < 0.7 else float(rng.uniform(0.05, 0.5))
+    gain, rng_db = float(rng.choice([20.0, 0.0, 35.5, -10.0])), float(rng.choice([80.0, 60.0, 100.0, 45.25]))
+    level = float(10.0 ** rng.uniform(-6, 1.5))
+    t = np.arange(n)
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        x = np.sin(rng.uniform(0.01, 3.0) * t + rng.uniform(0, 1e-4) * t * t) + 0.02 * rng.standard_normal(n)
+    elif kind == 1:
+        x = rng.standard_normal(n)
+    elif kind == 2:
+        x = 0.001 * rng.standard_normal(n)
+        if n:
+            x[rng.integers(0, n, size=max(1, n // 997))] += 1.0          # clicks
+    else:
+        x = np.sin(0.7 * t) * (t % (3 * H + 1) < H) + 1e-4 * rng.standard_normal(n)      # bursts next to quiet frames
+    x = (level * x).astype(np.float32)
+    what = f"seed {seed}: N={N} V={V} n={n} {window} alpha={alpha} gain={gain} range={rng_db} level={level:.3g} kind={kind}"
+    o = so.OracleEngine(N, window, alpha)
+    e = sa.SpectrogramEngine(N, window, alpha)
+    ref_mag = np.asarray(o.compute_spectrogram(x, V))
+    mag = e.compute_spectrogram(x, V)
+    assert mag.shape == ref_mag.shape == (sa.frames_for(n, N, V) * (N // 2),), what
+    parity.check_mag(mag, ref_mag, N // 2, what)
+    u8 = e.compute_spectrogram_u8(x, V, gain, rng_db)
+    ref = np.asarray(o.compute_spectrogram_u8(x, V, gain, rng_db))
+    nd, nt = parity.u8_diff(u8, ref, what)                   # never more than 1 LSB, wherever
+    if nt:
+        # the 0.1 % bound counts the bins within 80 dB of their frame's peak: further down two f32 FFTs differ by
+        # their own rounding (1e-7 of the frame's peak), which a range of 100 dB can see
+        rows = ref_mag.reshape(-1, N // 2)
+        live = rows >= rows.max(axis=1, keepdims=True) * 1e-4
+        nd = int(((u8.reshape(rows.shape) != ref.reshape(rows.shape)) & live).sum())
+        assert nd <= max(2, parity.U8_MAX_FRACTION * live.sum()), what
+    gmax = o.get_global_max()
+    assert abs(e.get_global_max() - gmax) <= 1e-6 * gmax, what
+    for ratio in (0.0, 0.4):
+        pk, rpk = e.get_peaks(ratio), np.asarray(o.get_peaks(ratio))
+        assert pk.shape == rpk.shape, what
+        if pk.size:
+            rows = ref_mag.reshape(-1, N // 2)
+            keep = rpk != 0xFFFF
+            # a frame whose peak sits within 1e-6 of the threshold may be kept by one and dropped by the other
+            edge = np.abs(rows.max(axis=1) - np.float32(gmax * ratio)) <= 1e-6 * gmax
+            assert np.array_equal((pk != 0xFFFF) | edge, keep | edge), what
+            for f in np.flatnonzero((pk != rpk) & keep & (pk != 0xFFFF)):
+                assert abs(rows[f, pk[f]] - rows[f, rpk[f]]) <= 1e-6 * rows[f].max(), f"{what}: frame {f}: bins {pk[f]} / {rpk[f]}"
+        pm, rpm = e.get_peak_magnitudes(ratio), np.asarray(o.get_peak_magnitudes(ratio))
+        assert pm.shape == rpm.shape, what
+        if pm.size:
+            both = (pm > 0) & (rpm > 0)
+            assert np.all(np.abs(pm[both] - rpm[both]) <= 1e-6 * gmax + 1e-6 * rpm[both]), what
+    e.free()
+
+
 def test_empty_inputs_and_errors(kernel_path):
     e = sa.SpectrogramEngine(1024, "hann")
     assert len(e.get_peaks(0.4)) == 0 and len(e.get_peak_magnitudes(0.0)) == 0      # before any u8 call
