@@ -454,8 +454,8 @@ struct TileLane {
             static_for<0, G::R1>([&](auto n_) {
                 constexpr int n1 = decltype(n_)::value;
 #ifdef SONO_EXP_NOLOAD      // diagnostic build: what the kernel costs without its sample loads
-                xa[jj * G::R1 + n1] = (float)(lane + n1) * 1e-3f + (float)fa * 1e-9f;
-                if constexpr (n1 >= OWN_B) xb[jj * G::R1 + n1] = (float)(lane - n1) * 1e-3f + (float)fb * 1e-9f;
+                xa[jj * G::R1 + n1] = (float)(lane + n1) * 1e-3f + (float)(j + ta) * 1e-9f;
+                if constexpr (n1 >= OWN_B) xb[jj * G::R1 + n1] = (float)(lane - n1) * 1e-3f + (float)(j + tb) * 1e-9f;
 #else
                 xa[jj * G::R1 + n1] = pa[R2 * n1];
                 if constexpr (n1 >= OWN_B) xb[jj * G::R1 + n1] = pb[R2 * n1];
