@@ -303,7 +303,7 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
             __hip_atomic_store(fb + 0, wg_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(fb + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(fb + 2, t_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(fb + 3, it.stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(fb + 3, it.stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // last: a record with this launch's stamp is whole
         }
     }
     if (MODE == MODE_U8 && a.gmax_bits) {
