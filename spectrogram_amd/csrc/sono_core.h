@@ -167,7 +167,11 @@ template <bool FLOOR = true, int BYTE = 0>
 SONO_HD unsigned int quantise(float p, float q_a, float q_c, float q_floor, unsigned int word = 0u)
 {
     const float pf = FLOOR ? max_nonneg(p, q_floor) : p;
+#ifdef SONO_EXP_NOLOG       // diagnostic build: what the kernel costs without its logarithms (wrong codes)
+    return cvt_pk_u8<BYTE>(__builtin_fmaf(q_a, pf, q_c), word);
+#else
     return cvt_pk_u8<BYTE>(__builtin_fmaf(q_a, fast_log2(pf), q_c), word);
+#endif
 }
 
 // Ordering key for "largest magnitude, lowest bin on ties" (lib.rs:370-378):

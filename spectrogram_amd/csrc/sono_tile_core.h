@@ -674,6 +674,9 @@ struct TileLane {
         constexpr int NB = R2 / 4, B = LOG_R2 == 6 ? (LOG_R1 == 6 ? SONO_EPI_BATCH_4096 : SONO_EPI_BATCH_WIDE) : LOG_R1 == 5 ? SONO_EPI_BATCH : SONO_EPI_BATCH_512;
         static_assert(NB % B == 0, "the epilogue batch must divide the reads per lane");
         if (!valid) return;          // lanes of frames past the end of the stream have nothing to store
+#ifdef SONO_EXP_NOSTORE
+        unsigned int nostore_sum = 0;
+#endif
         const float qa = in_vgpr(a.q_a), qc = in_vgpr(a.q_c);
         SONO_EPILOGUE_UNROLL
         for (int m0 = 0; m0 < NB; m0 += B) {
@@ -696,6 +699,9 @@ struct TileLane {
                         packed = quantise<FLOOR, 1>(p[1], qa, qc, a.q_floor, packed);
                         packed = quantise<FLOOR, 2>(p[2], qa, qc, a.q_floor, packed);
                         packed = quantise<FLOOR, 3>(p[3], qa, qc, a.q_floor, packed);
+#ifdef SONO_EXP_NOSTORE     // diagnostic build: what the kernel costs without its row stores (the codes stay alive in a sum that is never written)
+                        if ((nostore_sum += packed) == 0x12345679u && best_m == 77)
+#endif
                         *(unsigned int *)((a.out_u8 + tile_elem) + ((size_t)lane_elem + 2 * G::R1 * (m0 + i))) = packed;
                     }
                     const float top = max_of_4(p[0], p[1], p[2], p[3]);
