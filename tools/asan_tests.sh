@@ -14,7 +14,7 @@ RT="$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)"
 export SONO_LIB_PATH="$ROOT/spectrogram_amd/lib/libsonostft_asan.so" SONO_EMUL_LIB="$ROOT/tests/host_emul/libemul_asan.so"
 export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1
 LD_PRELOAD="$RT${LD_PRELOAD:+:$LD_PRELOAD}" python -m pytest -x -q tests/test_measure_host.py tests/test_framing_host.py tests/test_host_emul.py \
-    tests/test_abi_cpu.py tests/test_wav.py tests/test_guano.py tests/test_plugin_host.py -m "not gpu" "$@"
+    tests/test_abi_cpu.py tests/test_tile_balance.py tests/test_wav.py tests/test_guano.py tests/test_plugin_host.py -m "not gpu" "$@"
 
 # the Node addon (napi/sonostft_napi.c) the same way: built with clang and the sanitizers against the sanitizer build of
 # the library, loaded into node with the same runtime preloaded; its CPU tests cover the export surface, argument
