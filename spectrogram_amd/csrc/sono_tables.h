@@ -20,14 +20,14 @@ inline std::vector<float2> make_twiddles(unsigned int len, unsigned int count)
 }
 
 // Inter-pass twiddles of the tiled kernel for N = R1*R2 (R2 = 32 or 64): one row of
-// R2 entries W_N^(n2*k1) per k1.  R1 < 64: rows k1 = 1..R1/2.  R1 = 64: rows
+// R2 entries W_N^(n2*k1) per k1: rows k1 = 1..R1/2.  R1 = R2 = 64: rows
 // k1 = 1..R1/4, then one row with k1 = R1/2 (the kernel derives the rows in
 // between from these).
 inline std::vector<float2> make_tile_twiddles(unsigned int N, unsigned int r2)
 {
     const unsigned int r1 = N / r2, half = r1 / 2;
     std::vector<unsigned int> ks;
-    if (r1 == 64) {
+    if (r1 == 64 && r2 == 64) {
         for (unsigned int k1 = 1; k1 <= half / 2; ++k1) ks.push_back(k1);
         ks.push_back(half);
     } else {

@@ -6,6 +6,16 @@
 
 namespace sono {
 
+// Values per lane and pass (log2) of the geometry that serves fft size N: 32 below SONO_WIDE_FROM (four waves per
+// SIMD), 64 from there on (two).  fft 2048 is 32 x 64 by default.  -DSONO_WIDE_FROM=4096 builds it as 64 x 32 (one
+// frame per lane in pass 1, see "split" in sono_tile_core.h): measured 2.5 % faster at hops that are not a quarter
+// frame and 5 % slower at 75 % overlap, where the 32 x 64 form shares loads between the frames of a pair and the
+// 64 x 32 form cannot (tools/kbench: 3.35 against 3.18 ms per hour of audio; 2.52 against 2.59 ms at 95 %).
+#ifndef SONO_WIDE_FROM
+#define SONO_WIDE_FROM 2048
+#endif
+constexpr int tile_log_r2(unsigned int N) { return N >= SONO_WIDE_FROM ? 6 : 5; }
+
 // Device table private to the tiled kernel: the inter-pass twiddle rows of
 // make_tile_twiddles(N) (empty for fft sizes the kernel does not cover).
 // What an engine knows about how fast the chip's XCDs get through their ranges of a launch.  The tiled kernel cuts

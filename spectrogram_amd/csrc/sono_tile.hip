@@ -18,10 +18,6 @@ hipError_t launch_tile_band(const StftArgs &a, const float2 *tw_rows, const Ragg
 
 namespace {
 
-#ifndef SONO_WIDE_FROM
-#define SONO_WIDE_FROM 2048
-#endif
-constexpr int tile_log_r2(unsigned int N) { return N >= SONO_WIDE_FROM ? 6 : 5; }
 
 hipError_t launch_any(int mode, const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream)
 {
@@ -154,7 +150,7 @@ unsigned int tile_frames_per_wave(unsigned int N)
 {
     switch (N) {
     case 4096: return tile::Geo<6, 6>::FPW;
-    case 2048: return tile::Geo<5, 6>::FPW;
+    case 2048: return tile::Geo<11 - tile_log_r2(2048), tile_log_r2(2048)>::FPW;
     case 1024: return tile::Geo<10 - tile_log_r2(1024), tile_log_r2(1024)>::FPW;
     case 512: return tile::Geo<9 - tile_log_r2(512), tile_log_r2(512)>::FPW;
     case 256: return tile::Geo<3, 5>::FPW;

@@ -2,8 +2,9 @@
 //
 // One wave64 transforms FPW = 128/R1 real frames of N = R1*R2 samples, two frames
 // ("a pair": A = 2q, B = 2q+1) at a time, with a two-pass real-input FFT that
-// never forms the redundant half of the spectrum.  R2 = 32 with R1 = 32, 16, 8
-// serves N = 1024, 512, 256; R2 = 64 with R1 = 32, 64 serves N = 2048, 4096.
+// never forms the redundant half of the spectrum.  R2 = 32 with R1 = 64, 32, 16, 8
+// serves N = 2048, 1024, 512, 256; R2 = 64 with R1 = 64 serves N = 4096 (and, as an
+// alternative that the tests keep alive, R1 = 32 serves N = 2048).
 // Written out for R2 = 32:
 //
 //   X[k1 + R1*k2] = sum_{n2<32} W_32^(n2*k2) * W_N^(n2*k1) * Y[k1][n2],
@@ -43,6 +44,13 @@
 //   hop     With hop = N/4 or N/2 (HOPQ = 1, 2) frame B's first samples ARE frame
 //           A's samples R1/4 (R1/2) rows further down the same column, so only
 //           B's last R1/4 (R1/2) rows are loaded; HOPQ = 0 loads both frames whole.
+//
+//   split   R1 = 64 with R2 = 32 (N = 2048): a lane's 64 registers hold ONE frame's column, so
+//           the two frames of the pair sit in the two halves of the wave during pass 1
+//           (lanes 0..31 frame A, 32..63 frame B) and every frame is loaded whole.  What the
+//           shared rows need of the other frame (Y[0], Y[R1/2], the maxima for the scale)
+//           crosses between the halves in the caller (v_permlane32_swap in the kernel).
+//           Everything after pass 1 is the same code: 64 rows of 32 columns.
 //
 // Everything is __host__ __device__: tests/host_emul runs the passes lane by
 // lane against an ordinary array standing in for LDS.
@@ -262,7 +270,8 @@ struct Geo {
     static constexpr int HALF = R1 / 2;        // the Nyquist row of pass 1; lanes per frame in the epilogue
     static constexpr int PPW = 64 / R1;        // frame pairs per wave
     static constexpr int FPW = 2 * PPW;        // frames per wave
-    static constexpr int JPL = R2 / R1;        // pass-1 jobs (pairs) per lane
+    static constexpr bool SPLIT = R1 > R2;     // pass 1 holds one frame per lane, the pair's frames in the wave's two halves
+    static constexpr int JPL = SPLIT ? 1 : R2 / R1;   // pass-1 jobs (pairs) per lane
     // Floats per frame in the power image.  The pad puts the frames that one 32-lane
     // group of pass 2 stores to on disjoint banks (ds_write_b32: 32 banks).  The
     // epilogue's 16-byte reads go by 64 banks in 16-lane groups that take lanes from
@@ -275,7 +284,7 @@ struct Geo {
     // k1 = 1..R1/2.  Folded (R1 = 64, where the full table would not fit beside
     // eight wave regions): rows k1 = 1..R1/4, then one row of W_N^(n2*R1/2); the
     // rows above R1/4 come from W^(n2*(R1/2-k)) = W^(n2*R1/2) * conj W^(n2*k).
-    static constexpr bool TW_FOLD = R1 == 64;
+    static constexpr bool TW_FOLD = R1 == 64 && R2 == 64;
     static constexpr int TW_ROWS = TW_FOLD ? HALF / 2 + 1 : HALF;
     // A wave's LDS region is first the exchange image (64 rows of R2 floats), then
     // the power image (FPW rows of PROW floats).
@@ -382,9 +391,11 @@ struct TileLane {
     // Rows by which frame B's column lies below frame A's (0: not known at compile time).
     static constexpr int SHIFT = HOPQ == 1 ? G::R1 / 4 : HOPQ == 2 ? G::R1 / 2 : 0;
     static constexpr int OWN_B = SHIFT ? G::R1 - SHIFT : 0;   // first row of frame B that is loaded for B itself
+    static constexpr bool SPLIT = G::SPLIT;
     const StftArgs &a;
     int lane;
-    float xa[R2], xb[R2];              // samples of frames A / B of job jj at [jj*R1 + n1] (B: rows >= OWN_B only)
+    // samples of frames A / B of job jj at [jj*R1 + n1] (B: rows >= OWN_B only); SPLIT: xa = this lane's frame, row n1 at [n1]
+    float xa[SPLIT ? G::R1 : R2], xb[SPLIT ? 1 : R2];
     float run_max;                     // running maximum of |2X|^2 over every frame this lane has finished (MODE_U8)
 
     SONO_HD TileLane(const StftArgs &args, int lane_) : a(args), lane(lane_), run_max(0.0f) {}
@@ -408,6 +419,28 @@ struct TileLane {
     {
         const unsigned int j = tr.j;
         const int h = hgroup(), n2 = col();
+        if constexpr (SPLIT) {
+            // One frame per lane: frame h of the tile's two (a frame past the end of the stream reads frame 0).
+            const unsigned int t = opaque((unsigned int)h);
+            if constexpr (PCM) {
+                const unsigned long long f = (unsigned long long)j * G::FPW + (t < tr.rem ? t : 0u);
+                const unsigned long long c = a.x16_channels, row = (unsigned long long)R2 * c;
+                const int16_t *q = a.x16 + (tr.xs_off + (unsigned int)n2 + f * a.hop) * c + a.x16_channel;
+                auto rows_at = [&](auto stride_) {
+                    constexpr int stride = decltype(stride_)::value;
+                    static_for<0, G::R1>([&](auto n_) { xa[decltype(n_)::value] = (float)q[stride * decltype(n_)::value]; });
+                };
+                if (c == 1) rows_at(ic<R2>{});
+                else if (c == 2) rows_at(ic<2 * R2>{});
+                else static_for<0, G::R1>([&](auto n_) { xa[decltype(n_)::value] = (float)q[row * decltype(n_)::value]; });
+            } else {
+                const float *base = tr.xs + (unsigned long long)j * G::FPW * a.hop;
+                const unsigned int off = t < tr.rem ? (unsigned int)n2 + t * a.hop : (unsigned int)n2;
+                const float *p = base + off;
+                static_for<0, G::R1>([&](auto n_) { xa[decltype(n_)::value] = p[R2 * decltype(n_)::value]; });
+            }
+            return;
+        }
         static_for<0, G::JPL>([&](auto jj_) {
             constexpr int jj = decltype(jj_)::value;
             if constexpr (PCM) {
@@ -563,6 +596,57 @@ struct TileLane {
             const float cr = ya[o + G::HALF], ci = yb[o + G::HALF] * sb;
             rr[o + G::HALF] = cr * tn.x - ci * tn.y;
             ri[o + G::HALF] = cr * tn.y + ci * tn.x;
+        });
+    }
+
+    // SPLIT, pass 1, first half: window and real-input DFT-R1 of this lane's column of its frame.
+    // Leaves Y in half-complex order in y and, in p, the larger of |Y[0]| and |Y[R1/2]|.
+    SONO_HD void pass1_dft_split(const float *win, float (&y)[G::R1], float &p) const
+    {
+        const int n2 = col();
+        static_for<0, G::HALF>([&](auto j_) {
+            constexpr int i = 2 * decltype(j_)::value, na = bitrev(i, LOG_R1), nb = na + G::HALF;
+            constexpr bool flip = rdft_flip<2, i, G::R1>();
+            const float wa = win[R2 * na + n2], wb = win[R2 * nb + n2];
+            const float a0 = xa[na] * wa, a1 = xa[nb];
+            y[i] = __builtin_fmaf(a1, wb, a0);
+            y[i + 1] = flip ? __builtin_fmaf(a1, wb, -a0) : __builtin_fmaf(-a1, wb, a0);
+        });
+        rdft_bitrev_in<G::R1, 4>(y);
+        pin_registers(y);
+        p = fmaxf(fabsf(y[0]), fabsf(y[G::HALF]));
+    }
+
+    // SPLIT, pass 1, second half.  a0 / b0 = Y[0] of frame A's / frame B's lane of this column, ah / bh
+    // = their Y[R1/2], pa / pb = the maxima of pass1_dft_split's p over the columns of frame A / B (all
+    // six the same in both lanes of a column).  Leaves this lane's R2 row values in rr / ri: value k1 =
+    // 1..R1/2-1 is its frame's Y[k1] * 2 W_N^(n2*k1) (row k1 of frame A, row R1/2 + k1 of frame B);
+    // value 0 is the shared row 0, Y_A[0] + i s Y_B[0], in frame A's lanes and the shared row R1/2,
+    // (Y_A[R1/2] + i s Y_B[R1/2]) * W_N^(n2*R1/2), in frame B's.
+    SONO_HD void pass1_rows_split(const float2 *tw, const float (&y)[G::R1], float a0, float b0, float ah, float bh, float pa,
+                                  float pb, float (&rr)[R2], float (&ri)[R2], float *meta) const
+    {
+        static_assert(G::HALF == R2, "one value per row and lane");
+        const int h = hgroup(), n2 = col();
+        int d = (pa > 0.0f && pb > 0.0f) ? float_exponent(pa) - float_exponent(pb) : 0;
+        d = d > 40 ? 40 : d < -40 ? -40 : d;
+        const float sb = pow2(d);
+        if (lane == 0) {
+            const float gb = pow2(-d);
+            meta[kMetaFix] = pa > 0.0f ? 1.0f : 0.0f;
+            meta[kMetaFix + 1] = pb > 0.0f ? gb * gb : 0.0f;
+        }
+        const float2 tn = tw[(G::HALF - 1) * R2 + n2];                                       // W_N^(n2*R1/2)
+        const float cr = h ? ah : a0, ci = (h ? bh : b0) * sb;
+        const float tx = h ? tn.x : 1.0f, ty = h ? tn.y : 0.0f;
+        rr[0] = cr * tx - ci * ty;
+        ri[0] = cr * ty + ci * tx;
+        static_for<1, G::HALF>([&](auto k_) {
+            constexpr int k1 = decltype(k_)::value;
+            const float2 t = tw[(k1 - 1) * R2 + n2];
+            const float ar = y[k1], ai = y[G::R1 - k1];
+            rr[k1] = ar * t.x - ai * t.y;
+            ri[k1] = ar * t.y + ai * t.x;
         });
     }
 

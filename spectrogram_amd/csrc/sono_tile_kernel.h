@@ -51,11 +51,6 @@ struct Occupancy {
     static constexpr int kBlocksPerCU = 4 * kWavesPerSimd / kWavesPerBlock;
 };
 
-// Values per lane and pass (log2) of the geometry that serves fft size N.
-#ifndef SONO_WIDE_FROM
-#define SONO_WIDE_FROM 2048
-#endif
-constexpr int tile_log_r2(unsigned int N) { return N >= SONO_WIDE_FROM ? 6 : 5; }
 
 // Diagnostic build (-DSONO_EXP_STAMPS, tools/expbuild.sh): every wave sums the
 // shader-clock cycles it spends in each phase; tools/kbench prints the totals.
@@ -158,6 +153,16 @@ __device__ __forceinline__ float column_max(float v)
     return v;
 }
 
+// {lower half's value of lane % 32, upper half's value of lane % 32}, in every lane.
+__device__ __forceinline__ float2 both_halves(float v)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    float2 o;
+    o.x = __uint_as_float(r[0]);
+    o.y = __uint_as_float(r[1]);
+    return o;
+}
+
 // RAGGED: streams of different lengths, located through TileIter's tables.
 // HOPQ: 1 / 2 = the launch's hop is N/4 / N/2 (frame B reuses frame A's loads), 0 = any hop.
 // PCM: 16-bit integer samples (StftArgs::x16) instead of f32.
@@ -223,7 +228,16 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
             float rr[R2], ri[R2];
             L.load(tr);
             STAMP(0);
-            {
+            if constexpr (G::SPLIT) {
+                float y[G::R1], p;
+                L.pass1_dft_split(s_win, y, p);
+                __builtin_amdgcn_sched_barrier(0);
+                // Frame A's lanes are the wave's lower half, frame B's the upper: each value of a column's
+                // two lanes that the other one needs comes over with one v_permlane32_swap ([0] = A's, [1] = B's).
+                const auto pm = both_halves(column_max<LOG_R2>(p));
+                const auto y0 = both_halves(y[0]), yh = both_halves(y[G::HALF]);
+                L.pass1_rows_split(s_tw, y, y0.x, y0.y, yh.x, yh.y, pm.x, pm.y, rr, ri, meta);
+            } else {
                 float ya[R2], yb[R2], pa[G::JPL], pb[G::JPL];
                 L.pass1_dft(s_win, ya, yb, pa, pb);
                 __builtin_amdgcn_sched_barrier(0);     // keeps the twiddle reads (60 registers) below the transforms
@@ -349,20 +363,22 @@ hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, const RaggedPlan
     // SONO_FORCE_ANY_HOP=1 (read per launch) takes the any-hop form regardless: the tests compare the two.
     constexpr int kHopQ = MODE == MODE_BAND ? 2 : 1;
     const char *any_hop = std::getenv("SONO_FORCE_ANY_HOP");
-    const bool q = a.hop * (kHopQ == 2 ? 2u : 4u) == (unsigned int)G::N && !(any_hop && any_hop[0] && any_hop[0] != '0');
+    // (a geometry that keeps one frame per lane in pass 1 loads every frame whole: it has the any-hop form only)
+    const bool q = !G::SPLIT && a.hop * (kHopQ == 2 ? 2u : 4u) == (unsigned int)G::N && !(any_hop && any_hop[0] && any_hop[0] != '0');
+    constexpr int kQ = G::SPLIT ? 0 : kHopQ;
     if (a.x16 && (plan || MODE == MODE_MAG)) return hipErrorInvalidValue;
     if constexpr (MODE != MODE_MAG) {
         if (a.x16) {        // 16-bit PCM input: uniform batches of the row and band modes only (tile_supports)
-            if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, kHopQ, true>), grid, block, 0, stream, a, it, tw_rows);
+            if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, kQ, true>), grid, block, 0, stream, a, it, tw_rows);
             else hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, 0, true>), grid, block, 0, stream, a, it, tw_rows);
             return hipGetLastError();
         }
     }
     if (plan) {
-        if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, true, kHopQ>), grid, block, 0, stream, a, it, tw_rows);
+        if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, true, kQ>), grid, block, 0, stream, a, it, tw_rows);
         else hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, true, 0>), grid, block, 0, stream, a, it, tw_rows);
     } else {
-        if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, kHopQ>), grid, block, 0, stream, a, it, tw_rows);
+        if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, kQ>), grid, block, 0, stream, a, it, tw_rows);
         else hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, 0>), grid, block, 0, stream, a, it, tw_rows);
     }
     return hipGetLastError();
@@ -374,7 +390,7 @@ hipError_t launch_mode(const StftArgs &a, const float2 *tw_rows, const RaggedPla
     switch (a.N) {
 #ifndef SONO_EXP_ONLY_1024      // tools/expbuild.sh: quicker experimental builds
     case 4096: return launch_one<6, 6, MODE>(a, tw_rows, plan, balance, stream);
-    case 2048: return launch_one<5, 6, MODE>(a, tw_rows, plan, balance, stream);
+    case 2048: return launch_one<11 - tile_log_r2(2048), tile_log_r2(2048), MODE>(a, tw_rows, plan, balance, stream);
     case 512: return launch_one<9 - tile_log_r2(512), tile_log_r2(512), MODE>(a, tw_rows, plan, balance, stream);
     case 256: return launch_one<3, 5, MODE>(a, tw_rows, plan, balance, stream);
 #endif

@@ -45,6 +45,18 @@ static void run_tiles(const StftArgs &a)
     for (unsigned long long t = 0; t < it.n_tiles; ++t) {
         const tile::TileRef tr = g_ragged ? tile::locate<true, G::FPW>(a, it, t) : tile::locate<false, G::FPW>(a, it, t);
         for (int l = 0; l < 64; ++l) lanes[l].load(tr);
+        if constexpr (G::SPLIT) {
+            // one frame per lane: frame A in lanes 0..31, frame B in lanes 32..63; what crosses between the halves
+            // in the kernel (v_permlane32_swap) is read from the other lane's arrays here
+            static float y[64][G::R1], p[64];
+            for (int l = 0; l < 64; ++l) lanes[l].pass1_dft_split(a.window, y[l], p[l]);
+            float pa = 0.0f, pb = 0.0f;
+            for (int l = 0; l < 32; ++l) { pa = std::fmax(pa, p[l]); pb = std::fmax(pb, p[32 + l]); }
+            for (int l = 0; l < 64; ++l) {
+                const int c = l & 31;
+                lanes[l].pass1_rows_split(tw.data(), y[l], y[c][0], y[32 + c][0], y[c][G::HALF], y[32 + c][G::HALF], pa, pb, rr[l], ri[l], meta);
+            }
+        } else {
         for (int l = 0; l < 64; ++l) lanes[l].pass1_dft(a.window, ya[l], yb[l], ma[l], mb[l]);
         for (int h = 0; h < HW; ++h)
             for (int jj = 0; jj < G::JPL; ++jj) {
@@ -53,6 +65,7 @@ static void run_tiles(const StftArgs &a)
                 for (int l = R2 * h; l < R2 * h + R2; ++l) { ma[l][jj] = va; mb[l][jj] = vb; }
             }
         for (int l = 0; l < 64; ++l) lanes[l].pass1_rows(tw.data(), ya[l], yb[l], ma[l], mb[l], rr[l], ri[l], meta);
+        }
         for (int l = 0; l < 64; ++l) lanes[l].exchange_store(rr[l], img);
         for (int l = 0; l < 64; ++l) lanes[l].exchange_load(img, re[l]);
         for (int l = 0; l < 64; ++l) lanes[l].exchange_store(ri[l], img);
@@ -137,6 +150,7 @@ extern "C" int emul_tile(int mode, const float *x, unsigned long long n_streams,
         else { if (quarter) run_tiles<L1, L2, MODE_U8, 1>(a); else run_tiles<L1, L2, MODE_U8, 0>(a); } } while (0)
     if (g_log_r2 == 6 && N == 1024) RUN(4, 6);
     else if (g_log_r2 == 6 && N == 512) RUN(3, 6);
+    else if (g_log_r2 == 5 && N == 2048) RUN(6, 5);
     else if (N == 4096) RUN(6, 6); else if (N == 2048) RUN(5, 6); else if (N == 1024) RUN(5, 5); else if (N == 512) RUN(4, 5); else RUN(3, 5);
 #undef RUN
     return 0;

@@ -181,14 +181,15 @@ def test_tile_wave_all_zero_frames_stay_exactly_zero(emul, N, V):
     assert not r["peak_mag"][:3].any()
 
 
-@pytest.mark.parametrize("N,V", [(1024, 768), (1024, 1000), (512, 256)])
-def test_tile_wave_alternative_geometry(emul, N, V):
-    # N = 1024 / 512 through the 64-column geometry (R1 = 16 / 8): same results within the tolerances
+@pytest.mark.parametrize("N,V,log_r2", [(1024, 768, 6), (1024, 1000, 6), (512, 256, 6), (2048, 1536, 5), (2048, 1948, 5), (2048, 0, 5)])
+def test_tile_wave_alternative_geometry(emul, N, V, log_r2):
+    # N = 1024 / 512 through the 64-column geometry (R1 = 16 / 8), N = 2048 as 64 x 32 (one frame per lane in
+    # pass 1, the pair's frames in the wave's two halves): same results within the tolerances
     H = N - V
     x = signal(N + 21 * H + 3, N + 2)
     x[: N + 2 * H] = 0.0
     e = so.OracleEngine(N, "hann")
-    emul.emul_tile_set_log_r2(6)
+    emul.emul_tile_set_log_r2(log_r2)
     try:
         r = run_emul(emul, "emul_tile", 0, x, N, V, e.window)
         parity.check_mag(r["mag"], e.compute_spectrogram(x, V), N // 2, f"wide tile mag N={N}")
