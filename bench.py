@@ -126,18 +126,39 @@ def end_to_end(sa, torch, engine, x_dev, n_fft, noverlap, frames, bins):
                     "kernel, download and copy-out overlapped; GBps_* = one plain copy of the same bytes from / to pinned memory"}
 
 
-def measured_traffic():
-    """HBM bytes per launch of the timed kernel from the committed rocprofv3 counter passes
-    (profiles/hbm_traffic.json, written by tools/profile_summary.py), or None."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+def library_sha256(path=None):
+    """sha256 of the library build that is being timed (the file the package loads), or None."""
+    import hashlib
+    path = path or os.environ.get("SONO_LIB_PATH") or os.path.join(ROOT, "spectrogram_amd", "lib", "libsonostft.so")
+    try:
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None
+
+
+def committed_counters(name, lib_hash, profiles_dir=None):
+    """A committed rocprofv3 counter summary (profiles/<name>, written by tools/profile_summary.py) -- but only when
+    it was taken on the very build that is being timed: the file names the library's sha256, and a file without one
+    or with another one describes some other kernel.  -> (dict or None, note or None)."""
+    path = os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), name)
     try:
         with open(path) as f:
             t = json.load(f)
-        if t.get("fft_size") == N_FFT and t.get("noverlap") == NOVERLAP and t.get("seconds") == SECONDS:
-            return t
     except (OSError, ValueError):
-        pass
-    return None
+        return None, f"no committed counters ({name})"
+    if not lib_hash or t.get("lib_sha256") != lib_hash:
+        return None, (f"profiles/{name} was measured on another build of the library (its lib_sha256 "
+                      f"{str(t.get('lib_sha256'))[:12]} is not this one's {str(lib_hash)[:12]}): not quoted")
+    return t, None
+
+
+def measured_traffic(lib_hash, profiles_dir=None):
+    """HBM bytes per launch of the timed kernel from the committed FETCH_SIZE / WRITE_SIZE passes -> (dict or None, note)."""
+    t, note = committed_counters("hbm_traffic.json", lib_hash, profiles_dir)
+    if t and not (t.get("fft_size") == N_FFT and t.get("noverlap") == NOVERLAP and t.get("seconds") == SECONDS):
+        return None, "profiles/hbm_traffic.json describes another workload"
+    return t, note
 
 
 def free_port():
@@ -147,16 +168,40 @@ def free_port():
         return so.getsockname()[1]
 
 
+def visible_gpus(topology="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs this process could use, counted WITHOUT any HIP call (the launcher process must stay GPU-free: it goes on
+    to start children, and torch.cuda.device_count() may initialise the runtime): the KFD topology nodes that have
+    SIMDs, cut down by a *_VISIBLE_DEVICES list if one is set.  None when the topology cannot be read."""
+    try:
+        nodes = os.listdir(topology)
+    except OSError:
+        return None
+    gpus = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(topology, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus += 1
+        except (OSError, ValueError):
+            continue
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            gpus = min(gpus, len([t for t in v.split(",") if t.strip() != ""]))
+    return gpus
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher around it: starts N ranks of this script (one per GPU,
-    torch.distributed.run on 127.0.0.1) as child processes and returns their exit code.  Nothing in this
-    process has touched a GPU at this point, and nothing does: it only waits for the children."""
+    torch.distributed.run on 127.0.0.1) as child processes (never exec) and returns their exit code.  This process
+    makes no HIP call, before or after: it counts GPUs from the KFD topology in /sys and waits for the children; when
+    the topology cannot be read it starts the ranks anyway and lets a rank without a device fail loudly."""
     import subprocess
     backend = os.environ.get("SONO_BENCH_BACKEND", "nccl")
     if backend == "nccl":
-        import torch
-        have = torch.cuda.device_count()          # counts devices without initialising them
-        if have < n:
+        have = visible_gpus()
+        if have is not None and have < n:
             sys.exit(f"bench.py: --gpus {n} needs {n} visible GPUs, this machine shows {have} "
                      f"(SONO_BENCH_BACKEND=gloo rehearses the multi-rank path on fewer cards)")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
@@ -164,14 +209,9 @@ def launch_ranks(n):
     return subprocess.call(cmd)
 
 
-def measured_valu():
-    """Vector-ALU counters per launch of the timed kernel from the committed rocprofv3 passes
-    (profiles/valu_counters.json, written by tools/profile_summary.py), or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "valu_counters.json")) as f:
-            return json.load(f)
-    except (OSError, ValueError):
-        return None
+def measured_valu(lib_hash, profiles_dir=None):
+    """Vector-ALU counters per launch of the timed kernel from the committed SQ passes -> (dict or None, note)."""
+    return committed_counters("valu_counters.json", lib_hash, profiles_dir)
 
 
 WORKLOADS = {
@@ -197,6 +237,7 @@ def main():
                     help="length of the recording per GPU (default: 3600 for cfg2, 600 for cfg4, 43200 for cfg5)")
     ap.add_argument("--files", type=int, default=10000, help="cfg3: number of files over all ranks")
     ap.add_argument("--no-end-to-end", action="store_true", help="cfg2: skip the host-pointer (PCIe-inclusive) measurement")
+    ap.add_argument("--no-latency", action="store_true", help="cfg2: skip the small-call latency figures")
     ap.add_argument("--cpu-seconds", type=float, default=600.0,
                     help="seconds of audio in the CPU baseline's sample, processed repeatedly for >= 10 s (0 disables it)")
     args = ap.parse_args()
@@ -411,11 +452,20 @@ def main():
         if detect:
             result["calls"] = {"rows_all_ranks": int(call_table.shape[0]), "rows_rank0": int(det_rows[0].shape[0]),
                                "columns": len(sharding.COLUMNS)}
-        traffic = measured_traffic() if args.workload == "cfg2" and seconds == SECONDS else None
-        if traffic:
-            result["roofline"]["traffic"] = traffic["hbm_bytes"]
-            result["roofline"]["traffic_source"] = traffic["source"]
-        counters = measured_valu() if args.workload == "cfg2" and seconds == SECONDS else None
+        lib_hash = library_sha256()
+        result["lib_sha256"] = lib_hash
+        traffic, counters = None, None
+        if args.workload == "cfg2" and seconds == SECONDS:
+            traffic, note = measured_traffic(lib_hash)
+            if traffic:
+                result["roofline"]["traffic"] = traffic["hbm_bytes"]
+                result["roofline"]["traffic_source"] = traffic["source"]
+            else:
+                result["roofline"]["traffic_note"] = note
+            counters, note = measured_valu(lib_hash)
+            if not counters:
+                result["valu_issue"] = None
+                result["valu_issue_note"] = note
         if counters:
             # what the vector ALU actually issued (hardware counters of the committed profile), beside the
             # conventional-flop figure above: instructions per launch and how busy that keeps the issue ports
@@ -429,6 +479,12 @@ def main():
                                     "source": counters.get("source")}
         if world == 1 and args.workload == "cfg2" and not args.no_end_to_end:
             result["end_to_end"] = end_to_end(sa, torch, engine, x, n_fft, noverlap, frames, bins)
+        if world == 1 and args.workload == "cfg2" and not args.no_latency:
+            # the application's own call sizes (seconds-long clips, millisecond selections) through the host-pointer
+            # entry points, p50 / p95 beside the C oracle: tools/latency_bench.py.  Outside the timed region, never `value`.
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import latency_bench
+            result["latency"] = latency_bench.measure(reps=20, quick=True)
         if world == 1 and args.cpu_seconds > 0 and args.workload == "cfg2":
             threads = min(16, os.cpu_count() or 1)
             n_cpu = int(min(args.cpu_seconds, seconds) * sr)

@@ -76,6 +76,26 @@ uint32_t sono_engine_freq_bins(const sono_engine *e);     /* spectrogramengine_g
 uint32_t sono_engine_num_filters(const sono_engine *e);   /* spectrogramengine_get_num_filters:17 */
 int sono_engine_device(const sono_engine *e);
 
+/* Host threads ONE library call may use for its copies, call framing and measurement (no counterpart in the
+ * reference, which is single-threaded).  Process-wide.  Default, fixed the first time it is needed: the environment's
+ * SONO_HOST_THREADS if set, else min(16, cores / LOCAL_WORLD_SIZE) -- LOCAL_WORLD_SIZE is what torchrun exports to
+ * the ranks it starts on one host, which share that host's cores.  n = 0 returns to the default. */
+int sono_set_host_threads(uint32_t n);
+uint32_t sono_host_threads(void);
+
+/* Switches of one engine (no counterpart in the reference: the wasm has one code path).  Every option is 0 or 1
+ * and starts at 0 unless the environment variable named beside it was set to something other than "0" when the
+ * engine was CREATED -- the environment is never read on a launch.
+ *   "force_generic"  (SONO_FORCE_GENERIC)  every transform through the generic LDS-staged kernel
+ *   "force_any_hop"  (SONO_FORCE_ANY_HOP)  the tiled kernel loads both frames of a pair whole at every hop
+ *   "fixed_tiles"    (SONO_FIXED_TILES)    equal tile ranges per XCD, no adapting to measured speeds
+ *   "balance_debug"  (SONO_BALANCE_DEBUG)  print the XCDs' times and the next ranges to stderr
+ *   "no_streaming"   (SONO_NO_STREAMING)   long host-pointer calls as one copy each way instead of the chunk pipeline
+ * None of them changes a result bit (the tests compare the forms).  SONO_EINVAL for an unknown name.
+ * Like every call on an engine: not while another thread is inside a call on the same engine. */
+int sono_engine_set_option(sono_engine *e, const char *name, int value);
+int sono_engine_get_option(const sono_engine *e, const char *name, int *value);
+
 /* spectrogramengine_get_window_values (wasm.d.ts:20; lib.rs:165): copies N floats. */
 int sono_engine_window_values(const sono_engine *e, float *out, size_t cap);
 

@@ -166,6 +166,10 @@ _SIGNATURES = {
     "sono_engine_freq_bins": (C.c_uint32, [C.c_void_p]),
     "sono_engine_num_filters": (C.c_uint32, [C.c_void_p]),
     "sono_engine_device": (C.c_int, [C.c_void_p]),
+    "sono_set_host_threads": (C.c_int, [C.c_uint32]),
+    "sono_host_threads": (C.c_uint32, []),
+    "sono_engine_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "sono_engine_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     "sono_engine_window_values": (C.c_int, [C.c_void_p, _f32p, C.c_size_t]),
     "sono_engine_load_filter_bank": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_uint32]),
     "sono_engine_clear_filter_bank": (C.c_int, [C.c_void_p]),
@@ -339,6 +343,15 @@ def device_count():
 def frames_for(n_samples, fft_size, noverlap):
     """Frame count rule of lib.rs:118-123."""
     return lib().sono_frames_for(n_samples, fft_size, noverlap)
+
+
+def set_host_threads(n):
+    """Host threads one library call may use (0: the default, min(16, cores / LOCAL_WORLD_SIZE))."""
+    _check(lib().sono_set_host_threads(int(n)))
+
+
+def host_threads():
+    return int(lib().sono_host_threads())
 
 
 class SpectrogramEngine:
@@ -525,6 +538,16 @@ class SpectrogramEngine:
 
     def synchronize(self):
         _check(lib().sono_engine_synchronize(self._handle()))
+
+    def set_option(self, name, value):
+        """Engine switches ("force_generic", "force_any_hop", "fixed_tiles", "balance_debug", "no_streaming"):
+        read from the environment once, when the engine is created; changed here afterwards."""
+        _check(lib().sono_engine_set_option(self._handle(), str(name).encode(), int(bool(value))))
+
+    def get_option(self, name):
+        v = C.c_int(0)
+        _check(lib().sono_engine_get_option(self._handle(), str(name).encode(), C.byref(v)))
+        return bool(v.value)
 
 
 def _ragged(d_samples, offsets, lengths):

@@ -5,7 +5,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <algorithm>
 #include <cstring>
+#include <thread>
 #include <map>
 #include <mutex>
 #include <new>
@@ -39,6 +42,31 @@ int hip_fail(hipError_t e, const char *what)
                 std::string(what) + ": " + hipGetErrorString(e));
 }
 
+namespace {
+std::atomic<unsigned int> g_host_threads{0};
+}
+
+unsigned int host_threads()
+{
+    const unsigned int set = g_host_threads.load(std::memory_order_relaxed);
+    if (set) return set;
+    static const unsigned int dflt = [] {
+        if (const char *v = std::getenv("SONO_HOST_THREADS")) return (unsigned int)std::max(1, atoi(v));
+        if (const char *v = std::getenv("SONO_COPY_THREADS")) return (unsigned int)std::max(1, atoi(v));      // older name
+        unsigned int local = 1;
+        if (const char *v = std::getenv("LOCAL_WORLD_SIZE")) local = (unsigned int)std::max(1, atoi(v));
+        const unsigned int hw = std::max(1u, std::thread::hardware_concurrency());
+        return std::min(16u, std::max(1u, hw / local));
+    }();
+    return dflt;
+}
+
+bool stage_timing()
+{
+    static const bool on = std::getenv("SONO_TIMING") != nullptr;
+    return on;
+}
+
 }  // namespace sono
 
 using sono::DevBuf;
@@ -49,7 +77,7 @@ using sono::hip_fail;
 
 namespace {
 
-int build_tables(unsigned int N, const float *window, Tables &t)
+int build_tables(unsigned int N, const float *window, Tables &t, bool with_tile = true)
 {
     t.N = N;
     std::vector<float2> twh = sono::make_twiddles(N / 2, N / 2);
@@ -60,23 +88,67 @@ int build_tables(unsigned int N, const float *window, Tables &t)
     HIP_TRY(hipMemcpy(t.d_window, window, N * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t.d_tw_half, twh.data(), twh.size() * sizeof(float2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t.d_tw_full, twf.data(), twf.size() * sizeof(float2), hipMemcpyHostToDevice));
+    if (!with_tile) return SONO_OK;
     hipError_t e = sono::tile_tables_build(N, t.tile);
     if (e != hipSuccess) return hip_fail(e, "tile_tables_build");
     return SONO_OK;
 }
 
-bool force_generic()
+// compute_power_spectrum is a free function in the reference (lib.rs:1019): no engine keeps its window and twiddle
+// tables between calls, and the application calls it on a few thousand samples at a time (powerSpectrum.js:49),
+// where building and freeing tables and staging buffers per call costs more than the transform.  The last few
+// (device, fft size, window) combinations therefore keep theirs, with staging buffers up to kPowerKeepBytes; a call
+// takes the cache's lock for its whole duration (the reference is single-threaded; concurrent callers take turns).
+// The entries are never freed: they are small, and a static destructor must not call into a HIP runtime that may
+// already be gone.
+constexpr size_t kPowerKeepBytes = (size_t)64 << 20;
+struct PowerCtx {
+    int device = -1;
+    unsigned int N = 0;
+    std::string window;
+    Tables t;
+    DevBuf d_x, d_pow, d_db;
+    unsigned long long used = 0;
+};
+std::mutex g_power_mu;
+PowerCtx *g_power_ctx[4] = {nullptr, nullptr, nullptr, nullptr};
+unsigned long long g_power_clock = 0;
+
+// -> the context for (device, N, window), tables built; nullptr with *rc set on failure.  Caller holds g_power_mu.
+PowerCtx *power_ctx(int device, unsigned int N, const char *window, int *rc)
 {
-    const char *v = std::getenv("SONO_FORCE_GENERIC");
+    const std::string w = window ? window : "";
+    PowerCtx *lru = nullptr;
+    for (PowerCtx *&c : g_power_ctx) {
+        if (c && c->device == device && c->N == N && c->window == w) { c->used = ++g_power_clock; return c; }
+        if (!c) { c = new PowerCtx(); c->used = 0; }
+        if (!lru || c->used < lru->used) lru = c;
+    }
+    lru->t.release();
+    lru->d_x.release(); lru->d_pow.release(); lru->d_db.release();
+    lru->device = -1;
+    std::vector<float> win(N);
+    sono::host_make_window(w.c_str(), N, 0.16f, win.data());                  // lib.rs:1041
+    *rc = build_tables(N, win.data(), lru->t, false);
+    if (*rc) { lru->t.release(); return nullptr; }
+    lru->device = device; lru->N = N; lru->window = w; lru->used = ++g_power_clock;
+    return lru;
+}
+
+// The switches an engine starts with: the environment is read here, once per engine, and never on a launch
+// (sono_engine_set_option changes them afterwards).
+bool env_flag(const char *name)
+{
+    const char *v = std::getenv(name);
     return v && v[0] && v[0] != '0';
 }
 
 // Picks the kernel for one launch.  The register-tiled kernel covers the common
-// sizes; everything else (and SONO_FORCE_GENERIC=1, used by the tests to compare
-// the two) goes through the generic LDS-staged kernel.
+// sizes; everything else (and the engine option "force_generic", used by the tests to
+// compare the two) goes through the generic LDS-staged kernel.
 hipError_t dispatch_stft(int mode, const sono::StftArgs &a, const Tables &t, hipStream_t stream)
 {
-    if (!force_generic() && sono::tile_supports(mode, a, t.tile))
+    if (!t.force_generic && sono::tile_supports(mode, a, t.tile))
         return sono::launch_stft_tile(mode, a, t.tile, stream);
     return sono::launch_stft_generic(mode, a, stream);
 }
@@ -128,6 +200,11 @@ int sono_engine_create(uint32_t fft_size, const char *window, int has_alpha, flo
     e->window.resize(fft_size);
     sono::host_make_window(e->window_name.c_str(), fft_size, e->alpha, e->window.data());
     int rc = build_tables(fft_size, e->window.data(), e->tables);
+    e->tables.force_generic = env_flag("SONO_FORCE_GENERIC");
+    e->tables.tile.any_hop = env_flag("SONO_FORCE_ANY_HOP");
+    e->tables.tile.balance.fixed = env_flag("SONO_FIXED_TILES");
+    e->tables.tile.balance.debug = env_flag("SONO_BALANCE_DEBUG");
+    e->no_streaming = env_flag("SONO_NO_STREAMING");
     if (rc == SONO_OK && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
         rc = hip_fail(hipGetLastError(), "hipStreamCreate");
     if (rc == SONO_OK) rc = sono::noalloc_init_device(dev);      // this GPU's fixed scratch of sono_detect_runs_static_dev
@@ -157,6 +234,41 @@ void sono_engine_destroy(sono_engine *e)
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->pipe) sono::stream_pipe_destroy(e->pipe);
     delete e;
+}
+
+int sono_set_host_threads(uint32_t n)
+{
+    sono::g_host_threads.store(n > 256 ? 256u : n, std::memory_order_relaxed);
+    return SONO_OK;
+}
+
+uint32_t sono_host_threads(void) { return sono::host_threads(); }
+
+int sono_engine_set_option(sono_engine *e, const char *name, int value)
+{
+    if (!e || !name) return fail(SONO_EINVAL, "sono_engine_set_option: NULL argument");
+    const std::string n(name);
+    const bool on = value != 0;
+    if (n == "force_generic") e->tables.force_generic = on;
+    else if (n == "force_any_hop") e->tables.tile.any_hop = on;
+    else if (n == "fixed_tiles") e->tables.tile.balance.fixed = on;
+    else if (n == "balance_debug") e->tables.tile.balance.debug = on;
+    else if (n == "no_streaming") e->no_streaming = on;
+    else return fail(SONO_EINVAL, "sono_engine_set_option: unknown option '" + n + "'");
+    return SONO_OK;
+}
+
+int sono_engine_get_option(const sono_engine *e, const char *name, int *value)
+{
+    if (!e || !name || !value) return fail(SONO_EINVAL, "sono_engine_get_option: NULL argument");
+    const std::string n(name);
+    if (n == "force_generic") *value = e->tables.force_generic;
+    else if (n == "force_any_hop") *value = e->tables.tile.any_hop;
+    else if (n == "fixed_tiles") *value = e->tables.tile.balance.fixed;
+    else if (n == "balance_debug") *value = e->tables.tile.balance.debug;
+    else if (n == "no_streaming") *value = e->no_streaming;
+    else return fail(SONO_EINVAL, "sono_engine_get_option: unknown option '" + n + "'");
+    return SONO_OK;
 }
 
 uint32_t sono_engine_fft_size(const sono_engine *e) { return e ? e->N : 0; }
@@ -254,14 +366,6 @@ int check_aligned(const void *p, unsigned int bytes, const char *who, const char
     if (reinterpret_cast<uintptr_t>(p) & (bytes - 1))
         return fail(SONO_EINVAL, std::string(who) + ": " + what + " must be " + std::to_string(bytes) + "-byte aligned");
     return SONO_OK;
-}
-
-// SONO_NO_STREAMING=1 (read per call) keeps long host-pointer calls on the one-copy-each-way form: the tests
-// compare the two.
-bool no_streaming()
-{
-    const char *v = std::getenv("SONO_NO_STREAMING");
-    return v && v[0] && v[0] != '0';
 }
 
 // Uploads the samples the frames actually touch.
@@ -396,7 +500,7 @@ int run_ragged(sono_engine *e, const sono_ragged_batch *in, uint32_t noverlap, i
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
     a.x = in->d_samples;
     a.n_streams = 0; a.stream_stride = 0; a.frames_per_stream = 0;
-    const bool tiled = fpw && !force_generic() &&
+    const bool tiled = fpw && !e->tables.force_generic &&
                        [&] { sono::StftArgs p = a; p.frames_per_stream = 2; return sono::tile_supports(mode, p, e->tables.tile); }();
     std::vector<sono::RaggedStreamEntry> streams;
     std::vector<unsigned int> tile_stream;
@@ -499,7 +603,7 @@ int sono_stft_band_active_dev(sono_engine *e, const sono_batch *in, uint32_t nov
     a.band_active = d_active; a.band_energy = d_band_energy;
     DeviceGuard guard(e->device);
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
-    if (force_generic() || !sono::tile_supports(sono::MODE_BAND, a, e->tables.tile)) {
+    if (e->tables.force_generic || !sono::tile_supports(sono::MODE_BAND, a, e->tables.tile)) {
         // the generic kernel has no fused form: magnitudes to a scratch matrix, then the band pass
         const size_t F = (size_t)(a.n_streams * a.frames_per_stream), B = e->N / 2;
         HIP_TRY(e->d_mags.reserve(F * B * sizeof(float)));
@@ -579,7 +683,7 @@ int sono_stft_u8(sono_engine *e, const float *x, size_t n, uint32_t noverlap, fl
     if (F == 0) return SONO_OK;
     if (!out || cap < F * out_bins) return fail(SONO_ECAPACITY, "sono_stft_u8: output buffer too small");
     DeviceGuard guard(e->device);
-    if (!bank && F > 2 * sono::stream_chunk_frames(e->N - noverlap) && !no_streaming()) {
+    if (!bank && F > 2 * sono::stream_chunk_frames(e->N - noverlap) && !e->no_streaming) {
         // a long recording: chunks of frames through pinned rings, copies and kernels overlapped (sono_stream.hip)
         e->last_peak_bin.resize(F);
         e->last_peak_mag.resize(F);
@@ -744,13 +848,16 @@ int sono_power_spectrum(const float *x, size_t n, uint32_t sample_rate, uint32_t
     if (!guard.ok()) return fail(SONO_EDEVICE, "sono_power_spectrum: cannot select the device");
     const size_t hop = sono::host_power_hop(fft_size, has_overlap != 0, overlap_percent);
     const size_t F = (n - fft_size) / hop + 1;
-    std::vector<float> win(fft_size);
-    sono::host_make_window(window ? window : "", fft_size, 0.16f, win.data());   // lib.rs:1041
-    Tables t;
-    int rc = build_tables(fft_size, win.data(), t);
-    DevBuf d_x, d_pow, d_db;
-    auto cleanup = [&]() { t.release(); d_x.release(); d_pow.release(); d_db.release(); };
-    if (rc) { cleanup(); return rc; }
+    int dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return hip_fail(hipGetLastError(), "hipGetDevice");
+    std::lock_guard<std::mutex> lock(g_power_mu);
+    int rc = SONO_OK;
+    PowerCtx *c = power_ctx(dev, fft_size, window, &rc);
+    if (!c) return rc;
+    Tables &t = c->t;
+    DevBuf &d_x = c->d_x, &d_pow = c->d_pow, &d_db = c->d_db;
+    // large staging buffers do not outlive the call
+    auto cleanup = [&]() { if (d_x.cap > kPowerKeepBytes) d_x.release(); if (d_pow.cap > kPowerKeepBytes) d_pow.release(); };
     const size_t used = (F - 1) * hop + fft_size;
     hipError_t he;
     if ((he = d_x.reserve(used * sizeof(float))) != hipSuccess ||

@@ -56,7 +56,7 @@ Band band_of(uint32_t N, double sample_rate, double flow_khz, double fhigh_khz, 
 // SONO_TIMING=1 prints the wall time of the stages of the whole-file entry points to stderr.
 struct StageTimer {
     const char *who;
-    bool on = std::getenv("SONO_TIMING") != nullptr;
+    bool on = sono::stage_timing();
     std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
     explicit StageTimer(const char *w) : who(w) {}
     void lap(const char *what)
@@ -76,7 +76,7 @@ void parallel_copy(const std::vector<CopyJob> &jobs)
 {
     size_t total = 0;
     for (const CopyJob &j : jobs) total += j.bytes;
-    unsigned int threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    unsigned int threads = sono::host_threads();
     if (total < ((size_t)8 << 20)) threads = 1;
     std::atomic<size_t> next{0};
     auto work = [&]() {
@@ -141,7 +141,7 @@ int peaks_pass(sono_engine *e, const float *d_src, const std::vector<uint64_t> &
                 }
             }
     };
-    const unsigned int threads = frames < 100000 ? 1u : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    const unsigned int threads = frames < 100000 ? 1u : sono::host_threads();
     std::vector<std::thread> pool;
     for (unsigned int w = 1; w < threads; ++w) pool.emplace_back(work);
     work();
@@ -489,7 +489,7 @@ int sono_frame_roi_calls(const float *x, const float *x_filtered, size_t n, cons
             }
         }
     };
-    const unsigned int nt = (unsigned int)std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())),
+    const unsigned int nt = (unsigned int)std::min<size_t>(sono::host_threads(),
                                                            std::max<size_t>(n_rois / 64, 1));
     std::vector<std::thread> pool;
     for (unsigned int w = 1; w < nt; ++w) pool.emplace_back(work);
@@ -546,7 +546,7 @@ static int measure_roi_calls(sono_engine *e, const float *x, const float *x_filt
     }
     DeviceGuard guard(e->device);
     hipStream_t s = e->stream;
-    if (threads == 0) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (threads == 0) threads = sono::host_threads();
     StageTimer timer("sono_measure_roi_calls");
     // Batches of at most kMeasureFrames frames go through two slots of staging memory: while the host threads measure
     // the calls of one batch, the next one is packed, uploaded, transformed and copied back.

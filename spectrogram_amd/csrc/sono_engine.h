@@ -72,7 +72,8 @@ struct Tables {
     float *d_window = nullptr;
     float2 *d_tw_half = nullptr;   // N/2 entries
     float2 *d_tw_full = nullptr;   // N/2 + 1 entries
-    TileTables tile;               // inter-pass twiddles of the register-tiled kernel (may be empty)
+    TileTables tile;               // inter-pass twiddles of the register-tiled kernel (may be empty), its launch switches
+    bool force_generic = false;    // engine option "force_generic": every launch through the generic LDS-staged kernel
     void release()
     {
         if (d_window) (void)hipFree(d_window);
@@ -98,6 +99,13 @@ struct FullFileAxes {
 };
 void stream_pipe_destroy(StreamPipe *p);
 size_t stream_chunk_frames(uint32_t hop);
+
+// Host threads one library call may use for copies, call framing and measurement: sono_set_host_threads' value, else
+// (read once per process) SONO_HOST_THREADS, else min(16, cores / LOCAL_WORLD_SIZE) -- the ranks that a launcher
+// such as torchrun starts on one host share its cores, and eight ranks that each took sixteen threads would oversubscribe them.
+unsigned int host_threads();
+// True when SONO_TIMING was set when the process first asked (stage times of the whole-file entry points on stderr).
+bool stage_timing();
 
 // Makes `dev` (if >= 0) the current HIP device for the lifetime of the guard.
 class DeviceGuard {
@@ -201,6 +209,7 @@ struct sono_engine {
     std::vector<uint16_t> last_peak_bin;
     std::vector<float> last_peak_mag;
     float last_gmax = 0.0f;
+    bool no_streaming = false;          // engine option "no_streaming": long host-pointer calls as one copy each way
     // colour map / config (lib.rs:28-32)
     std::vector<uint32_t> color_map;
     std::string scale = "linear";

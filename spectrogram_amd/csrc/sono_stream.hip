@@ -101,8 +101,8 @@ private:
 
 bool no_pinned_upload()
 {
-    const char *v = std::getenv("SONO_NO_PINNED_UPLOAD");
-    return v && *v && *v != '0';
+    static const bool off = [] { const char *v = std::getenv("SONO_NO_PINNED_UPLOAD"); return v && *v && *v != '0'; }();      // read once per process
+    return off;
 }
 
 struct StreamPipe {
@@ -181,9 +181,7 @@ int upload_host_array(sono_engine *e, void *d_dst, const void *h_src, size_t byt
         if (bytes >= 2 * kPiece) HIP_TRY(hipStreamSynchronize(s));
         return SONO_OK;
     }
-    unsigned int threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    if (const char *v = std::getenv("SONO_COPY_THREADS")) threads = (unsigned int)std::max(1, atoi(v));
-    CopyPool pool(threads);
+    CopyPool pool(host_threads());
     size_t piece = 0;
     for (size_t off = 0; off < bytes; off += kPiece, ++piece) {
         sono_engine::UploadSlot &slot = e->upload_slot[piece % 3];
@@ -216,9 +214,7 @@ int stream_stft_u8(sono_engine *e, StreamPipe **pipe, const float *x, size_t F, 
     const size_t B = N / 2, C = stream_chunk_frames(hop);
     const size_t chunks = (F + C - 1) / C;
     if (!*pipe) {
-        unsigned int hw = std::thread::hardware_concurrency();
-        if (const char *v = std::getenv("SONO_COPY_THREADS")) hw = (unsigned int)std::max(1, atoi(v));
-        else hw = std::max(1u, std::min(8u, hw / 2));        // per direction
+        const unsigned int hw = std::max(1u, host_threads() / 2);        // per direction
         *pipe = new (std::nothrow) StreamPipe(hw);
         if (!*pipe) return fail(SONO_ENOMEM, "sono_stft_u8: out of host memory");
     }
@@ -256,7 +252,15 @@ int stream_stft_u8(sono_engine *e, StreamPipe **pipe, const float *x, size_t F, 
     auto finish = [&](int code) {
         { std::lock_guard<std::mutex> l(m); if (code) drain_error = 1; }
         cv.notify_all();
-        drainer.join();
+        if (drainer.joinable()) drainer.join();
+        if (code) {
+            // Work of up to three ring slots may still be queued; the next call starts by writing into slot 0's pinned
+            // buffer from host threads, so a failed call only returns once the rings are idle.
+            (void)hipStreamSynchronize(p.up);
+            (void)hipStreamSynchronize(e->stream);
+            (void)hipStreamSynchronize(p.down);
+            (void)hipGetLastError();
+        }
         return code;
     };
 
@@ -287,7 +291,7 @@ int stream_stft_u8(sono_engine *e, StreamPipe **pipe, const float *x, size_t F, 
         cv.notify_all();
     }
     drainer.join();
-    if (drain_error.load()) return fail(SONO_EDEVICE, "sono_stft_u8: a download failed");
+    if (drain_error.load()) return finish(fail(SONO_EDEVICE, "sono_stft_u8: a download failed"));
     HIP_TRY(hipMemcpyAsync(gmax_bits, e->d_gmax.p, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return SONO_OK;

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "sono_core.h"
 
 namespace sono {
@@ -30,18 +32,28 @@ struct TileBalance {
     double share[8] = {1, 1, 1, 1, 1, 1, 1, 1};            // relative size of each part's range (mean 1)
     unsigned long long stamp = 0;                         // stamps handed to launches so far
     unsigned long long seen = 0;                          // stamp of the reports taken up last
+    bool fixed = false;                                   // keep the ranges equal (engine option "fixed_tiles")
+    bool debug = false;                                   // print times and shares to stderr (engine option "balance_debug")
+    std::mutex mu;                                        // launches of one engine from several threads plan in turn
 };
 
+// What the launcher needs beside the kernel arguments.  Filled once per engine (tile_tables_build); the switches
+// are the engine's options (sono_engine_set_option), so that no launch reads the environment or asks the runtime
+// about the device.
 struct TileTables {
     unsigned int N = 0;
     void *d_blob = nullptr;
+    int cus = 0;                    // compute units of the engine's device
+    bool any_hop = false;           // take the any-hop form even where frame B could reuse frame A's loads (option "force_any_hop")
     mutable TileBalance balance;
 };
 
 namespace tile { struct TileIter; }
 // Fills it.parts / part_begin / feedback / stamp for a launch of it.n_tiles tiles by `blocks` workgroups of `waves_per_block`
 // waves, `resident` of which the chip holds at once; takes up the reports of the last large launch first.  Small
-// launches, and all launches under SONO_FIXED_TILES=1 (read per launch), get equal ranges and report nothing.
+// launches, launches on a device that is not one whole chip of eight XCDs (blocks must be 256 or 512: a partition or
+// another part deals its workgroups differently), and all launches of an engine with b->fixed set get equal ranges
+// and report nothing.
 void tile_balance_plan(TileBalance *b, unsigned long long blocks, unsigned long long resident, unsigned int waves_per_block, tile::TileIter &it);
 
 hipError_t tile_tables_build(unsigned int N, TileTables &t);

@@ -2,6 +2,7 @@
 // serves, dispatch to the per-mode translation units.
 #include "sono_tile.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -12,20 +13,18 @@
 
 namespace sono {
 
-hipError_t launch_tile_u8(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, TileBalance *balance, hipStream_t stream);
-hipError_t launch_tile_mag(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, TileBalance *balance, hipStream_t stream);
-hipError_t launch_tile_band(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, TileBalance *balance, hipStream_t stream);
+hipError_t launch_tile_u8(const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream);
+hipError_t launch_tile_mag(const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream);
+hipError_t launch_tile_band(const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream);
 
 namespace {
 
 
 hipError_t launch_any(int mode, const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream)
 {
-    const float2 *tw_rows = (const float2 *)t.d_blob;
-    TileBalance *bal = t.balance.feedback ? &t.balance : nullptr;
-    return mode == MODE_MAG ? launch_tile_mag(a, tw_rows, plan, bal, stream)
-         : mode == MODE_BAND ? launch_tile_band(a, tw_rows, plan, bal, stream)
-                             : launch_tile_u8(a, tw_rows, plan, bal, stream);
+    return mode == MODE_MAG ? launch_tile_mag(a, t, plan, stream)
+         : mode == MODE_BAND ? launch_tile_band(a, t, plan, stream)
+                             : launch_tile_u8(a, t, plan, stream);
 }
 
 }  // namespace
@@ -34,11 +33,14 @@ hipError_t tile_tables_build(unsigned int N, TileTables &t)
 {
     t.N = N;
     t.d_blob = nullptr;
+    int dev = 0;
+    hipError_t e0 = hipGetDevice(&dev);
+    if (e0 == hipSuccess) e0 = hipDeviceGetAttribute(&t.cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e0 != hipSuccess) return e0;
     if (N != 4096 && N != 2048 && N != 1024 && N != 512 && N != 256) return hipSuccess;
     const std::vector<float2> rows = make_tile_twiddles(N, 1u << (N == 256 ? 5 : tile_log_r2(N)));
     hipError_t e = hipMalloc(&t.d_blob, rows.size() * sizeof(float2));
     if (e != hipSuccess) { t.d_blob = nullptr; return e; }
-    t.balance = TileBalance();
     const size_t fb_bytes = (size_t)TileBalance::kMaxGroups * tile::kFeedbackWords * sizeof(unsigned long long);
     e = hipHostMalloc((void **)&t.balance.feedback, fb_bytes, hipHostMallocDefault);
     if (e != hipSuccess) { t.balance.feedback = nullptr; return e; }
@@ -64,20 +66,29 @@ void tile_balance_plan(TileBalance *b, unsigned long long blocks, unsigned long 
     // at least kMinTilesPerWave tiles, tile numbers fit 32 bits.
     constexpr unsigned long long kMinTilesPerWave = 64;
     constexpr unsigned int P = tile::kTileParts;
-    const char *fixed = std::getenv("SONO_FIXED_TILES");
-    if (!b || !b->feedback || (fixed && fixed[0] && fixed[0] != '0')) return;
-    if (blocks != resident || blocks % P != 0 || blocks > TileBalance::kMaxGroups) return;
+    if (!b || !b->feedback || b->fixed) return;
+    // Workgroup g runs on XCD g % 8 only when the device is one whole chip of eight XCDs of 32 CUs: 256 workgroups
+    // (one per CU) or 512 (two).  Anything else -- a partition of the chip, a part with another number of XCDs --
+    // keeps equal ranges.
+    if (blocks != resident || (blocks != 256 && blocks != 512) || blocks > TileBalance::kMaxGroups) return;
+    std::lock_guard<std::mutex> lock(b->mu);
     if (it.n_tiles >= (1ull << 32) || it.n_tiles < blocks * waves_per_block * kMinTilesPerWave) return;
     // Reports of the last large launch that has finished: usable when every workgroup's record carries one stamp,
     // newer than the one taken up last (a launch still running, or records of two launches mixed, are left alone).
+    // The records are read while a later launch may be rewriting them: a writer voids a record's stamp, writes the
+    // fields, then the new stamp, and the reader takes a record only when its stamp is the expected one before AND
+    // after the fields were read.
     const volatile unsigned long long *fb = b->feedback;
     const unsigned long long s0 = fb[3];
-    bool whole = s0 > b->seen && s0 <= b->stamp;
+    bool whole = s0 != 0 && s0 > b->seen && s0 <= b->stamp;
     unsigned long long first[P], last[P], tiles[P];
     for (unsigned int p = 0; p < P; ++p) { first[p] = ~0ull; last[p] = 0; tiles[p] = 0; }
     for (unsigned long long g = 0; whole && g < blocks; ++g) {
         const volatile unsigned long long *r = fb + g * tile::kFeedbackWords;
+        if (r[3] != s0) { whole = false; break; }
+        std::atomic_thread_fence(std::memory_order_acquire);
         const unsigned long long t0 = r[0], t1 = r[1], n = r[2];
+        std::atomic_thread_fence(std::memory_order_acquire);
         if (r[3] != s0 || t1 <= t0) { whole = false; break; }
         const unsigned int p = (unsigned int)(g % P);
         if (t0 < first[p]) first[p] = t0;
@@ -104,7 +115,7 @@ void tile_balance_plan(TileBalance *b, unsigned long long blocks, unsigned long 
             for (unsigned int p = 0; p < P; ++p) b->share[p] *= P / total;
         }
         b->seen = s0;
-        if (const char *dbg = std::getenv("SONO_BALANCE_DEBUG"); dbg && dbg[0] == '1') {
+        if (b->debug) {
             std::fprintf(stderr, "tile balance, launch %llu: part times (us)", s0);
             for (unsigned int p = 0; p < P; ++p) std::fprintf(stderr, " %.1f", (double)(last[p] - first[p]) * 0.01);
             std::fprintf(stderr, "; next shares");
@@ -181,6 +192,8 @@ extern "C" unsigned int sono_debug_tile_balance(const unsigned long long *record
         std::memcpy(fb.data(), records, (size_t)blocks * sono::tile::kFeedbackWords * sizeof(unsigned long long));
     sono::TileBalance b;
     b.feedback = fb.data();
+    const char *fixed = std::getenv("SONO_FIXED_TILES");      // this hook only: an engine takes the switch as an option
+    b.fixed = fixed && fixed[0] && fixed[0] != '0';
     for (int p = 0; p < 8; ++p) b.share[p] = share[p];
     b.stamp = *stamp;
     b.seen = *seen;

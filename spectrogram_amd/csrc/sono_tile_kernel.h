@@ -17,8 +17,6 @@
 // shares with its neighbours is served by that XCD's L2 instead of being fetched
 // from HBM once per XCD.
 #pragma once
-#include <cstdlib>
-
 #include "sono_tile.h"
 #include "sono_tile_core.h"
 
@@ -314,6 +312,10 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
         if (lane == 0) done = atomicAdd(&s_done, 1u);
         if (lane == 0 && done == (unsigned int)kWavesPerBlock - 1u) {
             unsigned long long *fb = it.feedback + (size_t)blockIdx.x * tile::kFeedbackWords;
+            // the old record is marked void before its fields change, so that a reader between the stores cannot take
+            // a mix of two launches for a whole record (it reads stamp, fields, stamp)
+            __hip_atomic_store(fb + 3, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __atomic_thread_fence(__ATOMIC_RELEASE);
             __hip_atomic_store(fb + 0, wg_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(fb + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(fb + 2, t_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -329,8 +331,10 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
 }
 
 template <int LOG_R1, int LOG_R2, int MODE>
-hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, TileBalance *balance, hipStream_t stream)
+hipError_t launch_one(const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream)
 {
+    const float2 *tw_rows = (const float2 *)t.d_blob;
+    TileBalance *balance = t.balance.feedback ? &t.balance : nullptr;
     using G = tile::Geo<LOG_R1, LOG_R2>;
     constexpr int kWavesPerBlock = Occupancy<LOG_R1, LOG_R2>::kWavesPerBlock;
     constexpr int kBlocksPerCU = Occupancy<LOG_R1, LOG_R2>::kBlocksPerCU;
@@ -348,11 +352,8 @@ hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, const RaggedPlan
         it.tile_stream = nullptr;
     }
     if (it.n_tiles == 0) return hipSuccess;
-    int dev = 0, cus = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return e;
+    const int cus = t.cus;
+    if (cus <= 0) return hipErrorInvalidDevice;
     unsigned long long blocks = (it.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const unsigned long long resident = (unsigned long long)cus * kBlocksPerCU;
     if (blocks > resident) blocks = resident;
@@ -360,11 +361,10 @@ hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, const RaggedPlan
     tile_balance_plan(balance, blocks, resident, kWavesPerBlock, it);
     // The hops that let frame B reuse frame A's loads: a quarter frame (75 % overlap) for
     // the row and magnitude modes, half a frame (the fast scan's 50 %) for the band mode.
-    // SONO_FORCE_ANY_HOP=1 (read per launch) takes the any-hop form regardless: the tests compare the two.
+    // The engine option "force_any_hop" takes the any-hop form regardless: the tests compare the two.
     constexpr int kHopQ = MODE == MODE_BAND ? 2 : 1;
-    const char *any_hop = std::getenv("SONO_FORCE_ANY_HOP");
     // (a geometry that keeps one frame per lane in pass 1 loads every frame whole: it has the any-hop form only)
-    const bool q = !G::SPLIT && a.hop * (kHopQ == 2 ? 2u : 4u) == (unsigned int)G::N && !(any_hop && any_hop[0] && any_hop[0] != '0');
+    const bool q = !G::SPLIT && a.hop * (kHopQ == 2 ? 2u : 4u) == (unsigned int)G::N && !t.any_hop;
     constexpr int kQ = G::SPLIT ? 0 : kHopQ;
     if (a.x16 && (plan || MODE == MODE_MAG)) return hipErrorInvalidValue;
     if constexpr (MODE != MODE_MAG) {
@@ -385,16 +385,16 @@ hipError_t launch_one(const StftArgs &a, const float2 *tw_rows, const RaggedPlan
 }
 
 template <int MODE>
-hipError_t launch_mode(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, TileBalance *balance, hipStream_t stream)
+hipError_t launch_mode(const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream)
 {
     switch (a.N) {
 #ifndef SONO_EXP_ONLY_1024      // tools/expbuild.sh: quicker experimental builds
-    case 4096: return launch_one<6, 6, MODE>(a, tw_rows, plan, balance, stream);
-    case 2048: return launch_one<11 - tile_log_r2(2048), tile_log_r2(2048), MODE>(a, tw_rows, plan, balance, stream);
-    case 512: return launch_one<9 - tile_log_r2(512), tile_log_r2(512), MODE>(a, tw_rows, plan, balance, stream);
-    case 256: return launch_one<3, 5, MODE>(a, tw_rows, plan, balance, stream);
+    case 4096: return launch_one<6, 6, MODE>(a, t, plan, stream);
+    case 2048: return launch_one<11 - tile_log_r2(2048), tile_log_r2(2048), MODE>(a, t, plan, stream);
+    case 512: return launch_one<9 - tile_log_r2(512), tile_log_r2(512), MODE>(a, t, plan, stream);
+    case 256: return launch_one<3, 5, MODE>(a, t, plan, stream);
 #endif
-    case 1024: return launch_one<10 - tile_log_r2(1024), tile_log_r2(1024), MODE>(a, tw_rows, plan, balance, stream);
+    case 1024: return launch_one<10 - tile_log_r2(1024), tile_log_r2(1024), MODE>(a, t, plan, stream);
     default: return hipErrorInvalidValue;
     }
 }

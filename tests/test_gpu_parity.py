@@ -20,7 +20,7 @@ def kernel_path(request, monkeypatch):
     """Runs a test once through the normal kernel dispatch, once with the generic
     LDS-staged kernel forced and once with the tiled kernel's any-hop form forced
     where the dispatch would pick the shared-load form (SONO_FORCE_GENERIC and
-    SONO_FORCE_ANY_HOP are read per launch)."""
+    SONO_FORCE_ANY_HOP are read when an engine is created; every test creates its engines itself)."""
     monkeypatch.delenv("SONO_FORCE_GENERIC", raising=False)
     monkeypatch.delenv("SONO_FORCE_ANY_HOP", raising=False)
     if request.param == "generic":
@@ -155,12 +155,8 @@ def test_random_configurations_against_oracle(seed):
     ref = np.asarray(o.compute_spectrogram_u8(x, V, gain, rng_db))
     nd, nt = parity.u8_diff(u8, ref, what)                   # never more than 1 LSB, wherever
     if nt:
-        # the 0.1 % bound counts the bins within 80 dB of their frame's peak: further down two f32 FFTs differ by
-        # their own rounding (1e-7 of the frame's peak), which a range of 100 dB can see
-        rows = ref_mag.reshape(-1, N // 2)
-        live = rows >= rows.max(axis=1, keepdims=True) * 1e-4
-        nd = int(((u8.reshape(rows.shape) != ref.reshape(rows.shape)) & live).sum())
-        assert nd <= max(2, parity.U8_MAX_FRACTION * live.sum()), what
+        nd = parity.u8_count_for_bound(u8, ref, ref_mag, N // 2, rng_db)
+        assert nd[0] <= max(2, parity.U8_MAX_FRACTION * nd[1]), what
     gmax = o.get_global_max()
     assert abs(e.get_global_max() - gmax) <= 1e-6 * gmax, what
     for ratio in (0.0, 0.4):
@@ -672,22 +668,20 @@ def test_ragged_launches_back_to_back_keep_their_own_tables():
 @pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096])
 def test_shared_loads_change_nothing(monkeypatch, N):
     # hop = N/4: frame B takes the rows it shares with frame A from A's registers instead of loading them again;
-    # SONO_FORCE_ANY_HOP=1 (read per launch) selects the form that loads both frames whole -- identical bits
+    # the engine option "force_any_hop" selects the form that loads both frames whole -- identical bits
     V, H = N - N // 4, N // 4
     x = signal(N + 41 * H + 5, N + 1)
     x[: N + H] = 0.0
     x[N + 6 * H: N + 7 * H] *= 300.0                      # a burst that only some frames see
     res = []
+    monkeypatch.delenv("SONO_FORCE_ANY_HOP", raising=False)
     for any_hop in (False, True):
-        if any_hop:
-            monkeypatch.setenv("SONO_FORCE_ANY_HOP", "1")
-        else:
-            monkeypatch.delenv("SONO_FORCE_ANY_HOP", raising=False)
         e = sa.SpectrogramEngine(N, "hann")
+        assert not e.get_option("force_any_hop")
+        e.set_option("force_any_hop", any_hop)
         u8 = e.compute_spectrogram_u8(x, V, 20.0, 80.0)
         res.append((e.compute_spectrogram(x, V), u8, e.get_peaks(0.0), e.get_peak_magnitudes(0.0), np.float32(e.get_global_max())))
         e.free()
-    monkeypatch.delenv("SONO_FORCE_ANY_HOP", raising=False)
     for a, b in zip(res[0], res[1]):
         assert np.array_equal(a, b)
     assert res[0][1].any()

@@ -20,16 +20,16 @@ def test_streamed_rows_equal_one_copy_rows(n_fft, noverlap, chunks, monkeypatch)
     x = synth.chirp_numpy(0, n, 384000, stream=5)
     x[n // 3: n // 3 + 4 * n_fft] = 0.0                                 # some exactly silent frames
     e = sa.SpectrogramEngine(n_fft, "blackman" if n_fft == 4096 else "hann")
-    monkeypatch.delenv("SONO_NO_STREAMING", raising=False)
+    e.set_option("no_streaming", False)
     a = e.compute_spectrogram_u8(x, noverlap, 20.0, 80.0)
     pa, ma, ga = e.get_peaks(0.3), e.get_peak_magnitudes(0.0), e.get_global_max()
-    monkeypatch.setenv("SONO_NO_STREAMING", "1")
+    e.set_option("no_streaming", True)
     b = e.compute_spectrogram_u8(x, noverlap, 20.0, 80.0)
     pb, mb, gb = e.get_peaks(0.3), e.get_peak_magnitudes(0.0), e.get_global_max()
     assert a.shape == b.shape == (frames * (n_fft // 2),)
     assert np.array_equal(a, b) and np.array_equal(pa, pb) and np.array_equal(ma, mb) and ga == gb
     # the rings are reused by a second, shorter streamed call
-    monkeypatch.delenv("SONO_NO_STREAMING", raising=False)
+    e.set_option("no_streaming", False)
     m = (int(per_chunk * 2.05) - 1) * hop + n_fft
     c = e.compute_spectrogram_u8(x[:m], noverlap, 20.0, 80.0)
     assert np.array_equal(c, b[: c.size])

@@ -326,3 +326,31 @@ def test_tile_peak_rule_on_near_ties(emul):
     p[10], p[200] = hi, lo                    # the earlier bin larger: both rules agree
     assert peak(p)[0] == reference_rule(p)[0] == 10
     assert peak(np.zeros(512, np.float32)) == (0, np.float32(0.0))
+
+
+def test_quantiser_rounding_rule_is_pinned(emul):
+    """The reference truncates v = (dB - floor) * 255 / range to a code (lib.rs:277-293: `as u8`).  The kernels convert
+    v - 1/2 with round-to-nearest-even (one v_cvt_pk_u8_f32), which equals trunc(v) for every v >= 0 that is not an
+    integer, and differs in exactly one place: an exactly integral ODD v comes out one code lower (v - 1/2 is a tie and
+    goes to the even neighbour below).  That deviation is deliberate and is what the 1-LSB tolerance of the u8 rows
+    covers; this test pins it so that a later change cannot widen it silently."""
+    emul.emul_code_of.restype = C.c_uint
+    emul.emul_code_of.argtypes = [C.c_float]
+    code = lambda v: emul.emul_code_of(C.c_float(v))
+    for k in range(0, 256):
+        assert code(float(k)) == (k if k % 2 == 0 else k - 1), k                   # exact integers: even stays, odd drops one
+        if k < 255:
+            for frac in (2.0 ** -16, 0.25, 0.5, 0.75, 1.0 - 2.0 ** -16):           # everything in between truncates
+                assert code(k + frac) == k, (k, frac)
+    assert code(-0.0) == 0 and code(-1e-6) == 0 and code(-1e30) == 0 and code(float("-inf")) == 0      # saturation below
+    assert code(255.4) == 255 and code(256.0) == 255 and code(1e30) == 255 and code(float("inf")) == 255      # and above
+    assert code(float("nan")) == 0
+    emul.emul_quantise.restype = C.c_uint
+    emul.emul_quantise.argtypes = [C.c_float, C.c_uint, C.c_float, C.c_float]
+    q = lambda p, N=1024, gain=20.0, rng=80.0: emul.emul_quantise(C.c_float(p), N, C.c_float(gain), C.c_float(rng))
+    assert q(0.0) == 0 and q(float("nan")) == 0 and q(float("inf")) == 255 and q(1e-30) == 0
+    assert q(0.0, 1024, 20.0, 200.0) == q(1e-30, 1024, 20.0, 200.0)                 # the 1e-10 floor, where the range can see it
+    # full scale: |X| * 2/N = 1 -> 0 dB = gain above the top of the range -> 255; the top code's lower edge: -gain dB
+    assert q((1.0 * 1024) ** 2) == 255
+    top = (10.0 ** (-20.0 / 20.0) * 1024) ** 2
+    assert q(top * 1.001) == 255 and q(top * 0.98) == 254

@@ -9,8 +9,8 @@ OUT="$ROOT/gpurun_out/prof"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-end-to-end $*"
-TRACE_BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --cpu-seconds 0 --no-end-to-end $*"    # the default step count: its average is the one bench.py reports
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-end-to-end --no-latency $*"
+TRACE_BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --cpu-seconds 0 --no-end-to-end --no-latency $*"    # the default step count: its average is the one bench.py reports
 
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $TRACE_BENCH > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; tail -5 "$OUT/trace.log"; exit 1; }
 

@@ -58,7 +58,18 @@ for f in find("*/**/*counter_collection.csv"):
 # On gfx950 FETCH_SIZE tallies each 128-byte read request as 64 bytes, so read bytes = 2 x FETCH_SIZE; that the
 # factor applies to this kernel's loads is confirmed by the result itself: without it the kernel would have
 # fetched less than the samples it provably reads once.  WRITE_SIZE is exact.
+import hashlib
 import json
+
+# The counters describe ONE build of the library: its hash goes into the files, and bench.py only quotes them
+# beside a timing of that same build (a rebuilt kernel would otherwise keep reporting the old counters).
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = os.environ.get("SONO_LIB_PATH") or os.path.join(_root, "spectrogram_amd", "lib", "libsonostft.so")
+try:
+    with open(_lib, "rb") as _fh:
+        LIB_SHA256 = hashlib.sha256(_fh.read()).hexdigest()
+except OSError:
+    LIB_SHA256 = None
 
 vals = {}
 for f in find("*/**/*counter_collection.csv"):
@@ -74,7 +85,7 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     read_b, write_b = 2.0 * vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
     out_json = {"fft_size": 1024, "noverlap": 768, "seconds": 3600, "fetch_size_kib": vals["FETCH_SIZE"],
                 "write_size_kib": vals["WRITE_SIZE"], "read_bytes": read_b, "write_bytes": write_b,
-                "hbm_bytes": read_b + write_b,
+                "hbm_bytes": read_b + write_b, "lib_sha256": LIB_SHA256,
                 "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per dispatch of the STFT kernel; "
                           "reads = 2 x FETCH_SIZE (gfx950 counts a 128-B request as 64 B), writes = WRITE_SIZE"}
     with open(os.path.join(out, "hbm_traffic.json"), "w") as fh:
@@ -89,7 +100,7 @@ if "SQ_INSTS_VALU" in vals and "SQ_WAVE_CYCLES" in vals:
     vc = {"insts_valu": vals["SQ_INSTS_VALU"], "active_inst_valu_quadcycles": vals.get("SQ_ACTIVE_INST_VALU"),
           "wave_quadcycles": vals["SQ_WAVE_CYCLES"], "wait_inst_any_quadcycles": vals.get("SQ_WAIT_INST_ANY"),
           "wait_any_quadcycles": vals.get("SQ_WAIT_ANY"), "active_inst_any_quadcycles": vals.get("SQ_ACTIVE_INST_ANY"),
-          "waves": vals.get("SQ_WAVES"), "dispatch_cycles": cyc,
+          "waves": vals.get("SQ_WAVES"), "dispatch_cycles": cyc, "lib_sha256": LIB_SHA256,
           "source": "rocprofv3 --pmc passes of tools/profile.sh over bench.py, mean per dispatch of the STFT kernel"}
     if cyc > 0:
         # one vector instruction per 2 cycles and SIMD is the rate plain add / mul / fma instructions issue at
