@@ -292,13 +292,14 @@ def main():
     peak_mag = torch.empty(frames, dtype=torch.float32, device="cuda")
     gmax = torch.zeros(1, dtype=torch.int32, device="cuda")
     features_only = args.workload in ("cfg5", "cfg5_pcm16")
-    pcm16 = args.workload in ("cfg2_pcm16", "cfg5_pcm16")
+    pcm16 = args.workload in ("cfg2_pcm16", "cfg5_pcm16", "cfg5")
     if pcm16:
         x = torch.clamp(torch.round(x * 32768.0), -32768, 32767).to(torch.int16)
     bytes_per_frame = (2 if pcm16 else 4) * hop + (0 if features_only else bins) + 6
     detect = args.workload == "cfg5"          # the survey pass with the detector behind it
     if detect:
-        # sono_process_full_file takes the recording as the reference's processFullFile does: a host array
+        # the whole-file detector takes the recording as a host array, like the reference's processFullFile; here as the
+        # 16-bit samples a WAV file holds (sono_process_full_file_pcm16): 2 bytes per sample on the host and over the link
         from spectrogram_amd import framing
         x_host = x.cpu().numpy()
         det_rows = []
@@ -324,13 +325,20 @@ def main():
             engine.stft_u8_pcm16_dev(x.data_ptr(), n_streams, per, per, 1, 0, noverlap, GAIN_DB, RANGE_DB, out.data_ptr(),
                                      peak_bin.data_ptr(), peak_mag.data_ptr(), gmax.data_ptr(), stream.cuda_stream)
             return
-        if pcm16:
-            engine.stft_u8_pcm16_dev(x.data_ptr(), 1, per, per, 1, 0, noverlap, GAIN_DB, RANGE_DB, 0, peak_bin.data_ptr(),
-                                     peak_mag.data_ptr(), gmax.data_ptr(), stream.cuda_stream)
-            engine.stft_band_active_pcm16_dev(x.data_ptr(), 1, per, per, 1, 0, scan_v, min_bin, max_bin, target,
-                                              active.data_ptr(), 0, stream.cuda_stream)
+        if pcm16 and not detect:
+            # features at hop N/4 and the fast scan's flags at hop N/2 in ONE read of the samples, then the run list
+            engine.stft_survey_pcm16_dev(x.data_ptr(), 1, per, per, 1, 0, min_bin, max_bin, target, peak_bin.data_ptr(),
+                                         peak_mag.data_ptr(), gmax.data_ptr(), active.data_ptr(), 0, stream.cuda_stream)
             sa._check(sa.lib().sono_detect_runs_dev(engine._handle(), active.data_ptr(), scan_frames, run_first.data_ptr(),
                                                     run_last.data_ptr(), run_count.data_ptr(), stream.cuda_stream))
+            return
+        if detect:
+            engine.stft_u8_pcm16_dev(x.data_ptr(), 1, per, per, 1, 0, noverlap, GAIN_DB, RANGE_DB, 0, peak_bin.data_ptr(),
+                                     peak_mag.data_ptr(), gmax.data_ptr(), stream.cuda_stream)
+            # processFullFile (batCallDetector.js:584-840) in one library call: fast scan at 50 % overlap, regions,
+            # analysis spectrograms at hop 32, framing and measurement of every call; then the table's rows
+            det_rows[:] = [framing.process_full_file_table(engine, x_host, sr, 10.0, 128.0, {"threshold_dB": -60, "padding_ms": 5},
+                                                           {"debugMode": True}, file_id=rank, channel=0)]
             return
         if not features_only:
             engine.stft_u8_dev(x.data_ptr(), n_streams, per, per, noverlap, GAIN_DB, RANGE_DB, out.data_ptr(),
@@ -338,12 +346,6 @@ def main():
             return
         engine.stft_features_dev(x.data_ptr(), 1, per, per, noverlap, peak_bin.data_ptr(), peak_mag.data_ptr(),
                                  gmax.data_ptr(), stream.cuda_stream)
-        if detect:
-            # processFullFile (batCallDetector.js:584-840) in one library call: fast scan at 50 % overlap, regions,
-            # analysis spectrograms at hop 32, framing and measurement of every call; then the table's rows
-            det_rows[:] = [framing.process_full_file_table(engine, x_host, sr, 10.0, 128.0, {"threshold_dB": -60, "padding_ms": 5},
-                                                           {"debugMode": True}, file_id=rank, channel=0)]
-            return
         engine.stft_band_active_dev(x.data_ptr(), 1, per, per, scan_v, min_bin, max_bin, target, active.data_ptr(), 0,
                                     stream.cuda_stream)
         sa._check(sa.lib().sono_detect_runs_dev(engine._handle(), active.data_ptr(), scan_frames, run_first.data_ptr(),
@@ -407,11 +409,13 @@ def main():
             "cfg4": f"{seconds:g} s synthetic {sr} Hz recording per GPU, FFT {n_fft} Blackman(0.16), 95% overlap (hop {hop}), "
                     f"uint8 dB frames + peaks, {frames} frames per GPU",
             "cfg5_pcm16": f"{seconds / 3600:g} h synthetic {sr} Hz channel per GPU as 16-bit PCM in HBM: per-frame peak features at FFT "
-                          f"{n_fft} 75% overlap ({frames} frames, no u8 rows) + fused fast scan at 50% overlap + run extraction",
-            "cfg5": f"{seconds / 3600:g} h synthetic {sr} Hz channel per GPU: per-frame peak features at FFT {n_fft} 75% overlap "
-                    f"({frames} frames, no u8 rows) + the whole detector on the channel (processFullFile: fast scan at 50% overlap, "
-                    f"regions, analysis spectrograms at hop 32, call framing and measurement; recording handed over as a host "
-                    f"array, so its upload is inside the step) + call-summary rows, gathered over the ranks after the timed region",
+                          f"{n_fft} 75% overlap ({frames} frames, no u8 rows) and the fast scan's flags at 50% overlap from ONE "
+                          f"launch over the samples (sono_stft_survey_pcm16_dev) + run extraction",
+            "cfg5": f"{seconds / 3600:g} h synthetic {sr} Hz channel per GPU as 16-bit PCM: per-frame peak features at FFT {n_fft} 75% "
+                    f"overlap ({frames} frames, no u8 rows) + the whole detector on the channel (processFullFile: fast scan at 50% "
+                    f"overlap, regions, analysis spectrograms at hop 32, call framing and measurement; recording handed over as a "
+                    f"host int16 array, so its upload is inside the step) + call-summary rows, gathered over the ranks after the "
+                    f"timed region",
         }[args.workload]
         result = {
             "metric": "STFT frames/sec (audio-sec/sec) at FFT 1024, 75% overlap, 384 kHz; % HBM roofline",
@@ -450,8 +454,12 @@ def main():
             result["roofline"]["note"] = ("kernel_ms covers the features pass AND what follows it in the step (fast scan; cfg5: "
                                           "the detector's device work); bytes_per_frame counts the features pass only")
         if detect:
+            import resource
             result["calls"] = {"rows_all_ranks": int(call_table.shape[0]), "rows_rank0": int(det_rows[0].shape[0]),
                                "columns": len(sharding.COLUMNS)}
+            result["ms_per_hour_of_audio"] = ms_per_step / (seconds / 3600.0)
+            result["host_rss_peak_gb"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576.0
+            result["host_threads_per_rank"] = sa.host_threads()
         lib_hash = library_sha256()
         result["lib_sha256"] = lib_hash
         traffic, counters = None, None

@@ -288,6 +288,23 @@ int sono_stft_band_active_pcm16_dev(sono_engine *e, const int16_t *d_pcm, size_t
                                     size_t samples_per_stream, uint32_t channels, uint32_t channel, uint32_t noverlap,
                                     uint32_t min_bin, uint32_t max_bin, double target_energy_sum, uint8_t *d_active,
                                     double *d_band_energy, void *hip_stream);
+
+/* The survey pass over long channels in ONE read of the samples: the per-frame peak features of
+ * sono_stft_features_dev at 75 % overlap (hop N/4: d_peak_bin / d_peak_mag, one per frame, and the global maximum;
+ * lib.rs:349-443) AND the fast scan's band test of sono_stft_band_active_dev at 50 % overlap
+ * (batCallDetector.js:878-949: d_active / d_band_energy, one per scan frame = ceil(frames / 2) per stream, stream
+ * after stream) -- the scan's frames are the even frames of the feature pass.  The peak outputs equal those of the
+ * separate calls bit for bit; the band sums add the same terms in another order (flags equal unless a sum lies
+ * within rounding of the threshold).  Fused at fft 1024 (the detector's analysis engine, wsManager.js:350-361); other
+ * sizes run the two passes one after the other.  The _pcm16 form reads 16-bit sample frames like
+ * sono_stft_u8_pcm16_dev. */
+int sono_stft_survey_dev(sono_engine *e, const sono_batch *in, uint32_t min_bin, uint32_t max_bin, double target_energy_sum,
+                         uint16_t *d_peak_bin, float *d_peak_mag, uint32_t *d_gmax_bits, uint8_t *d_active, double *d_band_energy,
+                         void *hip_stream);
+int sono_stft_survey_pcm16_dev(sono_engine *e, const int16_t *d_pcm, size_t n_streams, size_t stream_stride, size_t samples_per_stream,
+                               uint32_t channels, uint32_t channel, uint32_t min_bin, uint32_t max_bin, double target_energy_sum,
+                               uint16_t *d_peak_bin, float *d_peak_mag, uint32_t *d_gmax_bits, uint8_t *d_active, double *d_band_energy,
+                               void *hip_stream);
 int sono_detect_band_active_dev(sono_engine *e, const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin,
                                 uint32_t max_bin, double target_energy_sum, uint8_t *d_active,
                                 double *d_band_energy /* may be NULL */, void *hip_stream);
@@ -589,6 +606,14 @@ typedef struct sono_full_file_call {
 } sono_full_file_call;
 int sono_process_full_file(sono_engine *e, const float *x, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
                            const sono_full_file_options *opt, sono_full_file_call *out, size_t cap, size_t *count);
+/* The same on a recording held as a WAV file holds it: `n` interleaved 16-bit sample frames of `channels` channels in
+ * host memory, of which `channel` is analysed (fileLoader.js:7-63 reads such files; the browser's decoder turns the
+ * integers into value / 32768, which is exact, so the calls equal those of sono_process_full_file on the converted
+ * floats value for value).  The recording crosses the link as 16-bit data -- half the bytes -- and no float copy of
+ * it exists on the host. */
+int sono_process_full_file_pcm16(sono_engine *e, const int16_t *pcm, size_t n, uint32_t channels, uint32_t channel, double sample_rate,
+                                 double flow_khz, double fhigh_khz, const sono_full_file_options *opt, sono_full_file_call *out,
+                                 size_t cap, size_t *count);
 /* The engine keeps the calls of its last sono_process_full_file.  When that returned SONO_ECAPACITY (*count = the
  * number of calls, the first cap of them written), fetch them all here with a larger buffer instead of running the
  * recording again.  cap = 0 only asks for the count. */

@@ -193,6 +193,11 @@ _SIGNATURES = {
     "sono_stft_band_active_pcm16_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32,
                                                   C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_void_p,
                                                   C.c_void_p, C.c_void_p]),
+    "sono_stft_survey_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sono_stft_survey_pcm16_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32,
+                                             C.c_uint32, C.c_uint32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
     "sono_stft_mag_f32_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_void_p, C.c_void_p]),
     "sono_stft_features_dev": (C.c_int, [C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p]),
@@ -233,6 +238,8 @@ _SIGNATURES = {
     "sono_db_percentile_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.POINTER(C.c_float), C.c_void_p]),
     "sono_process_full_file": (C.c_int, [C.c_void_p, _f32p, C.c_size_t, C.c_double, C.c_double, C.c_double,
                                          C.POINTER(FullFileOptions), C.POINTER(FullFileCall), C.c_size_t, _szp]),
+    "sono_process_full_file_pcm16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_double, C.c_double,
+                                               C.c_double, C.POINTER(FullFileOptions), C.POINTER(FullFileCall), C.c_size_t, _szp]),
     "sono_full_file_results": (C.c_int, [C.c_void_p, C.POINTER(FullFileCall), C.c_size_t, _szp]),
     "sono_full_file_call_spectrogram": (C.c_int, [C.c_void_p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_double), C.c_size_t, _f32p,
                                                   C.c_size_t, _szp, _szp, _u32p]),
@@ -504,6 +511,22 @@ class SpectrogramEngine:
                                                      int(samples_per_stream), int(channels), int(channel), int(noverlap),
                                                      int(min_bin), int(max_bin), float(target_energy_sum), d_active,
                                                      d_band_energy or None, stream or None))
+
+    def stft_survey_dev(self, d_samples, n_streams, stream_stride, samples_per_stream, min_bin, max_bin, target_energy_sum,
+                        d_peak_bin, d_peak_mag, d_gmax_bits, d_active, d_band_energy=0, stream=0):
+        """Peak features at hop N/4 and the fast scan's band flags at hop N/2 (one per EVEN frame) in one read of the samples."""
+        b = Batch(d_samples, n_streams, stream_stride, samples_per_stream)
+        _check(lib().sono_stft_survey_dev(self._handle(), C.byref(b), int(min_bin), int(max_bin), float(target_energy_sum),
+                                          d_peak_bin or None, d_peak_mag or None, d_gmax_bits or None, d_active,
+                                          d_band_energy or None, stream or None))
+
+    def stft_survey_pcm16_dev(self, d_pcm, n_streams, stream_stride, samples_per_stream, channels, channel, min_bin, max_bin,
+                              target_energy_sum, d_peak_bin, d_peak_mag, d_gmax_bits, d_active, d_band_energy=0, stream=0):
+        """stft_survey_dev on interleaved 16-bit sample frames."""
+        _check(lib().sono_stft_survey_pcm16_dev(self._handle(), d_pcm, int(n_streams), int(stream_stride), int(samples_per_stream),
+                                                int(channels), int(channel), int(min_bin), int(max_bin), float(target_energy_sum),
+                                                d_peak_bin or None, d_peak_mag or None, d_gmax_bits or None, d_active,
+                                                d_band_energy or None, stream or None))
 
     def stft_features_dev(self, d_samples, n_streams, stream_stride, samples_per_stream, noverlap,
                           d_peak_bin=0, d_peak_mag=0, d_gmax_bits=0, stream=0):

@@ -21,7 +21,7 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 # the tiled kernel's instantiations come first: they take longest (one translation unit per mode, compiled side by side)
-HIP_SOURCES = ["sono_tile_u8.hip", "sono_tile_mag.hip", "sono_tile_band.hip", "sono_tile.hip", "sono_kernels.hip", "sono_detect.hip",
+HIP_SOURCES = ["sono_tile_u8.hip", "sono_tile_mag.hip", "sono_tile_band.hip", "sono_tile_survey.hip", "sono_tile.hip", "sono_kernels.hip", "sono_detect.hip",
                "sono_capi.hip", "sono_capi_detect.hip", "sono_capi_rois.hip", "sono_capi_noalloc.hip", "sono_stream.hip"]
 CXX_SOURCES = ["sono_host.cpp", "sono_framing.cpp", "sono_measure.cpp"]
 # -fno-slp-vectorize: gfx950 executes v_pk_{add,mul,fma}_f32 at half the rate of the scalar forms

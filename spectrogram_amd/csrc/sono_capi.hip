@@ -616,6 +616,70 @@ int sono_stft_band_active_dev(sono_engine *e, const sono_batch *in, uint32_t nov
     return SONO_OK;
 }
 
+// The survey pass (a night-long channel: per-frame peak features at 75 % overlap, and the detector's fast scan, whose
+// 50 % overlap makes its frames the even frames of the feature pass): one read of the samples where the tiled kernel
+// has the fused form (fft 1024), else the two passes one after the other.  d_pcm != NULL: 16-bit sample frames.
+static int survey_pass(sono_engine *e, const float *d_x, const int16_t *d_pcm, uint32_t channels, uint32_t channel,
+                       size_t n_streams, size_t stream_stride, size_t samples_per_stream, uint32_t min_bin, uint32_t max_bin,
+                       double target, uint16_t *d_peak_bin, float *d_peak_mag, uint32_t *d_gmax_bits, uint8_t *d_active,
+                       double *d_band_energy, void *hip_stream, const char *who)
+{
+    if (!e) return fail(SONO_EINVAL, std::string(who) + ": NULL argument");
+    const uint32_t N = e->N, V = N - N / 4;
+    if (d_pcm && (channels == 0 || channel >= channels)) return fail(SONO_EINVAL, std::string(who) + ": channel out of range");
+    if (n_streams && samples_per_stream && !d_x && !d_pcm) return fail(SONO_EINVAL, std::string(who) + ": the samples are NULL");
+    if (n_streams > 1 && stream_stride < samples_per_stream)
+        return fail(SONO_EINVAL, std::string(who) + ": stream_stride < samples_per_stream");
+    if (max_bin >= N / 2 || min_bin > max_bin) return fail(SONO_EINVAL, std::string(who) + ": need min_bin <= max_bin < fft_size/2");
+    sono_batch in;
+    in.d_samples = d_x; in.n_streams = n_streams; in.stream_stride = stream_stride; in.samples_per_stream = samples_per_stream;
+    sono::StftArgs a;
+    fill_args(e, in, V, a);
+    if (a.n_streams * a.frames_per_stream == 0) return SONO_OK;
+    if (!d_active) return fail(SONO_EINVAL, std::string(who) + ": d_active is NULL");
+    a.x16 = d_pcm; a.x16_channels = d_pcm ? channels : 0; a.x16_channel = d_pcm ? channel : 0;
+    a.peak_bin = d_peak_bin; a.peak_mag = d_peak_mag; a.gmax_bits = d_gmax_bits;
+    a.band_lo = min_bin; a.band_hi = max_bin; a.band_target = target;
+    a.band_active = d_active; a.band_energy = d_band_energy;
+    DeviceGuard guard(e->device);
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    if (!e->tables.force_generic && sono::tile_supports(sono::MODE_SURVEY, a, e->tables.tile)) {
+        HIP_TRY(sono::launch_stft_tile(sono::MODE_SURVEY, a, e->tables.tile, s));
+        return SONO_OK;
+    }
+    // two passes: the features at hop N/4, then the fast scan at hop N/2
+    int rc;
+    if (d_peak_bin || d_peak_mag || d_gmax_bits) {
+        rc = d_pcm ? sono_stft_u8_pcm16_dev(e, d_pcm, n_streams, stream_stride, samples_per_stream, channels, channel, V, 20.0f, 80.0f,
+                                            nullptr, d_peak_bin, d_peak_mag, d_gmax_bits, hip_stream)
+                   : sono_stft_features_dev(e, &in, V, d_peak_bin, d_peak_mag, d_gmax_bits, hip_stream);
+        if (rc) return rc;
+    }
+    return d_pcm ? sono_stft_band_active_pcm16_dev(e, d_pcm, n_streams, stream_stride, samples_per_stream, channels, channel, N / 2,
+                                                   min_bin, max_bin, target, d_active, d_band_energy, hip_stream)
+                 : sono_stft_band_active_dev(e, &in, N / 2, min_bin, max_bin, target, d_active, d_band_energy, hip_stream);
+}
+
+int sono_stft_survey_dev(sono_engine *e, const sono_batch *in, uint32_t min_bin, uint32_t max_bin, double target_energy_sum,
+                         uint16_t *d_peak_bin, float *d_peak_mag, uint32_t *d_gmax_bits, uint8_t *d_active, double *d_band_energy,
+                         void *hip_stream)
+{
+    if (!in) return fail(SONO_EINVAL, "sono_stft_survey_dev: NULL argument");
+    return survey_pass(e, in->d_samples, nullptr, 0, 0, in->n_streams, in->stream_stride, in->samples_per_stream, min_bin, max_bin,
+                       target_energy_sum, d_peak_bin, d_peak_mag, d_gmax_bits, d_active, d_band_energy, hip_stream, "sono_stft_survey_dev");
+}
+
+int sono_stft_survey_pcm16_dev(sono_engine *e, const int16_t *d_pcm, size_t n_streams, size_t stream_stride, size_t samples_per_stream,
+                               uint32_t channels, uint32_t channel, uint32_t min_bin, uint32_t max_bin, double target_energy_sum,
+                               uint16_t *d_peak_bin, float *d_peak_mag, uint32_t *d_gmax_bits, uint8_t *d_active, double *d_band_energy,
+                               void *hip_stream)
+{
+    if (!d_pcm && n_streams && samples_per_stream) return fail(SONO_EINVAL, "sono_stft_survey_pcm16_dev: d_pcm is NULL");
+    return survey_pass(e, nullptr, d_pcm, channels, channel, n_streams, stream_stride, samples_per_stream, min_bin, max_bin,
+                       target_energy_sum, d_peak_bin, d_peak_mag, d_gmax_bits, d_active, d_band_energy, hip_stream,
+                       "sono_stft_survey_pcm16_dev");
+}
+
 int sono_stft_band_active_pcm16_dev(sono_engine *e, const int16_t *d_pcm, size_t n_streams, size_t stream_stride,
                                     size_t samples_per_stream, uint32_t channels, uint32_t channel, uint32_t noverlap,
                                     uint32_t min_bin, uint32_t max_bin, double target_energy_sum, uint8_t *d_active,

@@ -98,6 +98,27 @@ const float *region_audio(const float *x, const float *x_filtered, const sono_ro
     return filtered ? x_filtered : x;
 }
 
+// The recording as the caller's host memory holds it: f32 samples (x) or interleaved 16-bit sample frames (q), of
+// which `channel` is meant (the value / 32768, as the browser's decoder hands 16-bit WAV data to the reference).
+struct HostSamples {
+    const float *x = nullptr;
+    const int16_t *q = nullptr;
+    uint32_t channels = 1, channel = 0;
+};
+// -> sample 0 of region r as floats: the high-passed copy where the region went through the filter, the caller's
+// floats, or the region's 16-bit samples converted into `tmp` (exact: a division by a power of two).
+const float *region_samples(const HostSamples &hs, const float *x_filtered, const sono_segment *rois, const sono_roi_table *t,
+                            size_t r, double sample_rate, std::vector<float> &tmp)
+{
+    const float *src = region_audio(hs.x, x_filtered, t, r, sample_rate);
+    if (src) return src + rois[r].start;
+    const size_t len = (size_t)(rois[r].end - rois[r].start);
+    tmp.resize(len);
+    const int16_t *q = hs.q + (size_t)rois[r].start * hs.channels + hs.channel;
+    for (size_t i = 0; i < len; ++i) tmp[i] = (float)q[i * hs.channels] * (1.0f / 32768.0f);
+    return tmp.data();
+}
+
 // One pass over a set of regions whose samples sit at d_src + off[i]: magnitudes -> dB crop -> per-frame peak.
 // feat_rows[i] = where region i's records go in the host arrays.
 int peaks_pass(sono_engine *e, const float *d_src, const std::vector<uint64_t> &off, const std::vector<uint64_t> &len,
@@ -177,7 +198,7 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
                         double flow_khz, double fhigh_khz, double hop_percent, int auto_highpass, sono_roi_table *out,
                         size_t frames_cap, float *x_filtered, float *d_rec)
 {
-    if (!e || !out || (n && !x) || (n_rois && !rois)) return fail(SONO_EINVAL, "sono_analyze_rois: NULL argument");
+    if (!e || !out || (n && !x && !d_rec) || (n_rois && !rois)) return fail(SONO_EINVAL, "sono_analyze_rois: NULL argument");
     if (!(sample_rate > 0)) return fail(SONO_EINVAL, "sono_analyze_rois: sample_rate must be positive");
     if (n_rois && (!out->row0 || !out->zonal || !out->highpass_khz))
         return fail(SONO_EINVAL, "sono_analyze_rois: NULL output array");
@@ -405,12 +426,12 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
 }
 
 
-int sono_frame_roi_calls(const float *x, const float *x_filtered, size_t n, const sono_segment *rois, size_t n_rois, const sono_roi_table *t,
-                         double sample_rate, uint32_t fft_size, double call_threshold_db, double min_call_duration_ms,
-                         sono_roi_call *out, size_t cap, size_t *count)
+static int frame_roi_calls(const HostSamples &hs, const float *x_filtered, size_t n, const sono_segment *rois, size_t n_rois,
+                           const sono_roi_table *t, double sample_rate, uint32_t fft_size, double call_threshold_db,
+                           double min_call_duration_ms, sono_roi_call *out, size_t cap, size_t *count)
 {
     if (count) *count = 0;
-    if (!t || (n && !x) || (n_rois && (!rois || !t->row0)) || !(sample_rate > 0) || fft_size == 0)
+    if (!t || (n && !hs.x && !hs.q) || (n_rois && (!rois || !t->row0)) || !(sample_rate > 0) || fft_size == 0)
         return fail(SONO_EINVAL, "sono_frame_roi_calls: NULL or non-positive argument");
     for (size_t r = 0; r < n_rois; ++r)
         if (t->row0[r + 1] > t->row0[r] && (rois[r].end > n || rois[r].end < rois[r].start))
@@ -422,6 +443,7 @@ int sono_frame_roi_calls(const float *x, const float *x_filtered, size_t n, cons
     std::atomic<bool> low_rate{false};
     auto work = [&]() {
         std::vector<double> tf;
+        std::vector<float> converted;
         std::vector<sono::CallFrame> framed;
         std::vector<Cand> cands, kept;
         for (size_t r = next.fetch_add(1); r < n_rois; r = next.fetch_add(1)) {
@@ -454,9 +476,10 @@ int sono_frame_roi_calls(const float *x, const float *x_filtered, size_t n, cons
                 if (!close) kept.push_back(c);
             }
             const double offset = (double)rois[r].start / sample_rate;                  // js:737
+            const float *audio = kept.empty() ? nullptr : region_samples(hs, x_filtered, rois, t, r, sample_rate, converted);
             for (const Cand &c : kept) {
                 const sono::FrameRun run{c.s, c.e};
-                if (!sono::host_frame_calls(&run, 1, tf.data(), F, region_audio(x, x_filtered, t, r, sample_rate) + rois[r].start,
+                if (!sono::host_frame_calls(&run, 1, tf.data(), F, audio,
                                             (size_t)(rois[r].end - rois[r].start), sample_rate,
                                             fft_size, 5.0, min_call_duration_ms, true, framed)) {        // js:743-810
                     low_rate = true;
@@ -506,6 +529,15 @@ int sono_frame_roi_calls(const float *x, const float *x_filtered, size_t n, cons
     return SONO_OK;
 }
 
+int sono_frame_roi_calls(const float *x, const float *x_filtered, size_t n, const sono_segment *rois, size_t n_rois, const sono_roi_table *t,
+                         double sample_rate, uint32_t fft_size, double call_threshold_db, double min_call_duration_ms,
+                         sono_roi_call *out, size_t cap, size_t *count)
+{
+    HostSamples hs;
+    hs.x = x;
+    return frame_roi_calls(hs, x_filtered, n, rois, n_rois, t, sample_rate, fft_size, call_threshold_db, min_call_duration_ms, out, cap, count);
+}
+
 // sono_measure_roi_calls; `keep` (or nullptr) receives, for every call that processFullFile goes on to keep (not
 // discarded, longer than 1 ms: js:802-810), the call's own rows of the dB matrix and the number of its centre times.
 // d_rec (or nullptr): the recording in HBM with the filtered regions already in place (analyze_rois): the calls' frames
@@ -515,7 +547,7 @@ static int measure_roi_calls(sono_engine *e, const float *x, const float *x_filt
                              double fhigh_khz, double hop_percent, int debug_mode, unsigned int threads, sono_call_measurement *out,
                              std::vector<sono::FullFileSlice> *keep, const float *d_rec)
 {
-    if (!e || !t || (n && !x) || (n_rois && (!rois || !t->row0 || !t->zonal)) || (n_calls && (!calls || !out)))
+    if (!e || !t || (n && !x && !d_rec) || (n_rois && (!rois || !t->row0 || !t->zonal)) || (n_calls && (!calls || !out)))
         return fail(SONO_EINVAL, "sono_measure_roi_calls: NULL argument");
     if (!(sample_rate > 0)) return fail(SONO_EINVAL, "sono_measure_roi_calls: sample_rate must be positive");
     if (n_calls == 0) return SONO_OK;
@@ -670,11 +702,13 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filter
                              debug_mode, threads, out, nullptr, nullptr);
 }
 
-int sono_process_full_file(sono_engine *e, const float *x, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
-                           const sono_full_file_options *opt, sono_full_file_call *out, size_t cap, size_t *count)
+static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
+                             const sono_full_file_options *opt, sono_full_file_call *out, size_t cap, size_t *count)
 {
+    const float *x = hs.x;
     if (count) *count = 0;
-    if (!e || !opt || (n && !x) || (cap && !out)) return fail(SONO_EINVAL, "sono_process_full_file: NULL argument");
+    if (!e || !opt || (n && !hs.x && !hs.q) || (cap && !out)) return fail(SONO_EINVAL, "sono_process_full_file: NULL argument");
+    if (hs.q && (hs.channels == 0 || hs.channel >= hs.channels)) return fail(SONO_EINVAL, "sono_process_full_file_pcm16: channel out of range");
     e->full_file_calls.clear();
     e->full_file_slices.clear();
     if (!(sample_rate > 0)) return fail(SONO_EINVAL, "sono_process_full_file: sample_rate must be positive");
@@ -691,8 +725,20 @@ int sono_process_full_file(sono_engine *e, const float *x, size_t n, double samp
     DeviceGuard guard(e->device);
     HIP_TRY(e->d_rec.reserve(n * sizeof(float)));
     float *d_rec = (float *)e->d_rec.p;
-    int rc = sono::upload_host_array(e, d_rec, x, n * sizeof(float), e->stream);
-    if (rc) return rc;
+    int rc;
+    if (hs.q) {
+        // 16-bit sample frames cross the link as they are (half the bytes of the float recording) and become the
+        // resident float recording on the device: everything below reads the same floats as the f32 entry point
+        // would have uploaded (value / 32768 is exact).
+        const size_t bytes = n * (size_t)hs.channels * sizeof(int16_t);
+        HIP_TRY(e->d_in.reserve(bytes));
+        rc = sono::upload_host_array(e, e->d_in.p, hs.q, bytes, e->stream);
+        if (rc) return rc;
+        HIP_TRY(sono::launch_pcm_to_f32(e->d_in.p, n, hs.channels, hs.channel, 16, 0, d_rec, e->stream));
+    } else {
+        rc = sono::upload_host_array(e, d_rec, x, n * sizeof(float), e->stream);
+        if (rc) return rc;
+    }
     rc = sono::fast_scan_resident(e, d_rec, n, sample_rate, flow_khz, fhigh_khz, opt->threshold_db, raw.data(), raw.size(), &n_raw);
     if (rc) return rc;
     lap("upload, fast scan");
@@ -730,8 +776,8 @@ int sono_process_full_file(sono_engine *e, const float *x, size_t n, double samp
     // framing (js:677-794), measurement (js:797) and what follows it (js:802-827)
     std::vector<sono_roi_call> framed(total / 2 + n_rois + 1);
     size_t n_calls = 0;
-    rc = sono_frame_roi_calls(x, xf, n, rois.data(), n_rois, &t, sample_rate, N, opt->call_threshold_db,
-                              opt->min_call_duration_ms, framed.data(), framed.size(), &n_calls);
+    rc = frame_roi_calls(hs, xf, n, rois.data(), n_rois, &t, sample_rate, N, opt->call_threshold_db,
+                         opt->min_call_duration_ms, framed.data(), framed.size(), &n_calls);
     if (rc) return rc;
     lap("framing (host)");
     std::vector<sono_call_measurement> meas(n_calls + 1);
@@ -771,6 +817,23 @@ int sono_process_full_file(sono_engine *e, const float *x, size_t n, double samp
         o.quality = o.snr_db < 10 ? 0 : o.snr_db < 15 ? 1 : o.snr_db < 20 ? 2 : o.snr_db < 30 ? 3 : 4;    // getQualityRating, js:375-387
     }
     return sono_full_file_results(e, out, cap, count);
+}
+
+int sono_process_full_file(sono_engine *e, const float *x, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
+                           const sono_full_file_options *opt, sono_full_file_call *out, size_t cap, size_t *count)
+{
+    HostSamples hs;
+    hs.x = x;
+    return process_full_file(e, hs, n, sample_rate, flow_khz, fhigh_khz, opt, out, cap, count);
+}
+
+int sono_process_full_file_pcm16(sono_engine *e, const int16_t *pcm, size_t n, uint32_t channels, uint32_t channel, double sample_rate,
+                                 double flow_khz, double fhigh_khz, const sono_full_file_options *opt, sono_full_file_call *out,
+                                 size_t cap, size_t *count)
+{
+    HostSamples hs;
+    hs.q = pcm; hs.channels = channels; hs.channel = channel;
+    return process_full_file(e, hs, n, sample_rate, flow_khz, fhigh_khz, opt, out, cap, count);
 }
 
 int sono_full_file_results(sono_engine *e, sono_full_file_call *out, size_t cap, size_t *count)

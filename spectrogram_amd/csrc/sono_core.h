@@ -26,6 +26,8 @@ enum Mode : int {
     MODE_MAG = 0,    // frames x N/2 linear magnitudes           (lib.rs:113-161)
     MODE_U8 = 1,     // frames x N/2 u8 dB codes + peak features (lib.rs:199-304,349-443)
     MODE_POWER = 2,  // frames x (N/2+1) |X|^2 of mean-removed frames (lib.rs:1058-1094)
+    MODE_SURVEY = 4, // tiled kernel, hop N/4: MODE_U8's peak features without rows AND MODE_BAND's test on every second frame
+                     // (the frames of the fast scan's hop N/2): one read of the samples for both (batCallDetector.js:878-949 beside lib.rs:349-443)
     MODE_BAND = 3,   // per frame: sum of mag^2 over a band of bins, compared with a target (batCallDetector.js:913-927);
                      // tiled kernel only
 };
@@ -57,8 +59,8 @@ struct StftArgs {
     float q_floor;                // 0 = no floor (it would not change any code, see make_quant)
     unsigned int band_lo, band_hi;   // MODE_BAND: bins band_lo..band_hi (inclusive, band_hi < N/2)
     double band_target;              // MODE_BAND: a frame is active iff its band energy > band_target
-    uint8_t *band_active;            // MODE_BAND: one flag per frame
-    double *band_energy;             // MODE_BAND, optional: the sums themselves
+    uint8_t *band_active;            // MODE_BAND: one flag per frame; MODE_SURVEY: one per EVEN frame of each stream, ceil(frames / 2) per stream
+    double *band_energy;             // MODE_BAND / MODE_SURVEY, optional: the sums themselves
 };
 
 SONO_HD float2 cadd(float2 a, float2 b) { return float2{a.x + b.x, a.y + b.y}; }

@@ -16,13 +16,15 @@ namespace sono {
 hipError_t launch_tile_u8(const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream);
 hipError_t launch_tile_mag(const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream);
 hipError_t launch_tile_band(const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream);
+hipError_t launch_tile_survey(const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream);
 
 namespace {
 
 
 hipError_t launch_any(int mode, const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream)
 {
-    return mode == MODE_MAG ? launch_tile_mag(a, t, plan, stream)
+    return mode == MODE_SURVEY ? launch_tile_survey(a, t, plan, stream)
+         : mode == MODE_MAG ? launch_tile_mag(a, t, plan, stream)
          : mode == MODE_BAND ? launch_tile_band(a, t, plan, stream)
                              : launch_tile_u8(a, t, plan, stream);
 }
@@ -140,9 +142,10 @@ void tile_balance_plan(TileBalance *b, unsigned long long blocks, unsigned long 
 
 bool tile_supports(int mode, const StftArgs &a, const TileTables &t)
 {
-    if (mode != MODE_MAG && mode != MODE_U8 && mode != MODE_BAND) return false;
+    if (mode != MODE_MAG && mode != MODE_U8 && mode != MODE_BAND && mode != MODE_SURVEY) return false;
+    if (mode == MODE_SURVEY && (a.N != 1024 || a.hop * 4u != a.N)) return false;      // the one form the fused survey pass is built in
     if (a.x16 && (mode == MODE_MAG || a.x16_channels == 0 || a.x16_channel >= a.x16_channels)) return false;
-    if (mode == MODE_BAND && (!a.band_active || a.band_hi >= a.N / 2 || a.band_lo > a.band_hi)) return false;
+    if ((mode == MODE_BAND || mode == MODE_SURVEY) && (!a.band_active || a.band_hi >= a.N / 2 || a.band_lo > a.band_hi)) return false;
     if (a.N != 4096 && a.N != 2048 && a.N != 1024 && a.N != 512 && a.N != 256) return false;
     if (!t.d_blob || t.N != a.N) return false;
     const unsigned long long tps = (a.frames_per_stream + 1) / 2;

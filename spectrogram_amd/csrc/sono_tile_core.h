@@ -392,6 +392,7 @@ struct TileLane {
     static constexpr int SHIFT = HOPQ == 1 ? G::R1 / 4 : HOPQ == 2 ? G::R1 / 2 : 0;
     static constexpr int OWN_B = SHIFT ? G::R1 - SHIFT : 0;   // first row of frame B that is loaded for B itself
     static constexpr bool SPLIT = G::SPLIT;
+    static constexpr bool FEATURES = MODE == MODE_U8 || MODE == MODE_SURVEY;      // per-frame peak features and the global maximum
     const StftArgs &a;
     int lane;
     // samples of frames A / B of job jj at [jj*R1 + n1] (B: rows >= OWN_B only); SPLIT: xa = this lane's frame, row n1 at [n1]
@@ -778,7 +779,7 @@ struct TileLane {
                     o.z = fast_sqrt(p[2]) * a.inv_n; o.w = fast_sqrt(p[3]) * a.inv_n;
                     *(float4 *)((a.out_mag + tile_elem) + ((size_t)lane_elem + 2 * G::R1 * (m0 + i))) = o;
                 } else {
-                    if (a.out_u8) {
+                    if (MODE == MODE_U8 && a.out_u8) {
                         unsigned int packed = quantise<FLOOR, 0>(p[0], qa, qc, a.q_floor);
                         packed = quantise<FLOOR, 1>(p[1], qa, qc, a.q_floor, packed);
                         packed = quantise<FLOOR, 2>(p[2], qa, qc, a.q_floor, packed);
@@ -793,7 +794,7 @@ struct TileLane {
                 }
             });
         }
-        if (MODE == MODE_U8) {
+        if (FEATURES) {
             const float4 w4 = *(const float4 *)(row + 2 * G::R1 * best_m);
             const float w[4] = {w4.x * fix, w4.y, w4.z, w4.w};
             const int r = w[0] == best_p ? 0 : w[1] == best_p ? 1 : w[2] == best_p ? 2 : 3;
@@ -845,12 +846,61 @@ struct TileLane {
         if (a.band_energy) a.band_energy[g] = total;
     }
 
+    // MODE_SURVEY, after the feature epilogue: the band energy of the tile's EVEN frames (the fast scan's frames: its
+    // hop is twice the features' hop, and both start at sample 0).  All 64 lanes share the FPW/2 even frames, R1
+    // lanes per frame: lane (e, h, l) takes the bins 4l + 2*R1*(2m + h) + r (m < R2/8, r < 4) of frame 2e.  Step 2 (the
+    // caller's): add up the R1 lanes of the frame, pairing lanes by xor R1/2 ... 1.  Each term is MODE_BAND's term
+    // (double of the f32 magnitude, squared); only the order of the additions differs from that mode's.
+    SONO_HD double survey_band_sum(const float *P, const float *meta) const
+    {
+        static_assert(R2 % 8 == 0, "half of a frame's reads per lane");
+        const int frame = 2 * (lane >> LOG_R1), h = (lane >> (LOG_R1 - 1)) & 1, l0 = lane & (G::HALF - 1);
+        const int l = (l0 - G::ROT * frame) & (G::HALF - 1);
+        const float fix = ((4 * l) & (G::HALF - 1)) == 0 ? meta[kMetaFix + frame] : 1.0f;
+        const float *row = P + frame * G::PROW + 4 * l;
+        constexpr int NB = R2 / 8;
+        // Read i of every lane covers the bins [2*R1*2i, 2*R1*(2i + 2)): the reads that lie outside the band altogether
+        // (a third of them for the detector's 10 ... 128 kHz at 384 kHz) are left out, the same ones in every lane.
+        float4 p4[NB];
+        static_for<0, NB>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            if ((unsigned int)(4 * G::R1 * i) <= a.band_hi && (unsigned int)(4 * G::R1 * (i + 1)) > a.band_lo)
+                p4[i] = *(const float4 *)(row + 2 * G::R1 * (2 * i + h));
+        });
+        double acc = 0.0;
+        static_for<0, NB>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            if ((unsigned int)(4 * G::R1 * i) <= a.band_hi && (unsigned int)(4 * G::R1 * (i + 1)) > a.band_lo) {
+                const unsigned int k0 = (unsigned int)(4 * l + 2 * G::R1 * (2 * i + h));
+                const float p[4] = {p4[i].x * fix, p4[i].y, p4[i].z, p4[i].w};
+                static_for<0, 4>([&](auto r_) {
+                    constexpr int r = decltype(r_)::value;
+                    const double m = (double)(fast_sqrt(p[r]) * a.inv_n);
+                    const double t = m * m;
+                    acc += (k0 + r >= a.band_lo && k0 + r <= a.band_hi) ? t : 0.0;
+                });
+            }
+        });
+        return acc;
+    }
+    // Step 3: the frame's first lane writes flag (and sum) number (frame index / 2) of its stream.
+    SONO_HD void survey_band_emit(const TileRef &tr, double total) const
+    {
+        const int frame = 2 * (lane >> LOG_R1);
+        if ((lane & (G::R1 - 1)) != 0 || (unsigned int)frame >= tr.rem) return;
+        // tr.row0 = the stream's index x frames_per_stream; the scan has ceil(frames / 2) frames per stream
+        const unsigned long long stream = a.frames_per_stream ? tr.row0 / a.frames_per_stream : 0ull;
+        const unsigned long long g = stream * ((a.frames_per_stream + 1) / 2) + ((unsigned long long)tr.j * G::FPW + (unsigned int)frame) / 2;
+        a.band_active[g] = total > a.band_target ? 1 : 0;
+        if (a.band_energy) a.band_energy[g] = total;
+    }
+
     // pmax / bin = the frame's largest |2X|^2 and its lowest bin (the epilogue's values
     // reduced over the frame's lanes): the frame's first lane emits the features.
     SONO_HD void features(const TileRef &tr, float pmax, unsigned int bin) const
     {
         const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
-        if (MODE != MODE_U8 || l != 0) return;
+        if (!FEATURES || l != 0) return;
         const unsigned long long f0 = (unsigned long long)tr.j * G::FPW;
         if ((unsigned int)frame >= tr.rem) return;
         const unsigned long long g0 = tr.row0 + f0;           // a scalar; the lane adds its frame

@@ -270,11 +270,17 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
             unsigned int best_k;
             if (MODE == MODE_U8 && a.q_floor > 0.0f) L.template epilogue<true>(tr, img, meta, best_p, best_k);
             else L.template epilogue<false>(tr, img, meta, best_p, best_k);
-            if (MODE == MODE_U8) {
+            if (MODE == MODE_U8 || MODE == MODE_SURVEY) {
                 // the frame's largest power, then the lowest bin among the lanes that hold it (lib.rs:370-378)
                 const float pmax = group_max_f32<LOG_R1 - 1>(best_p);
                 const unsigned int bin = group_min_u32<LOG_R1 - 1>(best_p == pmax ? best_k : 0xFFFFFFFFu);
                 L.features(tr, pmax, bin);
+            }
+            if constexpr (MODE == MODE_SURVEY) {
+                // the fast scan's band test on the tile's even frames, from the power image that is still in place
+                double e = L.survey_band_sum(img, meta);
+                for (int o = G::HALF; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+                L.survey_band_emit(tr, e);
             }
         }
         wave_lds_fence();
@@ -322,7 +328,7 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
             __hip_atomic_store(fb + 3, it.stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // last: a record with this launch's stamp is whole
         }
     }
-    if (MODE == MODE_U8 && a.gmax_bits) {
+    if ((MODE == MODE_U8 || MODE == MODE_SURVEY) && a.gmax_bits) {
         // wave-wide maximum of |2X|^2, then one atomic per wave on the magnitude's bit pattern
         float m = L.run_max;
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -367,6 +373,12 @@ hipError_t launch_one(const StftArgs &a, const TileTables &t, const RaggedPlan *
     const bool q = !G::SPLIT && a.hop * (kHopQ == 2 ? 2u : 4u) == (unsigned int)G::N && !t.any_hop;
     constexpr int kQ = G::SPLIT ? 0 : kHopQ;
     if (a.x16 && (plan || MODE == MODE_MAG)) return hipErrorInvalidValue;
+    if constexpr (MODE == MODE_SURVEY) {        // hop N/4, uniform batches: the two forms this mode is built in
+        if (!q || plan) return hipErrorInvalidValue;
+        if (a.x16) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, kQ, true>), grid, block, 0, stream, a, it, tw_rows);
+        else hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, kQ, false>), grid, block, 0, stream, a, it, tw_rows);
+        return hipGetLastError();
+    } else {
     if constexpr (MODE != MODE_MAG) {
         if (a.x16) {        // 16-bit PCM input: uniform batches of the row and band modes only (tile_supports)
             if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, kQ, true>), grid, block, 0, stream, a, it, tw_rows);
@@ -382,11 +394,18 @@ hipError_t launch_one(const StftArgs &a, const TileTables &t, const RaggedPlan *
         else hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, 0>), grid, block, 0, stream, a, it, tw_rows);
     }
     return hipGetLastError();
+    }
 }
 
 template <int MODE>
 hipError_t launch_mode(const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream)
 {
+    if constexpr (MODE == MODE_SURVEY) {
+        // one geometry only: the detector's analysis engine is fft 1024 (wsManager.js:350-361); other sizes run the
+        // two passes one after the other (sono_capi.hip)
+        if (a.N != 1024 || plan || a.hop * 4u != a.N) return hipErrorInvalidValue;
+        return launch_one<10 - tile_log_r2(1024), tile_log_r2(1024), MODE>(a, t, plan, stream);
+    } else {
     switch (a.N) {
 #ifndef SONO_EXP_ONLY_1024      // tools/expbuild.sh: quicker experimental builds
     case 4096: return launch_one<6, 6, MODE>(a, t, plan, stream);
@@ -396,6 +415,7 @@ hipError_t launch_mode(const StftArgs &a, const TileTables &t, const RaggedPlan 
 #endif
     case 1024: return launch_one<10 - tile_log_r2(1024), tile_log_r2(1024), MODE>(a, t, plan, stream);
     default: return hipErrorInvalidValue;
+    }
     }
 }
 

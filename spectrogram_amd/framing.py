@@ -367,12 +367,18 @@ _CALL_TYPES = ("CF", "FM", "CF-FM")
 _QUALITIES = ("Very Poor", "Poor", "Normal", "Good", "Excellent")
 
 
-def _full_file_call_array(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options, config, threads, keep_spectrograms):
-    """sono_process_full_file -> (ctypes array of sono_full_file_call, number of calls)."""
+def _full_file_call_array(engine, full_audio_data, sample_rate, flow_khz, fhigh_khz, options, config, threads, keep_spectrograms,
+                          pcm_channel=0):
+    """sono_process_full_file -> (ctypes array of sono_full_file_call, number of calls).  An int16 array -- one
+    dimension: a mono recording; two: sample frames x channels, of which pcm_channel is analysed -- goes through
+    sono_process_full_file_pcm16 as it is (the samples mean value / 32768, as a decoded 16-bit WAV file's do)."""
     from . import FullFileCall as _Call, FullFileOptions as _Opt, SonoError, measure as _ms
     opt = dict({"threshold_dB": -60, "padding_ms": 5}, **(options or {}))
     cfg = dict(DEFAULT_FRAMING_CONFIG, **(config or {}))
-    x = _f32(full_audio_data)
+    pcm = isinstance(full_audio_data, np.ndarray) and full_audio_data.dtype == np.int16
+    x = np.ascontiguousarray(full_audio_data) if pcm else _f32(full_audio_data)
+    if pcm and x.ndim not in (1, 2):
+        raise ValueError("16-bit recordings are (frames,) or (frames, channels) arrays")
     o = _Opt(float(opt["threshold_dB"]), float(opt["padding_ms"]), float(cfg["hopPercent"]), float(cfg["callThreshold_dB"]),
              float(cfg["minCallDuration_ms"]), _ms.mode_flags(cfg.get("debugMode", False), cfg.get("timeExpansion", False)) | (4 if keep_spectrograms else 0),
              int(threads))
@@ -380,8 +386,13 @@ def _full_file_call_array(engine, full_audio_data, sample_rate, flow_khz, fhigh_
     out = (_Call * cap)()
     got = C.c_size_t(0)
     try:
-        _check(lib().sono_process_full_file(engine._handle(), _p(x), x.size, float(sample_rate), float(flow_khz), float(fhigh_khz),
-                                            C.byref(o), out, cap, C.byref(got)))
+        if pcm:
+            _check(lib().sono_process_full_file_pcm16(engine._handle(), x.ctypes.data, x.shape[0], 1 if x.ndim == 1 else x.shape[1],
+                                                      int(pcm_channel), float(sample_rate), float(flow_khz), float(fhigh_khz),
+                                                      C.byref(o), out, cap, C.byref(got)))
+        else:
+            _check(lib().sono_process_full_file(engine._handle(), _p(x), x.size, float(sample_rate), float(flow_khz), float(fhigh_khz),
+                                                C.byref(o), out, cap, C.byref(got)))
     except SonoError as err:
         if err.status == 5:                                # SONO_EREFERENCE
             raise _ms.ReferenceThrows(str(err)) from None

@@ -14,8 +14,8 @@ import math
 
 import numpy as np
 
-__all__ = ["COLUMNS", "files_of_rank", "frame_chunks", "chunk_samples", "calls_to_rows", "gather_call_tables",
-           "reduce_global_max", "FRAME_ALIGN"]
+__all__ = ["COLUMNS", "files_of_rank", "deal_units", "frame_chunks", "chunk_samples", "calls_to_rows", "gather_rows",
+           "gather_call_tables", "reduce_global_max", "agree_on_failure", "FRAME_ALIGN"]
 
 # Numeric columns of the reference's call-summary table (callSummaryTable.js:103-137), after the two
 # keys that identify where a row came from.  Columns a call does not carry stay NaN.
@@ -32,6 +32,20 @@ FRAME_ALIGN = 16
 def files_of_rank(n_files, rank, world_size):
     """Partition A: recording i goes to GPU i mod world_size."""
     return list(range(rank, n_files, world_size))
+
+
+def deal_units(lengths, world_size):
+    """Partition A for units of known, different lengths (a night of 5 s triggers next to a 12 h continuous
+    recording): longest first, each to the rank with the least work so far (ties: the lowest rank).  -> one list of
+    unit indices per rank, each in increasing order.  Every rank computes the same deal from the same lengths.  With
+    equal lengths this is the round-robin deal of files_of_rank."""
+    load = [0] * world_size
+    out = [[] for _ in range(world_size)]
+    for i in sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i)):
+        r = min(range(world_size), key=lambda r: (load[r], r))
+        out[r].append(i)
+        load[r] += int(lengths[i])
+    return [sorted(o) for o in out]
 
 
 def frame_chunks(total_frames, parts, align=FRAME_ALIGN):
@@ -68,33 +82,53 @@ def calls_to_rows(calls, file_id, channel=0):
     return rows
 
 
-def gather_call_tables(rows, device=None, group=None):
-    """All ranks contribute `rows` (n_i x len(COLUMNS) float64); every rank gets the concatenation ordered by
-    (file, channel, startTime_s).  Two collectives: all_gather of the counts, all_gather of the padded rows."""
+def gather_rows(rows, width, device=None, group=None):
+    """All ranks contribute `rows` (n_i x width float64); every rank gets the concatenation in rank order.  Two
+    collectives: all_gather of the counts, all_gather of the rows padded to the largest count."""
     import torch
     import torch.distributed as dist
 
-    rows = np.asarray(rows, np.float64).reshape(-1, len(COLUMNS))
+    rows = np.asarray(rows, np.float64).reshape(-1, width)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        table = rows
-    else:
-        world = dist.get_world_size(group)
-        dev = torch.device(device) if device is not None else torch.device("cpu")
-        count = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
-        counts = [torch.zeros_like(count) for _ in range(world)]
-        dist.all_gather(counts, count, group=group)
-        counts = [int(c.item()) for c in counts]
-        width = max(max(counts), 1)
-        mine = torch.full((width, len(COLUMNS)), float("nan"), dtype=torch.float64, device=dev)
-        if rows.shape[0]:
-            mine[: rows.shape[0]] = torch.from_numpy(rows).to(dev)
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine, group=group)
-        table = np.concatenate([p[:n].cpu().numpy() for p, n in zip(parts, counts)], axis=0)
+        return rows
+    world = dist.get_world_size(group)
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    count = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count, group=group)
+    counts = [int(c.item()) for c in counts]
+    pad = max(max(counts), 1)
+    mine = torch.full((pad, width), float("nan"), dtype=torch.float64, device=dev)
+    if rows.shape[0]:
+        mine[: rows.shape[0]] = torch.from_numpy(rows).to(dev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return np.concatenate([p[:n].cpu().numpy() for p, n in zip(parts, counts)], axis=0)
+
+
+def gather_call_tables(rows, device=None, group=None):
+    """All ranks contribute `rows` (n_i x len(COLUMNS) float64); every rank gets the concatenation ordered by
+    (file, channel, startTime_s)."""
+    table = gather_rows(rows, len(COLUMNS), device, group)
     if table.shape[0]:
         order = np.lexsort((table[:, 2], table[:, 1], table[:, 0]))
         table = table[order]
     return table
+
+
+def agree_on_failure(failed, device=None, group=None):
+    """One all_reduce(MAX) of a flag: -> -1 when no rank reports `failed`, else the highest rank that does.  A rank that cannot go on calls this with failed=True INSTEAD of leaving: the others, who call it with
+    False before they enter the gather, then learn of it and raise as well rather than wait in a collective for a
+    rank that will never arrive."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0 if failed else -1
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    t = torch.tensor([dist.get_rank(group) if failed else -1], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
 
 
 def reduce_global_max(local_max, device=None, group=None):

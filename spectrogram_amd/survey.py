@@ -2,9 +2,11 @@
 `runAutoDetection` does for the one file open in the browser (wsManager.js:241-299: the
 analysis engine SpectrogramEngine(1024, 'hann'), `processFullFile` on channel 0, then the
 call-summary table, callSummaryTable.js:103-137) done for a list of units, one process per
-GPU.  Units are dealt round-robin (sharding.files_of_rank), every rank runs the whole
-detector (sono_process_full_file: fast scan, regions, framing, measurement) on its units,
-and the per-rank tables are gathered with the path's only collective.
+GPU.  Units are dealt longest-first to the least-loaded rank when their lengths are known
+(sharding.deal_units; round-robin otherwise), every rank runs the whole detector
+(sono_process_full_file: fast scan, regions, framing, measurement) on its units, a unit that
+fails is set aside without stopping the rank, and the per-rank tables are gathered with the
+path's only collective.
 
 `sharded_peaks` is the other partition: ONE long recording cut into frame chunks with an
 fft_size - hop halo, the peak threshold of get_peaks (lib.rs:349-387) taken from the
@@ -14,45 +16,137 @@ import numpy as np
 
 from . import SpectrogramEngine, frames_for, framing, sharding
 
-__all__ = ["detect_units", "run_auto_detection", "sharded_peaks", "ANALYSIS_FFT", "ANALYSIS_WINDOW"]
+__all__ = ["detect_units", "run_auto_detection", "units_of_rank", "sharded_peaks", "ANALYSIS_FFT", "ANALYSIS_WINDOW",
+           "REJECT_REFERENCE_THROWS", "REJECT_LOAD_FAILED", "REJECT_DETECTION_FAILED"]
 
 ANALYSIS_FFT, ANALYSIS_WINDOW = 1024, "hann"          # getAnalysisWasmEngine, wsManager.js:350-361
 
 
+# Why a unit contributed no rows (third column of the rejected table)
+REJECT_REFERENCE_THROWS = 1      # the reference itself raises on this unit outside its debug mode (measure.ReferenceThrows)
+REJECT_LOAD_FAILED = 2           # the unit's samples could not be produced (its loader raised, or the array is unusable)
+REJECT_DETECTION_FAILED = 3      # the library reported an error on this unit (bad arguments, out of memory, a HIP error)
+
+
 def _samples(unit):
+    """A unit's samples: float32, or int16 as they are (a decoded 16-bit WAV channel; the library takes those without a
+    float copy on the host, framing._full_file_call_array)."""
     x = unit() if callable(unit) else unit
+    if isinstance(x, np.ndarray) and x.dtype == np.int16:
+        return np.ascontiguousarray(x)
     return np.ascontiguousarray(x, dtype=np.float32)
 
 
+def _unit_length(u):
+    """Samples of a unit when known without loading it: the array's size, or the optional fourth field."""
+    if len(u) > 3 and u[3] is not None:
+        return int(u[3])
+    return None if callable(u[2]) else int(np.size(u[2]))
+
+
+def units_of_rank(units, rank, world):
+    """Indices of this rank's units: longest first to the least-loaded rank (sharding.deal_units) when every unit's
+    length is known -- arrays, or loaders with a length as fourth field -- else round-robin (sharding.files_of_rank)."""
+    lengths = [_unit_length(u) for u in units]
+    if world > 1 and all(n is not None for n in lengths):
+        return sharding.deal_units(lengths, world)[rank]
+    return sharding.files_of_rank(len(units), rank, world)
+
+
+def _shard_path(shard_dir, key, file_id, channel):
+    import os
+    return os.path.join(shard_dir, f"unit_{key}_{int(file_id)}_{int(channel)}.npz")
+
+
+def _settings_key(sample_rate, flow_khz, fhigh_khz, options, config):
+    import hashlib
+    import json
+    text = json.dumps([float(sample_rate), float(flow_khz), float(fhigh_khz), options or {}, config or {}], sort_keys=True, default=str)
+    return hashlib.sha256(text.encode()).hexdigest()[:12]
+
+
 def detect_units(units, sample_rate, flow_khz=10.0, fhigh_khz=128.0, options=None, config=None, rank=0, world=1,
-                 engine=None, threads=0):
-    """This rank's share of `units` = [(file_id, channel, samples or a callable returning them)]: the reference's
-    whole-file detection on each, calls as float64 rows in sharding.COLUMNS order (file, channel, then the table's
-    numeric columns).  Units keep their order within the rank; a unit on which the reference itself would raise
-    (measure.ReferenceThrows, outside its debug mode) contributes no rows and is named in the second return value."""
-    from . import measure as _ms
-    own = engine is None
+                 engine=None, threads=0, shard_dir=None, detect=None):
+    """This rank's share of `units` = [(file_id, channel, samples or a callable returning them[, length])]: the
+    reference's whole-file detection on each, calls as float64 rows in sharding.COLUMNS order (file, channel, then the
+    table's numeric columns).  Units keep their order within the rank.
+
+    A unit that fails is CONTAINED: it contributes no rows, is named in the second return value as
+    (file_id, channel, REJECT_* code, message), and the rank goes on with its next unit -- one bad file or one unit that
+    does not fit must not cost the night's other recordings, and above all must not keep this rank out of the gather
+    the other ranks are waiting in.
+
+    shard_dir: every finished unit leaves `unit_<settings>_<file>_<channel>.npz` there (rows and status, written to a
+    temporary name and renamed), and a unit whose shard exists is read back instead of detected again: a survey that
+    was killed is started again with the same arguments and skips what it had finished.
+
+    detect: the per-unit detector, (engine, samples, file_id, channel) -> rows; default the library's whole-file
+    detection.  (The CPU tests of the sharding logic pass a stand-in.)"""
+    import os
+    from . import SonoError, measure as _ms
+    own = engine is None and detect is None
     e = SpectrogramEngine(ANALYSIS_FFT, ANALYSIS_WINDOW) if own else engine
+    if detect is None:
+        def detect(eng, x, file_id, channel):
+            return framing.process_full_file_table(eng, x, sample_rate, flow_khz, fhigh_khz, options, config, threads=threads,
+                                                   file_id=file_id, channel=channel)
+    key = _settings_key(sample_rate, flow_khz, fhigh_khz, options, config)
+    if shard_dir:
+        os.makedirs(shard_dir, exist_ok=True)
     rows, rejected = [], []
+    empty = np.zeros((0, len(sharding.COLUMNS)), np.float64)
     try:
-        for i in sharding.files_of_rank(len(units), rank, world):
-            file_id, channel, unit = units[i]
+        for i in units_of_rank(units, rank, world):
+            file_id, channel, unit = units[i][0], units[i][1], units[i][2]
+            path = _shard_path(shard_dir, key, file_id, channel) if shard_dir else None
+            if path and os.path.exists(path):
+                with np.load(path, allow_pickle=False) as z:
+                    code, msg, r = int(z["code"]), str(z["message"]), z["rows"]
+                if code:
+                    rejected.append((file_id, channel, code, msg))
+                else:
+                    rows.append(r)
+                continue
+            code, msg, r = 0, "", empty
             try:
-                rows.append(framing.process_full_file_table(e, _samples(unit), sample_rate, flow_khz, fhigh_khz, options, config,
-                                                            threads=threads, file_id=file_id, channel=channel))
-            except _ms.ReferenceThrows:
-                rejected.append((file_id, channel))
+                x = _samples(unit)
+            except Exception as err:          # noqa: BLE001 -- whatever a caller's loader raises stays with this unit
+                code, msg = REJECT_LOAD_FAILED, f"{type(err).__name__}: {err}"
+            if not code:
+                try:
+                    r = np.asarray(detect(e, x, file_id, channel), np.float64).reshape(-1, len(sharding.COLUMNS))
+                except _ms.ReferenceThrows as err:
+                    code, msg = REJECT_REFERENCE_THROWS, str(err)
+                except (SonoError, MemoryError, ValueError, RuntimeError) as err:
+                    code, msg = REJECT_DETECTION_FAILED, f"{type(err).__name__}: {err}"
+            if code:
+                rejected.append((file_id, channel, code, msg))
+                r = empty
+            else:
+                rows.append(r)
+            if path:
+                tmp = path + f".tmp{os.getpid()}"
+                with open(tmp, "wb") as fh:
+                    np.savez(fh, rows=r, code=np.int64(code), message=np.str_(msg))
+                os.replace(tmp, path)
     finally:
-        if own:
+        if own and e is not None:
             e.free()
-    table = np.concatenate(rows, axis=0) if rows else np.zeros((0, len(sharding.COLUMNS)), np.float64)
+    table = np.concatenate(rows, axis=0) if rows else empty
     return table, rejected
 
 
 def run_auto_detection(units, sample_rate, flow_khz=10.0, fhigh_khz=128.0, options=None, config=None, engine=None,
-                       collective_device=None, threads=0):
+                       collective_device=None, threads=0, shard_dir=None, detect=None):
     """detect_units on this process's rank of the initialised torch.distributed group (or on everything when there
-    is none), then the gathered call-summary table, identical on every rank and ordered by (file, channel, start)."""
+    is none), then the gathered call-summary table, identical on every rank and ordered by (file, channel, start), and
+    the gathered list of rejected units [(file, channel, REJECT_* code)], identical on every rank and ordered alike
+    (the messages stay on the rank that saw them: detect_units returns them).
+
+    Failures: a failing UNIT is contained by detect_units.  A rank that cannot go on at all (no device, no engine)
+    does not leave: it tells the others in one all_reduce that every rank performs before the gather, and then ALL
+    ranks raise RuntimeError -- nobody waits in a collective for a rank that will not arrive.  (A rank that is killed
+    outright is the launcher's business: torchrun ends the other ranks.)"""
     rank, world = 0, 1
     try:
         import torch.distributed as dist
@@ -60,8 +154,23 @@ def run_auto_detection(units, sample_rate, flow_khz=10.0, fhigh_khz=128.0, optio
             rank, world = dist.get_rank(), dist.get_world_size()
     except ImportError:
         pass
-    rows, rejected = detect_units(units, sample_rate, flow_khz, fhigh_khz, options, config, rank, world, engine, threads)
-    return sharding.gather_call_tables(rows, device=collective_device), rejected
+    rows, rejected, fatal = None, [], None
+    try:
+        rows, rejected = detect_units(units, sample_rate, flow_khz, fhigh_khz, options, config, rank, world, engine, threads,
+                                      shard_dir, detect)
+    except Exception as err:                  # noqa: BLE001 -- reported to every rank below, then raised
+        fatal = err
+    bad_rank = sharding.agree_on_failure(fatal is not None, device=collective_device)
+    if bad_rank >= 0:
+        if fatal is not None:
+            raise RuntimeError(f"survey: rank {rank} cannot continue: {type(fatal).__name__}: {fatal}") from fatal
+        raise RuntimeError(f"survey: rank {bad_rank} reported that it cannot continue; no table was gathered")
+    table = sharding.gather_call_tables(rows, device=collective_device)
+    rej = np.array([(f, c, code) for f, c, code, _ in rejected], np.float64).reshape(-1, 3)
+    rej = sharding.gather_rows(rej, 3, device=collective_device)
+    if rej.shape[0]:
+        rej = rej[np.lexsort((rej[:, 1], rej[:, 0]))]
+    return table, [(int(f), int(c), int(code)) for f, c, code in rej]
 
 
 def sharded_peaks(engine, audio, noverlap, threshold_ratio, rank=0, world=1, gain_db=20.0, range_db=80.0,

@@ -342,3 +342,48 @@ def test_rms_based_snr(golden):
                     assert (r["signalThreshold"], r["signalMax"], r["signalMin"]) == (w[5], w[6], w[7])
         assert k == len(want)
     e.free()
+
+
+def _quantise(x):
+    return np.clip(np.round(np.asarray(x, np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+
+
+def test_whole_file_detection_from_16_bit_samples(golden):
+    """sono_process_full_file_pcm16 takes the recording as a WAV file holds it (int16 sample frames, one channel of
+    them analysed; the samples mean value / 32768).  Its calls must equal, field for field, those of the f32 entry point
+    on the same quantised samples converted to float -- on the recorded whole-file cases quantised to 16 bits, on a
+    recording with regions of every class of the automatic high-pass (filtered regions are read back from the GPU,
+    unfiltered ones are converted from the integers on the host), mono and as channel 1 of a three-channel file."""
+    import spectrogram_amd.framing as frm
+    g, meta = golden
+    runs = []
+    for c in cases(meta, "fullfile") + cases(meta, "fullfile_measured"):
+        n = c["name"]
+        cfg = {"hopPercent": c["hop_percent"], "callThreshold_dB": c["call_threshold_db"], "minCallDuration_ms": c["min_call_duration_ms"],
+               "debugMode": True}
+        runs.append((c["fft"], c["window"], g[n + "/x"], c["sr"], c["flow_khz"], c["fhigh_khz"],
+                     {"threshold_dB": c["scan_threshold_db"], "padding_ms": c["padding_ms"]}, cfg))
+    sr = 384000
+    rng = np.random.default_rng(12)
+    x = (0.01 * rng.standard_normal(3 * sr)).astype(np.float32)
+    t = np.arange(1536) / sr
+    for k in range(0, 3 * sr - 4000, 19200):
+        f0 = [80000, 38000, 33000, 25000][(k // 19200) % 4]
+        x[k + 500:k + 2036] += (0.4 * np.hanning(1536) * np.sin(2 * np.pi * (f0 * t - 1e5 * t * t))).astype(np.float32)
+    runs.append((1024, "hann", x, sr, 15.0, 110.0, {"threshold_dB": -45.0}, {"hopPercent": 6.25, "debugMode": True}))
+    total = 0
+    for fft, window, x, sr, flow, fhigh, opt, cfg in runs:
+        q = _quantise(x)
+        xf = q.astype(np.float32) / np.float32(32768.0)
+        e = sa.SpectrogramEngine(fft, window)
+        want = frm.process_full_file_native(e, xf, sr, flow, fhigh, opt, cfg)
+        got = frm.process_full_file_native(e, q, sr, flow, fhigh, opt, cfg)
+        assert got == want
+        three = np.stack([_quantise(0.3 * x[::-1]), q, np.zeros_like(q)], axis=1)
+        assert frm._full_file_call_array(e, three, sr, flow, fhigh, opt, cfg, 0, False, pcm_channel=1)[1] == len(want)
+        rows = frm.process_full_file_table(e, q, sr, flow, fhigh, opt, cfg, file_id=3, channel=1)
+        assert np.array_equal(rows, frm.process_full_file_table(e, xf, sr, flow, fhigh, opt, cfg, file_id=3, channel=1), equal_nan=True)
+        total += len(want)
+        e.free()
+    assert total > 30
+    assert {c["highpass_kHz"] for c in want} >= {0.0, 20.0, 25.0, 30.0}

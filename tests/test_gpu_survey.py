@@ -15,11 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RANK = os.path.join(ROOT, "tests", "survey_rank.py")
 
 
-def run_world(world, out_dir):
+def run_world(world, out_dir, *extra):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = str(s.getsockname()[1])
-    procs = [subprocess.Popen([sys.executable, RANK, str(r), str(world), port, str(out_dir)]) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, RANK, str(r), str(world), port, str(out_dir), *extra]) for r in range(world)]
     codes = [p.wait(timeout=300) for p in procs]
     assert codes == [0] * world
 
@@ -50,3 +50,17 @@ def test_two_ranks_gather_the_single_process_table(tmp_path):
     whole = np.load(tmp_path / "peaks_w1_r0.npz")
     assert np.array_equal(whole["peaks"], want)
     assert (want != 0xFFFF).any() and (want == 0xFFFF).any()
+
+
+def test_a_failing_unit_is_contained_and_every_rank_learns_of_it(tmp_path):
+    """One unit's loader raises on the rank that owns it.  That rank sets the unit aside, finishes its other units and
+    enters the gather like the others: both ranks end with the table of the good units -- the one a run without the bad
+    unit gives -- and the same list of rejected units."""
+    from spectrogram_amd import survey
+    run_world(1, tmp_path)
+    run_world(2, tmp_path, "bad")
+    good = np.load(tmp_path / "table_w1_r0.npy")
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"table_w2_r{r}_bad.npy"), good, equal_nan=True)
+        rej = np.load(tmp_path / f"rejected_w2_r{r}.npy")
+        assert rej.tolist() == [[7, 0, survey.REJECT_LOAD_FAILED]]

@@ -135,3 +135,66 @@ def test_many_files_in_one_launch_equal_one_launch_per_file():
         assert torch.equal(one, out[f * F1 * 512:(f + 1) * F1 * 512]), f
         assert torch.equal(one_pb, pb[f * F1:(f + 1) * F1]) and torch.equal(one_pm, pm[f * F1:(f + 1) * F1]), f
     e.free()
+
+
+def test_survey_pass_in_one_read_equals_the_two_passes(night):
+    """sono_stft_survey(_pcm16)_dev: the peak features at hop N/4 and the fast scan's flags at hop N/2 from ONE launch over
+    the hour (the scan's frames are the even frames of the feature pass).  Peak bins, peak magnitudes and the global
+    maximum equal the feature pass bit for bit; the flags equal the fused fast scan's; the band sums agree to 1e-6 (a
+    scan frame is transformed beside another partner frame here than in the hop-N/2 kernel, which reaches its bins at
+    the level of the last bit of the f32 magnitudes, and the terms are added in another order).  Float and 16-bit forms, and a three-stream batch whose streams end on
+    odd and even frame counts (the scan has ceil(frames / 2) frames per stream)."""
+    torch, e = night["torch"], night["e"]
+    V, VS = 768, 512
+    F, FS = sa.frames_for(SAMPLES, N, V), sa.frames_for(SAMPLES, N, VS)
+    assert FS == (F + 1) // 2
+    target = (10.0 ** (-60.0 / 10.0)) * N * 0.25
+
+    def outputs(frames, scan):
+        return (torch.zeros(frames, dtype=torch.int16, device="cuda"), torch.zeros(frames, dtype=torch.float32, device="cuda"),
+                torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(scan, dtype=torch.uint8, device="cuda"),
+                torch.zeros(scan, dtype=torch.float64, device="cuda"))
+    ref = outputs(F, FS)
+    torch.cuda.synchronize()
+    e.stft_features_dev(night["xf"].data_ptr(), 1, SAMPLES, SAMPLES, V, ref[0].data_ptr(), ref[1].data_ptr(), ref[2].data_ptr())
+    e.stft_band_active_dev(night["xf"].data_ptr(), 1, SAMPLES, SAMPLES, VS, LO, HI, target, ref[3].data_ptr(), ref[4].data_ptr())
+    e.synchronize()
+    assert 0.01 * FS < int(ref[3].sum().item()) < 0.5 * FS
+    for pcm in (False, True):
+        got = outputs(F, FS)
+        torch.cuda.synchronize()
+        if pcm:
+            e.stft_survey_pcm16_dev(night["pcm"].data_ptr(), 1, SAMPLES, SAMPLES, 1, 0, LO, HI, target, *(t.data_ptr() for t in got))
+        else:
+            e.stft_survey_dev(night["xf"].data_ptr(), 1, SAMPLES, SAMPLES, LO, HI, target, *(t.data_ptr() for t in got))
+        e.synchronize()
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]), pcm
+        assert torch.equal(got[3], ref[3]), pcm
+        assert torch.allclose(got[4], ref[4], rtol=1e-6, atol=0), pcm
+    # three streams of 2 501 / 2 502 / 2 502 ... samples apart: 6, 7 frames ... per stream
+    for per in (N + 5 * 256 + 3, N + 6 * 256, N + 7 * 256 + 255):
+        f1, s1 = sa.frames_for(per, N, V), sa.frames_for(per, N, VS)
+        assert s1 == (f1 + 1) // 2
+        stride = per + 40
+        x3 = night["xf"][384000: 384000 + 3 * stride]
+        ref = outputs(3 * f1, 3 * s1)
+        got = outputs(3 * f1, 3 * s1)
+        torch.cuda.synchronize()
+        e.stft_features_dev(x3.data_ptr(), 3, stride, per, V, ref[0].data_ptr(), ref[1].data_ptr(), ref[2].data_ptr())
+        e.stft_band_active_dev(x3.data_ptr(), 3, stride, per, VS, LO, HI, target, ref[3].data_ptr(), ref[4].data_ptr())
+        e.stft_survey_dev(x3.data_ptr(), 3, stride, per, LO, HI, target, *(t.data_ptr() for t in got))
+        e.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(got[:4], ref[:4])), per
+        assert torch.allclose(got[4], ref[4], rtol=1e-6, atol=0), per
+    # another fft size takes the two passes one after the other behind the same entry point
+    e2 = sa.SpectrogramEngine(512, "hann")
+    n2 = 512 + 128 * 4001
+    f2, s2 = sa.frames_for(n2, 512, 384), sa.frames_for(n2, 512, 256)
+    ref, got = outputs(f2, s2), outputs(f2, s2)
+    torch.cuda.synchronize()
+    e2.stft_features_dev(night["xf"].data_ptr(), 1, n2, n2, 384, ref[0].data_ptr(), ref[1].data_ptr(), ref[2].data_ptr())
+    e2.stft_band_active_dev(night["xf"].data_ptr(), 1, n2, n2, 256, 13, 170, target, ref[3].data_ptr(), ref[4].data_ptr())
+    e2.stft_survey_dev(night["xf"].data_ptr(), 1, n2, n2, 13, 170, target, *(t.data_ptr() for t in got))
+    e2.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    e2.free()
