@@ -91,6 +91,7 @@ uint32_t sono_host_threads(void);
  *   "fixed_tiles"    (SONO_FIXED_TILES)    equal tile ranges per XCD, no adapting to measured speeds
  *   "balance_debug"  (SONO_BALANCE_DEBUG)  print the XCDs' times and the next ranges to stderr
  *   "no_streaming"   (SONO_NO_STREAMING)   long host-pointer calls as one copy each way instead of the chunk pipeline
+ *   "bank_two_kernels" (no variable)       filter banks as magnitude matrix + bank kernel even where the fused form exists
  * None of them changes a result bit (the tests compare the forms).  SONO_EINVAL for an unknown name.
  * Like every call on an engine: not while another thread is inside a call on the same engine. */
 int sono_engine_set_option(sono_engine *e, const char *name, int value);

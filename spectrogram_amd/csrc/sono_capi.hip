@@ -254,6 +254,7 @@ int sono_engine_set_option(sono_engine *e, const char *name, int value)
     else if (n == "fixed_tiles") e->tables.tile.balance.fixed = on;
     else if (n == "balance_debug") e->tables.tile.balance.debug = on;
     else if (n == "no_streaming") e->no_streaming = on;
+    else if (n == "bank_two_kernels") e->bank_two_kernels = on;
     else return fail(SONO_EINVAL, "sono_engine_set_option: unknown option '" + n + "'");
     return SONO_OK;
 }
@@ -267,6 +268,7 @@ int sono_engine_get_option(const sono_engine *e, const char *name, int *value)
     else if (n == "fixed_tiles") *value = e->tables.tile.balance.fixed;
     else if (n == "balance_debug") *value = e->tables.tile.balance.debug;
     else if (n == "no_streaming") *value = e->no_streaming;
+    else if (n == "bank_two_kernels") *value = e->bank_two_kernels;
     else return fail(SONO_EINVAL, "sono_engine_get_option: unknown option '" + n + "'");
     return SONO_OK;
 }
@@ -790,6 +792,24 @@ int sono_stft_u8(sono_engine *e, const float *x, size_t n, uint32_t noverlap, fl
             e->bank_taps_ready = true;
         }
         const size_t sb = e->num_filters * sizeof(unsigned int), tb = e->bank_tap_count * sizeof(unsigned int);
+        // A sparse bank on the default display size runs inside the transform's epilogue, straight from the power image
+        // in LDS: the samples are read once, the codes written once, no magnitude ever reaches HBM.
+        {
+            sono::StftArgs a;
+            fill_args(e, b, noverlap, a);
+            a.out_u8 = (uint8_t *)e->d_out.p; a.peak_bin = (uint16_t *)e->d_peak_bin.p; a.peak_mag = (float *)e->d_peak_mag.p;
+            a.gmax_bits = (uint32_t *)e->d_gmax.p;
+            a.bank_tap_bin = (const unsigned int *)((char *)e->d_bank.p + sb);
+            a.bank_tap_w = (const float *)((char *)e->d_bank.p + sb + tb);
+            a.bank_filters = e->num_filters;
+            a.bank_max_taps = e->num_filters ? (unsigned int)(e->bank_tap_count / e->num_filters) : 0u;
+            const sono::BankQuant bq = sono::make_bank_quant(gain_db, range_db);
+            a.bank_q_a = bq.a; a.bank_q_c = bq.c;
+            if (!e->tables.force_generic && !e->bank_two_kernels && sono::tile_supports(sono::MODE_BANK, a, e->tables.tile)) {
+                HIP_TRY(sono::launch_stft_tile(sono::MODE_BANK, a, e->tables.tile, e->stream));
+                goto copy_back;
+            }
+        }
         // The magnitudes only exist between the two kernels: they are formed for one piece of the recording at a time
         // (pieces start on multiples of 16 frames, so every frame meets the partner it has in the whole transform) in a
         // scratch of at most 2 GiB, whatever the recording's length.
@@ -809,6 +829,7 @@ int sono_stft_u8(sono_engine *e, const float *x, size_t n, uint32_t noverlap, fl
                                                (float *)e->d_peak_mag.p + f0, (uint32_t *)e->d_gmax.p, e->stream));
         }
     }
+copy_back:
     e->last_peak_bin.resize(F);
     e->last_peak_mag.resize(F);
     uint32_t gbits = 0;

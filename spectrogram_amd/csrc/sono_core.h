@@ -26,6 +26,8 @@ enum Mode : int {
     MODE_MAG = 0,    // frames x N/2 linear magnitudes           (lib.rs:113-161)
     MODE_U8 = 1,     // frames x N/2 u8 dB codes + peak features (lib.rs:199-304,349-443)
     MODE_POWER = 2,  // frames x (N/2+1) |X|^2 of mean-removed frames (lib.rs:1058-1094)
+    MODE_BANK = 5,   // tiled kernel, fft 1024: MODE_U8 with the rows taken through a sparse filter bank (lib.rs:310-334) in the
+                     // epilogue, from the power image in LDS: no magnitude matrix in HBM between transform and bank
     MODE_SURVEY = 4, // tiled kernel, hop N/4: MODE_U8's peak features without rows AND MODE_BAND's test on every second frame
                      // (the frames of the fast scan's hop N/2): one read of the samples for both (batCallDetector.js:878-949 beside lib.rs:349-443)
     MODE_BAND = 3,   // per frame: sum of mag^2 over a band of bins, compared with a target (batCallDetector.js:913-927);
@@ -59,6 +61,12 @@ struct StftArgs {
     float q_floor;                // 0 = no floor (it would not change any code, see make_quant)
     unsigned int band_lo, band_hi;   // MODE_BAND: bins band_lo..band_hi (inclusive, band_hi < N/2)
     double band_target;              // MODE_BAND: a frame is active iff its band energy > band_target
+    // MODE_BANK: the bank's non-zero taps as bank_taps() lists them (tap k of filter i at k * filters + i, filters with
+    // fewer taps padded with weight 0), at most kBankLdsTaps entries; rows of `bank_filters` codes go to out_u8
+    const unsigned int *bank_tap_bin;
+    const float *bank_tap_w;
+    unsigned int bank_filters, bank_max_taps;    // filters; largest number of taps of any filter
+    float bank_q_a, bank_q_c;                    // make_bank_quant
     uint8_t *band_active;            // MODE_BAND: one flag per frame; MODE_SURVEY: one per EVEN frame of each stream, ceil(frames / 2) per stream
     double *band_energy;             // MODE_BAND / MODE_SURVEY, optional: the sums themselves
 };
@@ -108,12 +116,36 @@ inline Quant make_quant(unsigned int N, float gain_db, float range_db)
     return q;
 }
 
+// What the tiled kernel's workgroup has LDS left for: the tap list of a sparse filter bank, one entry per (tap, filter).
+constexpr unsigned int kBankLdsTaps = 1536;
+struct alignas(8) BankTap { float w; unsigned int bin; };
+
 #if defined(__HIP_DEVICE_COMPILE__)
 SONO_HD float fast_log2(float p) { return __builtin_amdgcn_logf(p); }   // v_log_f32 (log2, ~1 ulp)
 SONO_HD float fast_sqrt(float p) { return __builtin_amdgcn_sqrtf(p); }  // v_sqrt_f32 (~1 ulp)
 #else
 SONO_HD float fast_log2(float p) { return std::log2(p); }
 SONO_HD float fast_sqrt(float p) { return std::sqrt(p); }
+#endif
+
+SONO_HD float as_float(unsigned int u)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+
+// Product and sum rounded on their own (the reference's wasm has no fused multiply-add): the compiler must not contract them.
+#if defined(__HIP_DEVICE_COMPILE__)
+SONO_HD float fmul_rn(float a, float b) { return __fmul_rn(a, b); }
+SONO_HD float fadd_rn(float a, float b) { return __fadd_rn(a, b); }
+#else
+SONO_HD float fmul_rn(float a, float b) { volatile float p = a * b; return p; }
+SONO_HD float fadd_rn(float a, float b) { volatile float s = a + b; return s; }
 #endif
 
 // Larger of two values that are +0, positive or NaN (p = |2X|^2 and the floor
@@ -153,6 +185,13 @@ SONO_HD unsigned int cvt_pk_u8(float v, unsigned int word)
 #endif
 }
 
+template <int BYTE = 0>
+SONO_HD unsigned int bank_code(float sum, float q_a, float q_c, unsigned int word = 0u)
+{
+    const float safe = sum > 1e-10f ? sum : 1e-10f;                      // lib.rs:280 (strict >; a NaN takes the floor)
+    return cvt_pk_u8<BYTE>(__builtin_fmaf(q_a, fast_log2(safe), q_c), word);
+}
+
 // Keeps a wave-uniform value in a vector register: a vector instruction with a
 // scalar-register operand issues in 3.2 cycles instead of 1.96 on gfx950, so a constant
 // that 32 instructions per tile multiply by is worth the register.
@@ -162,6 +201,21 @@ SONO_HD float in_vgpr(float x)
     asm volatile("" : "+v"(x));
 #endif
     return x;
+}
+
+// u8 code of a filter's output `sum` (a linear magnitude; the filter-bank paths cannot take the detour over |2X|^2):
+// the law of lib.rs:277-293 on the magnitude itself, code = trunc((20 log10(max(sum, 1e-10)) + gain + range) * 255 / range)
+// saturated to [0, 255], formed like quantise() below: one hardware log2, one fused multiply-add with
+// a = 20 log10(2) * 255 / range and c = (gain + range) * 255 / range - 1/2, one saturating conversion that rounds to
+// nearest (equal to the truncation except on exact integers, see make_quant).
+struct BankQuant { float a, c; };
+SONO_HD BankQuant make_bank_quant(float gain_db, float range_db)
+{
+    const double k = 255.0 / (double)range_db;
+    BankQuant q;
+    q.a = (float)(6.020599913279624 * k);
+    q.c = (float)(((double)gain_db + (double)range_db) * k - 0.5);
+    return q;
 }
 
 // u8 code of one bin from p = |2X|^2 (see make_quant), in byte BYTE of `word`.

@@ -209,6 +209,7 @@ struct sono_engine {
     std::vector<uint16_t> last_peak_bin;
     std::vector<float> last_peak_mag;
     float last_gmax = 0.0f;
+    bool bank_two_kernels = false;      // engine option "bank_two_kernels": filter banks through the magnitude matrix even where the fused form exists
     bool no_streaming = false;          // engine option "no_streaming": long host-pointer calls as one copy each way
     // colour map / config (lib.rs:28-32)
     std::vector<uint32_t> color_map;

@@ -155,8 +155,7 @@ __global__ __launch_bounds__(FB_THREADS) void filterbank_taps_u8_kernel(
         for (unsigned int t = threadIdx.x; t < taps; t += FB_THREADS) { l_bin[t] = tap_bin[t]; l_w[t] = tap_w[t]; }
     }
     __syncthreads();
-    const float gain_db_neg = -gain_db;
-    const float range_db_reciprocal = 255.0f / range_db;
+    const BankQuant bq = make_bank_quant(gain_db, range_db);
     const int quads = bins / 4;                            // float4 per row; lane owns quads lane, lane + 64, ...
     float *const row = rows + (size_t)wave * bins;
     const unsigned long long n_waves = (unsigned long long)gridDim.x * FB_ROWS;
@@ -221,17 +220,7 @@ __global__ __launch_bounds__(FB_THREADS) void filterbank_taps_u8_kernel(
                 for (unsigned int k = 0, n = tap_start[i]; k < n; ++k, t += (size_t)num_filters)
                     sum = __fadd_rn(sum, __fmul_rn(row[tap_bin[t]], tap_w[t]));
             }
-            const float safe = sum > 1e-10f ? sum : 1e-10f;
-            const float db = 20.0f * log10f(safe);
-            unsigned int code;
-            if (db < gain_db_neg - range_db) code = 0;
-            else if (db > gain_db_neg) code = 255;
-            else {
-                float v = (db - (gain_db_neg - range_db)) * range_db_reciprocal;
-                v = v > 0.0f ? v : 0.0f;
-                v = v < 255.0f ? v : 255.0f;
-                code = (unsigned int)v;
-            }
+            const unsigned int code = bank_code<0>(sum, bq.a, bq.c);
             out_u8[f * (unsigned long long)num_filters + i] = (uint8_t)code;
         }
     }

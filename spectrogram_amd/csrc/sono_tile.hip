@@ -17,13 +17,15 @@ hipError_t launch_tile_u8(const StftArgs &a, const TileTables &t, const RaggedPl
 hipError_t launch_tile_mag(const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream);
 hipError_t launch_tile_band(const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream);
 hipError_t launch_tile_survey(const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream);
+hipError_t launch_tile_bank(const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream);
 
 namespace {
 
 
 hipError_t launch_any(int mode, const StftArgs &a, const TileTables &t, const RaggedPlan *plan, hipStream_t stream)
 {
-    return mode == MODE_SURVEY ? launch_tile_survey(a, t, plan, stream)
+    return mode == MODE_BANK ? launch_tile_bank(a, t, plan, stream)
+         : mode == MODE_SURVEY ? launch_tile_survey(a, t, plan, stream)
          : mode == MODE_MAG ? launch_tile_mag(a, t, plan, stream)
          : mode == MODE_BAND ? launch_tile_band(a, t, plan, stream)
                              : launch_tile_u8(a, t, plan, stream);
@@ -142,7 +144,13 @@ void tile_balance_plan(TileBalance *b, unsigned long long blocks, unsigned long 
 
 bool tile_supports(int mode, const StftArgs &a, const TileTables &t)
 {
-    if (mode != MODE_MAG && mode != MODE_U8 && mode != MODE_BAND && mode != MODE_SURVEY) return false;
+    if (mode != MODE_MAG && mode != MODE_U8 && mode != MODE_BAND && mode != MODE_SURVEY && mode != MODE_BANK) return false;
+    if (mode == MODE_BANK) {        // fft 1024, a tap list that fits the workgroup's LDS, rows written as dwords
+        if (a.N != 1024 || a.x16 || !a.out_u8 || !a.bank_tap_bin || !a.bank_tap_w) return false;
+        if (a.bank_filters == 0 || a.bank_filters % 4 != 0) return false;
+        if (a.bank_max_taps == 0 || (unsigned long long)a.bank_max_taps * a.bank_filters > kBankLdsTaps) return false;
+        if (reinterpret_cast<uintptr_t>(a.out_u8) & 3u) return false;
+    }
     if (mode == MODE_SURVEY && (a.N != 1024 || a.hop * 4u != a.N)) return false;      // the one form the fused survey pass is built in
     if (a.x16 && (mode == MODE_MAG || a.x16_channels == 0 || a.x16_channel >= a.x16_channels)) return false;
     if ((mode == MODE_BAND || mode == MODE_SURVEY) && (!a.band_active || a.band_hi >= a.N / 2 || a.band_lo > a.band_hi)) return false;

@@ -392,7 +392,7 @@ struct TileLane {
     static constexpr int SHIFT = HOPQ == 1 ? G::R1 / 4 : HOPQ == 2 ? G::R1 / 2 : 0;
     static constexpr int OWN_B = SHIFT ? G::R1 - SHIFT : 0;   // first row of frame B that is loaded for B itself
     static constexpr bool SPLIT = G::SPLIT;
-    static constexpr bool FEATURES = MODE == MODE_U8 || MODE == MODE_SURVEY;      // per-frame peak features and the global maximum
+    static constexpr bool FEATURES = MODE == MODE_U8 || MODE == MODE_SURVEY || MODE == MODE_BANK;      // per-frame peak features and the global maximum
     const StftArgs &a;
     int lane;
     // samples of frames A / B of job jj at [jj*R1 + n1] (B: rows >= OWN_B only); SPLIT: xa = this lane's frame, row n1 at [n1]
@@ -844,6 +844,80 @@ struct TileLane {
         const unsigned long long g = tr.row0 + (unsigned long long)tr.j * G::FPW + (unsigned int)frame;
         a.band_active[g] = total > a.band_target ? 1 : 0;
         if (a.band_energy) a.band_energy[g] = total;
+    }
+
+    // MODE_BANK, after the feature epilogue: the frame's row of filter outputs (apply_filter_bank, lib.rs:310-334) from
+    // the power image, in two steps with a wave fence between them.
+    // Step 1: every lane turns its own bins of the image (the epilogue's assignment) into the f32 magnitudes that
+    // MODE_MAG stores, in place: a bin feeds two filters on average, so its square root is taken once, not per tap.
+    SONO_HD void bank_magnitudes(float *P, const float *meta) const
+    {
+        const int frame = lane >> (LOG_R1 - 1), l = bin_lane();
+        const float fix = shared_fix(meta);
+        float *row = P + frame * G::PROW + 4 * l;
+        constexpr int NB = R2 / 4;
+        float4 p4[NB];
+        static_for<0, NB>([&](auto i_) { p4[decltype(i_)::value] = *(const float4 *)(row + 2 * G::R1 * decltype(i_)::value); });
+        static_for<0, NB>([&](auto i_) {
+            constexpr int i = decltype(i_)::value;
+            float4 o;
+            o.x = fast_sqrt(p4[i].x * fix) * a.inv_n; o.y = fast_sqrt(p4[i].y) * a.inv_n;
+            o.z = fast_sqrt(p4[i].z) * a.inv_n; o.w = fast_sqrt(p4[i].w) * a.inv_n;
+            *(float4 *)(row + 2 * G::R1 * i) = o;
+        });
+    }
+    // Step 2: lane (frame, l) takes the filters 4l + 2*R1*m + r (r < 4) and writes their four codes as one dword.  A
+    // filter's output is the sum over its taps, bins ascending, of magnitude * weight, product and sum rounded
+    // separately as in the reference.  taps: the workgroup's LDS copy of the tap list, {weight, bin} of tap k of
+    // filter i at k * filters + i, every filter padded to bank_max_taps entries with weight 0 (the reference itself
+    // walks every bin of every filter, zero weights included: a zero product adds an exact zero).
+    SONO_HD void bank_rows(const TileRef &tr, const float *P, const BankTap *taps) const
+    {
+        const int frame = lane >> (LOG_R1 - 1), l = lane & (G::HALF - 1);
+        if ((unsigned int)frame >= tr.rem) return;
+        const float *row = P + frame * G::PROW;
+        const unsigned int filters = a.bank_filters;
+        const float qa = in_vgpr(a.bank_q_a), qc = in_vgpr(a.bank_q_c);
+        uint8_t *out = a.out_u8 + (tr.row0 + (unsigned long long)tr.j * G::FPW + (unsigned int)frame) * (unsigned long long)filters;
+        auto emit = [&](unsigned int i0, const float (&sum)[4]) {
+            unsigned int packed = bank_code<0>(sum[0], qa, qc);
+            packed = bank_code<1>(sum[1], qa, qc, packed);
+            packed = bank_code<2>(sum[2], qa, qc, packed);
+            packed = bank_code<3>(sum[3], qa, qc, packed);
+            *(unsigned int *)(out + i0) = packed;
+        };
+        if (a.bank_max_taps == 2) {
+            // The application's banks (two taps per filter, spectrogram.esm.js:1197-1232): the eight taps of a lane's
+            // four filters are four 16-byte reads, issued together, then the eight magnitudes, then the arithmetic --
+            // the reads of a lane's next four filters go out before this group's results are waited for.
+            SONO_PRAGMA(clang loop unroll_count(2))
+            for (unsigned int i0 = (unsigned int)(4 * l); i0 < filters; i0 += (unsigned int)(2 * G::R1)) {
+                const uint4 *q0 = (const uint4 *)(taps + i0), *q1 = (const uint4 *)(taps + filters + i0);
+                const uint4 t0a = q0[0], t0b = q0[1], t1a = q1[0], t1b = q1[1];     // {w, bin, w, bin} of filters i0, i0+1 | i0+2, i0+3
+                const float m0[4] = {row[t0a.y], row[t0a.w], row[t0b.y], row[t0b.w]};
+                const float m1[4] = {row[t1a.y], row[t1a.w], row[t1b.y], row[t1b.w]};
+                const float w0[4] = {as_float(t0a.x), as_float(t0a.z), as_float(t0b.x), as_float(t0b.z)};
+                const float w1[4] = {as_float(t1a.x), as_float(t1a.z), as_float(t1b.x), as_float(t1b.z)};
+                float sum[4];
+                static_for<0, 4>([&](auto r_) {
+                    constexpr int r = decltype(r_)::value;
+                    sum[r] = fadd_rn(fadd_rn(0.0f, fmul_rn(m0[r], w0[r])), fmul_rn(m1[r], w1[r]));
+                });
+                emit(i0, sum);
+            }
+            return;
+        }
+        for (unsigned int i0 = (unsigned int)(4 * l); i0 < filters; i0 += (unsigned int)(2 * G::R1)) {
+            float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (unsigned int k = 0, t = i0; k < a.bank_max_taps; ++k, t += filters) {
+                static_for<0, 4>([&](auto r_) {
+                    constexpr int r = decltype(r_)::value;
+                    const BankTap tap = taps[t + r];
+                    sum[r] = fadd_rn(sum[r], fmul_rn(row[tap.bin], tap.w));
+                });
+            }
+            emit(i0, sum);
+        }
     }
 
     // MODE_SURVEY, after the feature epilogue: the band energy of the tile's EVEN frames (the fast scan's frames: its

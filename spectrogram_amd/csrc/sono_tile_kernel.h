@@ -176,6 +176,13 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
     __shared__ __align__(16) float s_win[G::N];
     __shared__ unsigned int s_next, s_done;
     __shared__ float s_meta[kWavesPerBlock * tile::kMetaFloats];
+    // MODE_BANK: the bank's tap list (12 KB; the other modes' workgroups do not have this array)
+    constexpr bool kBank = MODE == MODE_BANK;
+    __shared__ BankTap s_taps[kBank ? kBankLdsTaps : 1];
+    if constexpr (kBank) {
+        const unsigned int taps = a.bank_max_taps * a.bank_filters;
+        for (unsigned int t = threadIdx.x; t < taps; t += blockDim.x) s_taps[t] = BankTap{a.bank_tap_w[t], a.bank_tap_bin[t]};
+    }
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -270,11 +277,16 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
             unsigned int best_k;
             if (MODE == MODE_U8 && a.q_floor > 0.0f) L.template epilogue<true>(tr, img, meta, best_p, best_k);
             else L.template epilogue<false>(tr, img, meta, best_p, best_k);
-            if (MODE == MODE_U8 || MODE == MODE_SURVEY) {
+            if (MODE == MODE_U8 || MODE == MODE_SURVEY || MODE == MODE_BANK) {
                 // the frame's largest power, then the lowest bin among the lanes that hold it (lib.rs:370-378)
                 const float pmax = group_max_f32<LOG_R1 - 1>(best_p);
                 const unsigned int bin = group_min_u32<LOG_R1 - 1>(best_p == pmax ? best_k : 0xFFFFFFFFu);
                 L.features(tr, pmax, bin);
+            }
+            if constexpr (MODE == MODE_BANK) {
+                L.bank_magnitudes(img, meta);
+                wave_lds_fence();
+                L.bank_rows(tr, img, s_taps);
             }
             if constexpr (MODE == MODE_SURVEY) {
                 // the fast scan's band test on the tile's even frames, from the power image that is still in place
@@ -328,7 +340,7 @@ void stft_tile_kernel(const StftArgs a, const tile::TileIter it, const float2 *t
             __hip_atomic_store(fb + 3, it.stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // last: a record with this launch's stamp is whole
         }
     }
-    if ((MODE == MODE_U8 || MODE == MODE_SURVEY) && a.gmax_bits) {
+    if ((MODE == MODE_U8 || MODE == MODE_SURVEY || MODE == MODE_BANK) && a.gmax_bits) {
         // wave-wide maximum of |2X|^2, then one atomic per wave on the magnitude's bit pattern
         float m = L.run_max;
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -373,7 +385,12 @@ hipError_t launch_one(const StftArgs &a, const TileTables &t, const RaggedPlan *
     const bool q = !G::SPLIT && a.hop * (kHopQ == 2 ? 2u : 4u) == (unsigned int)G::N && !t.any_hop;
     constexpr int kQ = G::SPLIT ? 0 : kHopQ;
     if (a.x16 && (plan || MODE == MODE_MAG)) return hipErrorInvalidValue;
-    if constexpr (MODE == MODE_SURVEY) {        // hop N/4, uniform batches: the two forms this mode is built in
+    if constexpr (MODE == MODE_BANK) {          // f32 samples, uniform batches, any hop
+        if (a.x16 || plan) return hipErrorInvalidValue;
+        if (q) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, kQ, false>), grid, block, 0, stream, a, it, tw_rows);
+        else hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, 0, false>), grid, block, 0, stream, a, it, tw_rows);
+        return hipGetLastError();
+    } else if constexpr (MODE == MODE_SURVEY) {        // hop N/4, uniform batches: the two forms this mode is built in
         if (!q || plan) return hipErrorInvalidValue;
         if (a.x16) hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, kQ, true>), grid, block, 0, stream, a, it, tw_rows);
         else hipLaunchKernelGGL((stft_tile_kernel<LOG_R1, LOG_R2, MODE, false, kQ, false>), grid, block, 0, stream, a, it, tw_rows);
@@ -404,6 +421,11 @@ hipError_t launch_mode(const StftArgs &a, const TileTables &t, const RaggedPlan 
         // one geometry only: the detector's analysis engine is fft 1024 (wsManager.js:350-361); other sizes run the
         // two passes one after the other (sono_capi.hip)
         if (a.N != 1024 || plan || a.hop * 4u != a.N) return hipErrorInvalidValue;
+        return launch_one<10 - tile_log_r2(1024), tile_log_r2(1024), MODE>(a, t, plan, stream);
+    } else if constexpr (MODE == MODE_BANK) {
+        // fft 1024 (the application's default display size): the one geometry whose workgroup has LDS left for the
+        // tap list; other sizes and longer lists go through the magnitude matrix (sono_capi.hip)
+        if (a.N != 1024 || plan) return hipErrorInvalidValue;
         return launch_one<10 - tile_log_r2(1024), tile_log_r2(1024), MODE>(a, t, plan, stream);
     } else {
     switch (a.N) {

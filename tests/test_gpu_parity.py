@@ -320,6 +320,47 @@ def test_filter_bank_shapes_against_the_oracle(N, nf, kind):
     e.free()
 
 
+@pytest.mark.parametrize("nf,V,kind", [(512, 768, "two_tap"), (512, 700, "two_tap"), (64, 0, "two_tap"), (300, 768, "three_tap"),
+                                       (36, 512, "empty_rows")])
+def test_filter_bank_in_the_transforms_epilogue_equals_the_two_kernel_form(nf, V, kind):
+    """At fft 1024 a sparse bank (at most 2 048 taps, filters a multiple of four) is applied inside the STFT kernel's
+    epilogue, from the power image in LDS; the engine option "bank_two_kernels" keeps the older form (magnitude matrix in
+    HBM, then the bank kernel).  Same magnitudes, same taps in the same order, same quantiser: the rows are equal bit
+    for bit, at the shared-load hop and at any other, and so are the peak magnitudes and the global maximum."""
+    N, B = 1024, 512
+    rng = np.random.default_rng(nf + V)
+    taps = {"two_tap": 2, "three_tap": 3, "empty_rows": 2}[kind]
+    bank = np.zeros((nf, B + 1), np.float32)
+    for i, p in enumerate(np.sort(rng.uniform(0, B - taps, nf))):
+        if kind == "empty_rows" and i % 3 == 0:
+            continue
+        o = int(p)
+        w = rng.uniform(0.05, 1.0, taps)
+        bank[i, o:o + taps] = (w / w.sum()).astype(np.float32)
+    H = N - V
+    x = signal(N + 203 * H + 5, nf + V, amp=0.7)
+    x[N + 20 * H: N + 23 * H] *= 200.0                          # a loud stretch beside quiet frames
+    x[: N + H] = 0.0                                            # silent frames
+    res = []
+    for two in (False, True):
+        e = sa.SpectrogramEngine(N, "hann")
+        e.set_option("bank_two_kernels", two)
+        e.load_filter_bank(bank.ravel(), nf)
+        u8 = e.compute_spectrogram_u8(x, V, 20.0, 80.0).copy()
+        res.append((u8, e.get_peak_magnitudes(0.0).copy(), np.float32(e.get_global_max()), e.get_peaks(0.0).copy()))
+        e.free()
+    assert res[0][0].size == 204 * nf and res[0][0].max() > 100
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+    # peak bins: the fused form ranks |2X|^2, the bank kernel the rounded magnitudes (first maximum): equal except on a
+    # near-tie of two bins, where both name a bin that holds the row's largest magnitude
+    assert (res[0][3] != res[1][3]).sum() <= 1
+    o = so.OracleEngine(N, "hann")
+    o.load_filter_bank(bank.ravel(), nf)
+    nd, nt = parity.u8_diff(res[0][0], o.compute_spectrogram_u8(x, V, 20.0, 80.0), f"{kind} bank in the epilogue")
+    assert nd <= max(2, parity.U8_MAX_FRACTION * nt)
+
+
 @pytest.mark.parametrize("N,V,width,height", [(256, 192, 40, 30), (1024, 768, 33, 64), (512, 0, 7, 5)])
 def test_image_against_the_restatement(N, V, width, height):
     """compute_spectrogram_image (lib.rs:494-616) pixel by pixel against oracle/image_oracle.py on the C oracle's

@@ -82,6 +82,15 @@ HAND_CASES = [
     ("truncated data", riff([(b"fmt ", fmt_chunk(384000)), (b"data", bytes(100))])[:-40], 384000, 1, 16, 100, 50 / 384000),
     ("extensible format", riff([(b"fmt ", fmt_chunk(250000, 1, 16, 0xFFFE, struct.pack("<HHI", 22, 16, 4) + struct.pack("<H", 1) + bytes(14))),
                                 (b"data", bytes(50))]), 250000, 1, 16, 50, 25 / 250000),
+    # header shapes of real recorders: a Broadcast Wave 'bext' chunk (602 bytes of description, originator, time reference,
+    # UMID ... plus an odd-length coding history, so a pad byte follows) in front of 'fmt '; a 'LIST'/'INFO' chunk in front
+    # of 'fmt '; a 'fact' chunk between 'fmt ' and 'data' (float and extensible files carry one)
+    ("bext before fmt", riff([(b"bext", bytes(602) + b"A=PCM,F=384000,W=16,M=mono,T=recorder\r\n"), (b"fmt ", fmt_chunk(384000)),
+                              (b"data", bytes(120))]), 384000, 1, 16, 120, 60 / 384000),
+    ("LIST INFO before fmt", riff([(b"LIST", b"INFOINAM" + struct.pack("<I", 5) + b"bat1\0\0"), (b"fmt ", fmt_chunk(300000, 2, 16)),
+                                   (b"data", bytes(80))]), 300000, 2, 16, 80, 20 / 300000),
+    ("fact between fmt and data", riff([(b"fmt ", fmt_chunk(192000, 1, 32, 3)), (b"fact", struct.pack("<I", 25)), (b"data", bytes(100))]),
+     192000, 1, 32, 100, 25 / 192000),
     # no 'fmt ': the rate falls back to 256000 (js:26) and the duration to 0 (js:57, 62)
     ("no fmt", riff([(b"LIST", b"abcd"), (b"data", bytes(32))]), 256000, 1, 16, 32, 0.0),
     ("no data", riff([(b"fmt ", fmt_chunk(384000))]), 384000, 1, 16, 0, 0.0),

@@ -22,7 +22,7 @@ for c in $CASES; do
         --output-format csv -d "$D/sq" -o sq -- "$VB" $c 4 > "$D/sq.log" 2>&1 || { echo "counter pass of $c failed"; tail -5 "$D/sq.log"; exit 1; }
     timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$D/grbm" -o grbm -- "$VB" $c 4 > "$D/grbm.log" 2>&1 || { echo "GRBM pass of $c failed"; tail -5 "$D/grbm.log"; exit 1; }
     case "$c" in
-        u8_*|features_*|band_1024_50|mag_*|filterbank_*)
+        u8_*|features_*|band_1024_50|mag_*|filterbank_*|survey_*)
             timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/fetch" -o fetch -- "$VB" $c 4 > "$D/fetch.log" 2>&1 || { echo "fetch pass of $c failed"; exit 1; }
             timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$D/write" -o write -- "$VB" $c 4 > "$D/write.log" 2>&1 || { echo "write pass of $c failed"; exit 1; }
             ;;

@@ -59,7 +59,7 @@ static const double SR = 384000;
 int main(int argc, char **argv)
 {
     static const char *const names[] = {"u8_1024", "u8_4096_blackman95", "u8_2048", "u8_512", "u8_256", "u8_1024_pcm16",
-                                        "features_1024", "band_1024_50", "mag_1024", "mag_1024_hop32", "filterbank_1024",
+                                        "features_1024", "band_1024_50", "mag_1024", "mag_1024_hop32", "filterbank_1024", "survey_1024_pcm16",
                                         "power_db", "db_max", "db_active", "frame_features", "zonal_floors", "band_active_2pass",
                                         "runs", "runs_static", "pcm_to_f32", "sustained_u8_1024"};
     if (argc < 2 || !strcmp(argv[1], "list")) {
@@ -110,13 +110,13 @@ int main(int argc, char **argv)
             CHECK(hipMemcpy(x_host, x, n * sizeof(float), hipMemcpyDeviceToHost));
         }
         float *mags = mode == 2 ? dalloc<float>(F * bins) : nullptr;
-        uint8_t *active = mode == 3 ? dalloc<uint8_t>(F) : nullptr;
+        uint8_t *active = mode == 3 || mode == 6 ? dalloc<uint8_t>(F) : nullptr;
         uint16_t *pb = dalloc<uint16_t>(F);
         float *pm = dalloc<float>(F);
         uint32_t *gm = dalloc<uint32_t>(1);
         CHECK(hipMemsetAsync(gm, 0, 4, s));
         int16_t *pcm = nullptr;
-        if (mode == 4) {
+        if (mode == 4 || mode == 6) {
             pcm = dalloc<int16_t>(n);
             to_pcm16<<<4096, 256, 0, s>>>(x, pcm, n);
         }
@@ -134,6 +134,8 @@ int main(int argc, char **argv)
                 c.launch = [=] { SONO(sono_stft_band_active_dev(e, &b, V, lo, hi, 1e-3, active, nullptr, s)); }; break;
         case 4: c.bytes = (double)F * (hop * 2 + bins + 6);
                 c.launch = [=] { SONO(sono_stft_u8_pcm16_dev(e, pcm, 1, n, n, 1, 0, V, 20.0f, 80.0f, out, pb, pm, gm, s)); }; break;
+        case 6: c.bytes = (double)F * (hop * 2 + 6) + (double)((F + 1) / 2);      // survey pass, 16-bit samples: features + every second frame's flag
+                c.launch = [=] { SONO(sono_stft_survey_pcm16_dev(e, pcm, 1, n, n, 1, 0, lo, hi, 1e-3, pb, pm, gm, active, nullptr, s)); }; break;
         case 5: c.bytes = (double)F * (hop * 4 + nf + 6);
                 c.launch = [=] { size_t frames = 0; SONO(sono_stft_u8(e, x_host, n, V, 20.0f, 80.0f, out_host, F * nf, &frames)); }; break;
         }
@@ -200,6 +202,7 @@ int main(int argc, char **argv)
     else if (name == "mag_1024") stft_case(1024, "hann", 0, 0, 768, 900, 2);
     else if (name == "mag_1024_hop32") stft_case(1024, "hann", 0, 0, 992, 120, 2);
     else if (name == "filterbank_1024") stft_case(1024, "hann", 0, 0, 768, 600, 5);
+    else if (name == "survey_1024_pcm16") stft_case(1024, "hann", 0, 0, 768, 3600, 6);
     else if (name == "power_db") detect_case(0);
     else if (name == "db_max") detect_case(1);
     else if (name == "db_active") detect_case(2);
