@@ -295,6 +295,7 @@ def main():
     pcm16 = args.workload in ("cfg2_pcm16", "cfg5_pcm16", "cfg5")
     if pcm16:
         x = torch.clamp(torch.round(x * 32768.0), -32768, 32767).to(torch.int16)
+        torch.cuda.empty_cache()        # the float recording's block goes back to the device: the library allocates beside torch
     bytes_per_frame = (2 if pcm16 else 4) * hop + (0 if features_only else bins) + 6
     detect = args.workload == "cfg5"          # the survey pass with the detector behind it
     if detect:

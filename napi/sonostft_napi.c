@@ -638,6 +638,25 @@ static int set_spectrogram(napi_env env, napi_value o, sono_engine *e, size_t i,
            napi_set_named_property(env, o, "freqBins", *freq_bins) == napi_ok;
 }
 
+/* engine.set_option(name: string, on: boolean): the engine's switches (sono_engine_set_option).  Not part of the wasm
+ * surface. */
+static napi_value engine_set_option(napi_env env, napi_callback_info info)
+{
+    napi_value argv[2], self;
+    if (!get_args(env, info, 2, argv, &self)) return NULL;
+    engine_box *b = engine_of(env, self);
+    if (!b) return NULL;
+    char name[64];
+    size_t len = 0;
+    bool on = false;
+    if (napi_get_value_string_utf8(env, argv[0], name, sizeof name, &len) != napi_ok || napi_get_value_bool(env, argv[1], &on) != napi_ok) {
+        napi_throw_type_error(env, NULL, "set_option(string, boolean)");
+        return NULL;
+    }
+    const int rc = sono_engine_set_option(b->e, name, on ? 1 : 0);
+    return rc ? throw_status(env, rc) : undefined(env);
+}
+
 static napi_value engine_process_full_file(napi_env env, napi_callback_info info)
 {
     static const char *const types[] = {"CF", "FM", "CF-FM"};
@@ -649,9 +668,12 @@ static napi_value engine_process_full_file(napi_env env, napi_callback_info info
     void *x = NULL;
     size_t n = 0;
     double sr = 0, flow = 0, fhigh = 0;
-    if (!get_typed(env, argv[0], napi_float32_array, &x, &n) || !get_f64(env, argv[1], &sr) || !get_f64(env, argv[2], &flow) ||
-        !get_f64(env, argv[3], &fhigh)) {
-        napi_throw_type_error(env, NULL, "process_full_file(Float32Array, sampleRate, flowKHz, fhighKHz, options?, config?)");
+    /* the recording: a Float32Array as the reference's processFullFile takes it, or the Int16Array of a decoded 16-bit
+     * WAV channel (mono), which goes to the GPU as it is: half the bytes over the link, no float copy on the host */
+    const int is_f32 = get_typed(env, argv[0], napi_float32_array, &x, &n);
+    const int pcm16 = !is_f32 && get_typed(env, argv[0], napi_int16_array, &x, &n);
+    if ((!is_f32 && !pcm16) || !get_f64(env, argv[1], &sr) || !get_f64(env, argv[2], &flow) || !get_f64(env, argv[3], &fhigh)) {
+        napi_throw_type_error(env, NULL, "process_full_file(Float32Array | Int16Array, sampleRate, flowKHz, fhighKHz, options?, config?)");
         return NULL;
     }
     sono_full_file_options opt;
@@ -669,7 +691,8 @@ static napi_value engine_process_full_file(napi_env env, napi_callback_info info
     napi_value freq_bins = NULL;
     opt.threads = 0;
     size_t count = 0;
-    int rc = sono_process_full_file(b->e, (const float *)x, n, sr, flow, fhigh, &opt, NULL, 0, &count);
+    int rc = pcm16 ? sono_process_full_file_pcm16(b->e, (const int16_t *)x, n, 1, 0, sr, flow, fhigh, &opt, NULL, 0, &count)
+                   : sono_process_full_file(b->e, (const float *)x, n, sr, flow, fhigh, &opt, NULL, 0, &count);
     if (rc != SONO_OK && rc != SONO_ECAPACITY) return throw_status(env, rc);
     sono_full_file_call *calls = (sono_full_file_call *)malloc((count ? count : 1) * sizeof(*calls));
     if (!calls) { napi_throw_error(env, NULL, "sonostft: out of memory"); return NULL; }
@@ -730,6 +753,7 @@ static napi_value init(napi_env env, napi_value exports)
         METHOD("compute_spectrogram_image", engine_compute_spectrogram_image),
         METHOD("release_memory", engine_release_memory),
         METHOD("process_full_file", engine_process_full_file),
+        METHOD("set_option", engine_set_option),
     };
     const napi_property_descriptor wave_methods[] = {
         METHOD("free", wave_free),

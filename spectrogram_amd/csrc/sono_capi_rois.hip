@@ -730,11 +730,18 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
         // 16-bit sample frames cross the link as they are (half the bytes of the float recording) and become the
         // resident float recording on the device: everything below reads the same floats as the f32 entry point
         // would have uploaded (value / 32768 is exact).
-        const size_t bytes = n * (size_t)hs.channels * sizeof(int16_t);
-        HIP_TRY(e->d_in.reserve(bytes));
-        rc = sono::upload_host_array(e, e->d_in.p, hs.q, bytes, e->stream);
-        if (rc) return rc;
-        HIP_TRY(sono::launch_pcm_to_f32(e->d_in.p, n, hs.channels, hs.channel, 16, 0, d_rec, e->stream));
+        // In pieces of at most 512 MB through one staging buffer: copy and conversion follow each other on the
+        // engine's stream, so a piece is converted before the next one overwrites it, and no second whole copy of a
+        // night-long recording has to fit beside the float one.
+        const size_t frame_bytes = (size_t)hs.channels * sizeof(int16_t);
+        const size_t piece_frames = std::max<size_t>(1, ((size_t)512 << 20) / frame_bytes);
+        HIP_TRY(e->d_in.reserve(std::min(n, piece_frames) * frame_bytes));
+        for (size_t f0 = 0; f0 < n; f0 += piece_frames) {
+            const size_t cnt = std::min(piece_frames, n - f0);
+            rc = sono::upload_host_array(e, e->d_in.p, hs.q + f0 * hs.channels, cnt * frame_bytes, e->stream);
+            if (rc) return rc;
+            HIP_TRY(sono::launch_pcm_to_f32(e->d_in.p, cnt, hs.channels, hs.channel, 16, 0, d_rec + f0, e->stream));
+        }
     } else {
         rc = sono::upload_host_array(e, d_rec, x, n * sizeof(float), e->stream);
         if (rc) return rc;

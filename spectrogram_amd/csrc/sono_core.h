@@ -18,6 +18,7 @@
 #define SONO_HD inline
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
+struct uint4 { unsigned int x, y, z, w; };
 #endif
 
 namespace sono {
@@ -26,12 +27,12 @@ enum Mode : int {
     MODE_MAG = 0,    // frames x N/2 linear magnitudes           (lib.rs:113-161)
     MODE_U8 = 1,     // frames x N/2 u8 dB codes + peak features (lib.rs:199-304,349-443)
     MODE_POWER = 2,  // frames x (N/2+1) |X|^2 of mean-removed frames (lib.rs:1058-1094)
-    MODE_BANK = 5,   // tiled kernel, fft 1024: MODE_U8 with the rows taken through a sparse filter bank (lib.rs:310-334) in the
-                     // epilogue, from the power image in LDS: no magnitude matrix in HBM between transform and bank
-    MODE_SURVEY = 4, // tiled kernel, hop N/4: MODE_U8's peak features without rows AND MODE_BAND's test on every second frame
-                     // (the frames of the fast scan's hop N/2): one read of the samples for both (batCallDetector.js:878-949 beside lib.rs:349-443)
     MODE_BAND = 3,   // per frame: sum of mag^2 over a band of bins, compared with a target (batCallDetector.js:913-927);
                      // tiled kernel only
+    MODE_SURVEY = 4, // tiled kernel, hop N/4: MODE_U8's peak features without rows AND MODE_BAND's test on every second frame
+                     // (the frames of the fast scan's hop N/2): one read of the samples for both (batCallDetector.js:878-949 beside lib.rs:349-443)
+    MODE_BANK = 5,   // tiled kernel, fft 1024: MODE_U8 with the rows taken through a sparse filter bank (lib.rs:310-334) in the
+                     // epilogue, from the power image in LDS: no magnitude matrix in HBM between transform and bank
 };
 
 // Arguments common to the STFT kernels.  Frames are numbered globally:

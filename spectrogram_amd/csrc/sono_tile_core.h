@@ -440,8 +440,7 @@ struct TileLane {
                 const float *p = base + off;
                 static_for<0, G::R1>([&](auto n_) { xa[decltype(n_)::value] = p[R2 * decltype(n_)::value]; });
             }
-            return;
-        }
+        } else {
         static_for<0, G::JPL>([&](auto jj_) {
             constexpr int jj = decltype(jj_)::value;
             if constexpr (PCM) {
@@ -496,6 +495,7 @@ struct TileLane {
 #endif
             });
         });
+        }
     }
 
     // Pass 1, first half: window and real-input DFT-R1 of this lane's column of

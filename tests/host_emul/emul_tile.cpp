@@ -1,6 +1,7 @@
 // Host emulation of one wave of the register-tiled STFT kernel
 // (sono_tile_core.h): the passes run lane by lane against a plain array that
 // stands in for the wave's LDS region.  Test-only.
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -10,6 +11,7 @@
 
 using namespace sono;
 
+static const BankTap *g_bank_taps = nullptr;      // MODE_BANK: the tap list as the kernel holds it in LDS
 static int g_ragged = 0;      // 1 = walk the tiles through the ragged-batch tables
 extern "C" void emul_tile_set_ragged(int v) { g_ragged = v; }
 
@@ -96,8 +98,21 @@ static void run_tiles(const StftArgs &a)
                 if (bp[m] == pmax[l] && bk[m] < bin[l]) bin[l] = bk[m];
         }
         for (int l = 0; l < 64; ++l) lanes[l].features(tr, pmax[l], bin[l]);
+        if constexpr (MODE == MODE_SURVEY) {                // the band test on the tile's even frames, R1 lanes per frame
+            double e[64], e2[64];
+            for (int l = 0; l < 64; ++l) e[l] = lanes[l].survey_band_sum(img, meta);
+            for (int o = G::HALF; o > 0; o >>= 1) {
+                for (int l = 0; l < 64; ++l) e2[l] = e[l] + e[l ^ o];
+                std::memcpy(e, e2, sizeof(e));
+            }
+            for (int l = 0; l < 64; ++l) lanes[l].survey_band_emit(tr, e[l]);
+        }
+        if constexpr (MODE == MODE_BANK) {                  // the filter bank from the power image: magnitudes in place, then the rows
+            for (int l = 0; l < 64; ++l) lanes[l].bank_magnitudes(img, meta);
+            for (int l = 0; l < 64; ++l) lanes[l].bank_rows(tr, img, g_bank_taps);
+        }
     }
-    if (MODE == MODE_U8 && a.gmax_bits) {
+    if ((MODE == MODE_U8 || MODE == MODE_SURVEY || MODE == MODE_BANK) && a.gmax_bits) {
         float m = 0.0f;
         for (int l = 0; l < 64; ++l) m = lanes[l].run_max > m ? lanes[l].run_max : m;
         const float mag = fast_sqrt(m) * a.inv_n;
@@ -123,6 +138,11 @@ extern "C" void emul_tile_set_band(unsigned int lo, unsigned int hi, double targ
     g_band_lo = lo; g_band_hi = hi; g_band_target = target; g_band_active = active; g_band_energy = energy;
 }
 
+static const float *g_bank = nullptr;
+static size_t g_bank_len = 0, g_bank_filters = 0;
+// The filter bank of the next emul_tile call with mode 5 (flat weights with row stride fft/2, lib.rs:317-326).
+extern "C" void emul_tile_set_bank(const float *w, size_t len, size_t filters) { g_bank = w; g_bank_len = len; g_bank_filters = filters; }
+
 extern "C" int emul_tile(int mode, const float *x, unsigned long long n_streams,
                          unsigned long long stream_stride, unsigned long long frames_per_stream,
                          unsigned int hop, unsigned int N, const float *window, float gain_db,
@@ -131,7 +151,8 @@ extern "C" int emul_tile(int mode, const float *x, unsigned long long n_streams,
 {
     (void)out_power;
     if (N != 4096 && N != 2048 && N != 1024 && N != 512 && N != 256) return 1;
-    if (mode != MODE_MAG && mode != MODE_U8 && mode != MODE_BAND) return 1;
+    if (mode != MODE_MAG && mode != MODE_U8 && mode != MODE_BAND && mode != MODE_SURVEY && mode != MODE_BANK) return 1;
+    if ((mode == MODE_SURVEY || mode == MODE_BANK) && (N != 1024 || (mode == MODE_SURVEY && hop * 4u != N))) return 1;
     StftArgs a;
     std::memset(&a, 0, sizeof(a));
     a.x = x; a.n_streams = n_streams; a.stream_stride = stream_stride;
@@ -143,6 +164,30 @@ extern "C" int emul_tile(int mode, const float *x, unsigned long long n_streams,
     a.band_active = g_band_active; a.band_energy = g_band_energy;
     const Quant q = make_quant(N, gain_db, range_db);
     a.q_a = q.a; a.q_c = q.c; a.q_floor = q.floor;
+    std::vector<BankTap> taps;
+    if (mode == MODE_BANK) {
+        // the bank's tap list exactly as the library builds and stages it (bank_taps_host: sono_kernels.hip's bank_taps)
+        if (!g_bank || g_bank_filters == 0 || g_bank_filters % 4) return 1;
+        const size_t bins = N / 2;
+        size_t most = 0;
+        std::vector<std::vector<BankTap>> per(g_bank_filters);
+        for (size_t i = 0; i < g_bank_filters; ++i) {
+            for (size_t j = 0; j < bins && i * bins + j < g_bank_len; ++j)
+                if (!(g_bank[i * bins + j] == 0.0f)) per[i].push_back(BankTap{g_bank[i * bins + j], (unsigned int)j});
+            most = std::max(most, per[i].size());
+        }
+        if (most == 0 || most * g_bank_filters > kBankLdsTaps) return 1;
+        taps.assign(most * g_bank_filters, BankTap{0.0f, 0u});
+        for (size_t i = 0; i < g_bank_filters; ++i)
+            for (size_t k = 0; k < per[i].size(); ++k) taps[k * g_bank_filters + i] = per[i][k];
+        g_bank_taps = taps.data();
+        a.bank_filters = (unsigned int)g_bank_filters;
+        a.bank_max_taps = (unsigned int)most;
+        const BankQuant bq = make_bank_quant(gain_db, range_db);
+        a.bank_q_a = bq.a; a.bank_q_c = bq.c;
+    }
+    if (mode == MODE_SURVEY) { if (g_any_hop) return 1; run_tiles<5, 5, MODE_SURVEY, 1>(a); return 0; }
+    if (mode == MODE_BANK) { if (!g_any_hop && hop * 4u == N) run_tiles<5, 5, MODE_BANK, 1>(a); else run_tiles<5, 5, MODE_BANK, 0>(a); return 0; }
     const bool quarter = !g_any_hop && hop * 4u == N, half = !g_any_hop && hop * 2u == N;
 #define RUN(L1, L2) do { \
         if (mode == MODE_MAG) { if (quarter) run_tiles<L1, L2, MODE_MAG, 1>(a); else run_tiles<L1, L2, MODE_MAG, 0>(a); } \

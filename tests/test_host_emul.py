@@ -223,6 +223,64 @@ def test_tile_wave_band_energy(emul, N, V, lo, hi):
     assert np.array_equal(active, (energy > target).astype(np.uint8))
 
 
+def test_tile_wave_survey_pass(emul):
+    # features at hop N/4 and the band test on the even frames from one pass: peaks equal the row mode's, flags and sums
+    # equal the band mode's at hop N/2 (the sums to the f32 magnitudes' last bits: another partner frame, another order)
+    N, V, lo, hi = 1024, 768, 26, 341
+    for n in (N + 13 * 256 + 7, N + 12 * 256):                 # 14 frames -> 7 scan frames; 13 -> 7
+        x = signal(n, N + 9)
+        x[: N + 2 * 256] = 0.0
+        e = so.OracleEngine(N, "hann")
+        F, FS = so.num_frames(n, N, V), so.num_frames(n, N, 512)
+        assert FS == (F + 1) // 2
+        want = run_emul(emul, "emul_tile", 1, x, N, V, e.window)
+        ref_active, ref_energy = np.full(FS, 7, np.uint8), np.zeros(FS, np.float64)
+        probe = np.zeros(FS, np.float64)
+        emul.emul_tile_set_band(C.c_uint(lo), C.c_uint(hi), C.c_double(0.0), _p(ref_active), _p(probe))
+        run_emul(emul, "emul_tile", 3, x, N, 512, e.window)
+        srt = np.sort(probe)
+        target = float(0.5 * (srt[FS // 2 - 1] + srt[FS // 2]))          # between two frames' sums, not on one
+        emul.emul_tile_set_band(C.c_uint(lo), C.c_uint(hi), C.c_double(target), _p(ref_active), _p(ref_energy))
+        run_emul(emul, "emul_tile", 3, x, N, 512, e.window)
+        active, energy = np.full(FS, 9, np.uint8), np.zeros(FS, np.float64)
+        emul.emul_tile_set_band(C.c_uint(lo), C.c_uint(hi), C.c_double(target), _p(active), _p(energy))
+        got = run_emul(emul, "emul_tile", 4, x, N, V, e.window)
+        assert np.array_equal(got["peak_bin"], want["peak_bin"]) and np.array_equal(got["peak_mag"], want["peak_mag"])
+        assert got["gmax"] == want["gmax"] and not got["u8"].any()              # no rows in this mode
+        assert np.array_equal(active, ref_active) and np.allclose(energy, ref_energy, rtol=1e-6, atol=0)
+        assert energy[0] == 0.0 and 0 < active.sum() < FS
+
+
+@pytest.mark.parametrize("V,nf,taps", [(768, 512, 2), (700, 64, 2), (0, 36, 3)])
+def test_tile_wave_filter_bank_in_the_epilogue(emul, V, nf, taps):
+    # apply_filter_bank (lib.rs:310-334) from the power image, against the oracle's rows
+    N, B = 1024, 512
+    rng = np.random.default_rng(nf + V)
+    bank = np.zeros((nf, B + 1), np.float32)                   # rows of B + 1 weights, used with stride B (the reference's quirk)
+    for i, p in enumerate(np.sort(rng.uniform(0, B - taps, nf))):
+        if i % 5 == 4:
+            continue                                           # filters without any tap
+        o = int(p)
+        w = rng.uniform(0.05, 1.0, taps)
+        bank[i, o:o + taps] = (w / w.sum()).astype(np.float32)
+    flat = np.ascontiguousarray(bank.ravel())
+    H = N - V
+    x = signal(N + 9 * H + 5, nf)
+    x[: N + H] = 0.0
+    o = so.OracleEngine(N, "hann")
+    o.load_filter_bank(flat, nf)
+    want = np.asarray(o.compute_spectrogram_u8(x, V, 20.0, 80.0))
+    F = so.num_frames(len(x), N, V)
+    emul.emul_tile_set_bank.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+    emul.emul_tile_set_bank(_p(flat), flat.size, nf)
+    got = run_emul(emul, "emul_tile", 5, x, N, V, o.window)
+    rows = got["u8"][: F * nf]
+    nd, nt = parity.u8_diff(rows, want, "bank in the epilogue")
+    assert nt == F * nf and nd <= max(2, 1e-3 * nt)
+    assert not rows[: 2 * nf].any() and rows.max() > 100
+    assert np.array_equal(got["peak_bin"], np.asarray(o.get_peaks(0.0)))
+
+
 @pytest.mark.parametrize("N,V", [(1024, 768), (256, 128), (4096, 3891)])
 def test_tile_wave_ragged_tables_give_the_same_rows(emul, N, V):
     # the same batch walked through the ragged-batch tables (per-tile stream ids, per-stream offsets): identical output

@@ -172,3 +172,38 @@ def test_addon_whole_file_pass_equals_python_binding(tmp_path):
                 continue
             assert got[k] == v, (k, got[k], v)                           # same library, doubles through JSON: bit-exact
         assert got["kneeTime_ms"] == ref["kneeFreq_ms"]
+
+
+@pytest.mark.gpu
+def test_addon_takes_a_16_bit_recording_and_engine_options(tmp_path):
+    """engine.process_full_file on the Int16Array of a decoded 16-bit WAV channel gives the calls of the Float32Array of
+    the same samples / 32768; engine.set_option reaches the engine's switches and rejects unknown names."""
+    need_node()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_framing.npz"))
+    meta = json.loads(bytes(g["__meta__"]).decode())
+    (c,) = [c for c in meta if c["kind"] == "fullfile_measured"]
+    q = np.clip(np.round(np.asarray(g[c["name"] + "/x"], np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+    q.tofile(tmp_path / "x.i16")
+    script = """
+        const fs = require('fs');
+        const w = require('./napi/sonoradar_gpu.js');
+        const buf = fs.readFileSync(%r);
+        const q = new Int16Array(buf.buffer, buf.byteOffset, buf.length / 2);
+        const x = Float32Array.from(q, (v) => v / 32768);
+        const e = new w.SpectrogramEngine(%d, %r, null);
+        const cfg = {hopPercent: %r, callThreshold_dB: %r, minCallDuration_ms: %r, debugMode: 1};
+        const opt = {threshold_dB: %r, padding_ms: %r};
+        const a = e.process_full_file(q, %d, %r, %r, opt, cfg), b = e.process_full_file(x, %d, %r, %r, opt, cfg);
+        const r = {n: a.length, same: JSON.stringify(a) === JSON.stringify(b)};
+        e.set_option('force_any_hop', true);
+        r.again = JSON.stringify(e.process_full_file(q, %d, %r, %r, opt, cfg)) === JSON.stringify(a);
+        try { e.set_option('no_such_switch', true); } catch (err) { r.unknown = err.message; }
+        try { e.process_full_file(new Uint8Array(8), 1, 1, 1); } catch (err) { r.wrongType = err.message; }
+        e.free();
+        console.log(JSON.stringify(r));
+    """ % (str(tmp_path / "x.i16"), c["fft"], c["window"], c["hop_percent"], c["call_threshold_db"], c["min_call_duration_ms"],
+           c["scan_threshold_db"], c["padding_ms"], c["sr"], c["flow_khz"], c["fhigh_khz"], c["sr"], c["flow_khz"], c["fhigh_khz"],
+           c["sr"], c["flow_khz"], c["fhigh_khz"])
+    out = json.loads(node(script))
+    assert out["n"] > 0 and out["same"] and out["again"]
+    assert "unknown option" in out["unknown"] and "Int16Array" in out["wrongType"]
