@@ -319,6 +319,7 @@ int sono_engine_release_memory(sono_engine *e)
     for (auto &slot : e->upload_slot) slot.release();
     std::free(e->filtered); e->filtered = nullptr; e->filtered_cap = 0;
     e->frame_tables.clear(); e->frame_tables.shrink_to_fit();
+    e->scan_segments.clear(); e->scan_segments.shrink_to_fit();
     e->full_file_slices.clear(); e->full_file_slices.shrink_to_fit();
     if (e->pipe) { sono::stream_pipe_destroy(e->pipe); e->pipe = nullptr; }
     return SONO_OK;

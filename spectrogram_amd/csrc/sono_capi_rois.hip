@@ -428,8 +428,10 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
 
 static int frame_roi_calls(const HostSamples &hs, const float *x_filtered, size_t n, const sono_segment *rois, size_t n_rois,
                            const sono_roi_table *t, double sample_rate, uint32_t fft_size, double call_threshold_db,
-                           double min_call_duration_ms, sono_roi_call *out, size_t cap, size_t *count)
+                           double min_call_duration_ms, sono_roi_call *out, size_t cap, size_t *count,
+                           std::vector<sono_roi_call> *grown = nullptr)
 {
+    // grown: the calls go into this vector, sized to what was found, instead of out[0..cap)
     if (count) *count = 0;
     if (!t || (n && !hs.x && !hs.q) || (n_rois && (!rois || !t->row0)) || !(sample_rate > 0) || fft_size == 0)
         return fail(SONO_EINVAL, "sono_frame_roi_calls: NULL or non-positive argument");
@@ -520,6 +522,13 @@ static int frame_roi_calls(const HostSamples &hs, const float *x_filtered, size_
     for (std::thread &th : pool) th.join();
     if (low_rate) return fail(SONO_EINVAL, "sono_frame_roi_calls: sample rate below 20 kHz (the 0.1 ms window has no hop)");
     size_t made = 0;
+    if (grown) {
+        size_t found = 0;
+        for (size_t r = 0; r < n_rois; ++r) found += per_region[r].size();
+        grown->resize(found);
+        out = grown->data();
+        cap = found;
+    }
     for (size_t r = 0; r < n_rois; ++r) {
         if (made + per_region[r].size() > cap || (!out && !per_region[r].empty()))
             return fail(SONO_ECAPACITY, "sono_frame_roi_calls: output buffer too small");
@@ -719,9 +728,10 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
     // The recording goes to HBM once and stays there: the fast scan, the regions' and the calls' transforms all read it
     // where it lies (sono_fast_scan_segments, sono_analyze_rois and sono_measure_roi_calls, called one by one, each
     // upload what they need).
-    std::vector<sono_segment> raw(n / std::max<size_t>(N / 2, 1) + 2);
+    std::vector<sono_segment> &raw = e->scan_segments;      // kept by the engine: tens of MB of fresh pages per call otherwise
     size_t n_raw = 0;
     if (n < N) return SONO_OK;                                                      // no frame, no segment (js:595-598)
+    if (raw.size() < n / std::max<size_t>(N / 2, 1) + 2) raw.resize(n / std::max<size_t>(N / 2, 1) + 2);
     DeviceGuard guard(e->device);
     HIP_TRY(e->d_rec.reserve(n * sizeof(float)));
     float *d_rec = (float *)e->d_rec.p;
@@ -781,10 +791,10 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
     if (rc) return rc;
     lap("region analysis (GPU)");
     // framing (js:677-794), measurement (js:797) and what follows it (js:802-827)
-    std::vector<sono_roi_call> framed(total / 2 + n_rois + 1);
+    std::vector<sono_roi_call> framed;       // sized by the framing: a bound from the frame count would be hundreds of MB of fresh pages
     size_t n_calls = 0;
     rc = frame_roi_calls(hs, xf, n, rois.data(), n_rois, &t, sample_rate, N, opt->call_threshold_db,
-                         opt->min_call_duration_ms, framed.data(), framed.size(), &n_calls);
+                         opt->min_call_duration_ms, nullptr, 0, &n_calls, &framed);
     if (rc) return rc;
     lap("framing (host)");
     std::vector<sono_call_measurement> meas(n_calls + 1);

@@ -157,6 +157,7 @@ struct sono_engine {
     float *filtered = nullptr;              // ... and the host copy of its high-passed regions (pageable, kept, never cleared)
     size_t filtered_cap = 0;                // in samples
     std::vector<uint32_t> frame_tables;     // ... and the per-frame records of its regions (six 4-byte arrays)
+    std::vector<sono_segment> scan_segments;   // ... and the fast scan's segments (one per half frame at most)
     sono::HostBuf h_in, h_out;              // staging of the whole-file passes (packed samples; records / dB matrices)
     // The measurement stage's two slots: one batch is measured on host threads while the next is on the GPU.
     struct MeasureSlot {

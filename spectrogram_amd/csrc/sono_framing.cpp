@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <emmintrin.h>
 
 namespace sono {
 
@@ -33,37 +34,87 @@ bool host_refine_end(const float *audio, size_t n, double sample_rate, int64_t s
     const int64_t sustained = (int64_t)std::floor(sample_rate * (0.5 / 1000));   // js:1663
     const int64_t hop = window / 2;                                              // js:1664
     if (hop < 1) return false;
-    std::vector<float> db_values;                                                // Float32Array, js:1669
-    std::vector<int64_t> centre;
+    // The window energies first (js:1676-1683).  A window's sum runs over its samples in order, one rounding per sample,
+    // so it cannot be split; but the windows are independent, and four of them are summed side by side.
+    const int64_t span = safe_end - window - safe_start;
+    const size_t steps = span > 0 ? (size_t)((span + hop - 1) / hop) : 0;
+    if (steps == 0) return true;
+    // Every sample lies in two windows: its square (exact in a double: 24-bit factors) is formed once, two per instruction.
+    static thread_local std::vector<double> scratch;
+    const size_t covered = (size_t)((int64_t)(steps - 1) * hop + window);
+    if (scratch.size() < covered + steps) scratch.resize(covered + steps);
+    double *sq = scratch.data(), *sums = sq + covered;
+    {
+        const float *a = audio + safe_start;
+        size_t i = 0;
+        for (; i + 4 <= covered; i += 4) {
+            const __m128 v = _mm_loadu_ps(a + i);
+            const __m128d lo = _mm_cvtps_pd(v), hi = _mm_cvtps_pd(_mm_movehl_ps(v, v));
+            _mm_storeu_pd(sq + i, _mm_mul_pd(lo, lo));
+            _mm_storeu_pd(sq + i + 2, _mm_mul_pd(hi, hi));
+        }
+        for (; i < covered; ++i) { const double v = (double)a[i]; sq[i] = v * v; }
+    }
+    size_t k = 0;
+    for (; k + 8 <= steps; k += 8) {
+        const double *q0 = sq + k * (size_t)hop, *q1 = q0 + hop, *q2 = q1 + hop, *q3 = q2 + hop, *q4 = q3 + hop, *q5 = q4 + hop,
+                     *q6 = q5 + hop, *q7 = q6 + hop;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
+        for (int64_t j = 0; j < window; ++j) {
+            a0 += q0[j]; a1 += q1[j]; a2 += q2[j]; a3 += q3[j]; a4 += q4[j]; a5 += q5[j]; a6 += q6[j]; a7 += q7[j];
+        }
+        sums[k] = a0; sums[k + 1] = a1; sums[k + 2] = a2; sums[k + 3] = a3;
+        sums[k + 4] = a4; sums[k + 5] = a5; sums[k + 6] = a6; sums[k + 7] = a7;
+    }
+    for (; k < steps; ++k) {
+        const double *q0 = sq + k * (size_t)hop;
+        double a0 = 0.0;
+        for (int64_t j = 0; j < window; ++j) a0 += q0[j];
+        sums[k] = a0;
+    }
+    // dB of one window (js:1685), worked out when it is first asked for: the walk below ends soon after the call does
+    std::vector<float> db_values(steps);                                         // Float32Array, js:1669
+    std::vector<char> have(steps, 0);
+    auto db_exact = [&](size_t i) { return 20 * std::log10(std::sqrt(sums[i] / (double)window) + 1e-9); };
+    auto db_at = [&](size_t i) {
+        if (!have[i]) { db_values[i] = (float)db_exact(i); have[i] = 1; }
+        return (double)db_values[i];
+    };
+    auto centre = [&](size_t i) { return safe_start + (int64_t)i * hop + window / 2; };
+    // The loudest window, first one on a tie, judged on the unrounded dB (js:1688).  The dB grows with the energy; when
+    // the loudest window is above -60 dB (where the 1e-9 inside the logarithm no longer matters), a window a billionth
+    // below the largest energy is 4e-9 dB lower, a million rounding steps of the dB: only the windows within that
+    // margin can reach the largest dB, and only those are evaluated, in order.  Quieter spans, and energies that are
+    // not finite numbers (NaN or infinite samples), go through every window as the reference does.
+    double top = 0.0;
+    bool finite = true;
+    for (size_t i = 0; i < steps; ++i) {
+        if (!(sums[i] <= 1.79769313486231570815e308)) finite = false;
+        if (sums[i] > top) top = sums[i];
+    }
+    const bool margin = finite && top / (double)window > 1e-6;
+    const double near_top = top * (1 - 1e-9);
     double peak = -INFINITY;
     size_t peak_index = 0;
-    for (int64_t i = safe_start; i < safe_end - window; i += hop) {              // js:1676
-        double sum_sq = 0.0;
-        for (int64_t j = 0; j < window; ++j) {
-            const double v = (double)audio[i + j];
-            sum_sq += v * v;
-        }
-        const double db = 20 * std::log10(std::sqrt(sum_sq / (double)window) + 1e-9);
-        if (db > peak) { peak = db; peak_index = db_values.size(); }             // on the unrounded value, js:1688
-        db_values.push_back((float)db);
-        centre.push_back(i + window / 2);
+    for (size_t i = 0; i < steps; ++i) {
+        if (margin && sums[i] < near_top) continue;
+        const double db = db_exact(i);
+        if (db > peak) { peak = db; peak_index = i; }
     }
-    const size_t steps = db_values.size();
-    if (steps == 0) return true;
     double min_db = peak;                                                        // js:1699
     size_t min_index = peak_index;
     const size_t ahead = (size_t)std::ceil((double)sustained / (double)hop);
     for (size_t i = peak_index + 1; i < steps; ++i) {
-        const double cur = (double)db_values[i];
+        const double cur = db_at(i);
         if (cur < min_db) { min_db = cur; min_index = i; }
-        if (min_db < -60 && cur < -60 + 2) { *refined = centre[min_index]; return true; }     // js:1714
+        if (min_db < -60 && cur < -60 + 2) { *refined = centre(min_index); return true; }     // js:1714
         if (cur - min_db > 0.5) {                                                // js:1722-1723
             if (min_db > -32) continue;                                          // js:1728: still inside the signal body
             const size_t limit = steps < i + ahead ? steps : i + ahead;          // js:1744
             bool is_sustained = true;
-            for (size_t k = i + 1; k < limit; ++k)
-                if ((double)db_values[k] < min_db + 0.5) { is_sustained = false; break; }
-            if (is_sustained) { *refined = centre[min_index]; return true; }     // js:1798
+            for (size_t q = i + 1; q < limit; ++q)
+                if (db_at(q) < min_db + 0.5) { is_sustained = false; break; }
+            if (is_sustained) { *refined = centre(min_index); return true; }     // js:1798
         }
     }
     return true;

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "sono_framing.h"
+#include "sono_rowscan.h"
 
 namespace sono {
 
@@ -48,57 +49,16 @@ double zone_floor(const double *zonal, size_t zones, double freq_khz)
     return -100;                                                                 // the map has no such key
 }
 
-// Running maxima of a call matrix's rows, built row by row on first use.  The threshold searches ask, a hundred
-// thresholds per call and for frame after frame, "which is the first bin of this row above the threshold, counting from
-// the bottom (or from the top)": with the running maximum from that end -- which exceeds the threshold exactly from that
-// bin on -- the answer is a binary search instead of a walk along the row.  Same bins as the reference's loops, which
-// walk (batCallDetector.js:2509-2522, 2002-2038); a NaN is never above a threshold and never raises a maximum.
-class RowMaxima {
-public:
-    RowMaxima(const CallMatrix &m, bool from_bottom) : m_(m), from_bottom_(from_bottom), run_(m.frames * m.bins), built_(m.frames, 0) {}
-    // lowest bin b <= top with db[f][b] > thr, or -1 (from_bottom)
-    int64_t first_above(int64_t f, int64_t top, double thr)
-    {
-        const float *r = row(f);
-        if (top < 0 || !((double)r[top] > thr)) return -1;
-        int64_t lo = 0, hi = top;                            // r[hi] > thr; find the first such
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) / 2;
-            if ((double)r[mid] > thr) hi = mid; else lo = mid + 1;
-        }
-        return lo;
-    }
-    // highest bin b >= bottom with db[f][b] > thr, or -1 (from the top)
-    int64_t last_above(int64_t f, int64_t bottom, double thr)
-    {
-        const float *r = row(f);
-        const int64_t nb = (int64_t)m_.bins;
-        if (bottom >= nb || !((double)r[bottom] > thr)) return -1;
-        int64_t lo = bottom, hi = nb - 1;                    // r[lo] > thr; find the last such
-        while (lo < hi) {
-            const int64_t mid = (lo + hi + 1) / 2;
-            if ((double)r[mid] > thr) lo = mid; else hi = mid - 1;
-        }
-        return lo;
-    }
-
-private:
-    const float *row(int64_t f)
-    {
-        float *r = run_.data() + (size_t)f * m_.bins;
-        if (!built_[(size_t)f]) {
-            const float *src = m_.db + (size_t)f * m_.bins;
-            float cur = -INFINITY;
-            if (from_bottom_) for (size_t b = 0; b < m_.bins; ++b) { if (src[b] > cur) cur = src[b]; r[b] = cur; }
-            else for (size_t b = m_.bins; b-- > 0;) { if (src[b] > cur) cur = src[b]; r[b] = cur; }
-            built_[(size_t)f] = 1;
-        }
-        return r;
-    }
-    const CallMatrix &m_;
-    bool from_bottom_;
-    std::vector<float> run_;
-    std::vector<char> built_;
+// The threshold searches ask, a hundred thresholds per call and for frame after frame, "which is the first bin of this
+// row above the threshold, counting from the bottom (or from the top)".  Same bins as the reference's loops, which walk
+// the row entry by entry (batCallDetector.js:2509-2522, 2002-2038); here four entries per comparison (sono_rowscan.h).
+struct Rows {
+    const CallMatrix &m;
+    const float *row(int64_t f) const { return m.db + (size_t)f * m.bins; }
+    // lowest bin b <= top with db[f][b] > thr, or -1
+    int64_t first_above(int64_t f, int64_t top, float thr) const { return first_gt(row(f), 0, top, thr); }
+    // highest bin b >= bottom with db[f][b] > thr, or -1
+    int64_t last_above(int64_t f, int64_t bottom, float thr) const { return last_gt(row(f), bottom, (int64_t)m.bins - 1, thr); }
 };
 
 struct LowM { double threshold; double low_hz; bool found; int64_t end_frame; int64_t bin; };
@@ -126,12 +86,14 @@ LowResult find_optimal_low_threshold(const CallMatrix &m, double peak, int64_t p
     double opt_threshold = -24;
     int opt = -1;                                                                // index into meas
     std::vector<LowM> meas;
-    RowMaxima rows(m, true);
+    meas.reserve(100);
+    const Rows rows{m};
     int64_t start_frame = valid_peak, max_bin = nb - 1;                          // js:2449, 2453
     auto last_valid = [&]() { for (int i = (int)meas.size() - 1; i >= 0; --i) if (meas[i].found) return i; return -1; };
 
     for (int t = -1; t >= -100; --t) {                                           // js:2461
         const double thr = peak + (double)t;                                     // js:2475
+        const float thr_f = float_below(thr);                                    // entry > thr  <=>  entry > thr_f
         const int ref_i = last_valid();
         const bool has_ref = ref_i >= 0;
         const double ref_khz = has_ref ? meas[ref_i].low_hz / 1000 : 0;          // js:2478-2484
@@ -139,7 +101,7 @@ LowResult find_optimal_low_threshold(const CallMatrix &m, double peak, int64_t p
         int64_t active_end = start_frame;
         int silence = 0;
         for (int64_t f = start_frame; f <= search_end; ++f) {                    // js:2509-2546
-            const int64_t b0 = rows.first_above(f, max_bin, thr);              // the frame's lowest bin above the threshold
+            const int64_t b0 = rows.first_above(f, max_bin, thr_f);            // the frame's lowest bin above the threshold
             const bool has = b0 >= 0;
             const double lowest = has ? fb(b0) : 0;
             if (has) {
@@ -155,7 +117,7 @@ LowResult find_optimal_low_threshold(const CallMatrix &m, double peak, int64_t p
         bool found = false;
         double low_hz = 0, low_power = -INFINITY;
         int64_t found_bin = -1;
-        for (int64_t b = rows.first_above(active_end, max_bin, thr); b >= 0;) {   // js:2560-2612: the first bin above the threshold
+        for (int64_t b = rows.first_above(active_end, max_bin, thr_f); b >= 0;) {   // js:2560-2612: the first bin above the threshold
             double cand = fb(b);
             if (b > 0) {
                 const double p1 = at(active_end, b), p0 = at(active_end, b - 1);
@@ -271,7 +233,8 @@ HighResult find_optimal_high_threshold(const CallMatrix &m, const double *tf, do
     int opt = -1, stable = 0;
     int64_t min_bin = 0;
     std::vector<HighM> meas;
-    RowMaxima rows(m, false);
+    meas.reserve(100);
+    const Rows rows{m};
     auto last_valid = [&]() { for (int i = (int)meas.size() - 1; i >= 0; --i) if (meas[i].found) return i; return -1; };
     // upper edge of one frame above a threshold, interpolated towards the bin above (js:2009-2020, 2340-2349)
     auto edge = [&](int64_t f, int64_t b, double thr) {
@@ -285,6 +248,7 @@ HighResult find_optimal_high_threshold(const CallMatrix &m, const double *tf, do
 
     for (int t = -1; t >= -100; --t) {                                           // js:1965, 1979
         const double thr = peak + (double)t;
+        const float thr_f = float_below(thr);
         const int ref_i = last_valid();
         const bool has_ref = ref_i >= 0;
         const double ref_khz = has_ref ? meas[ref_i].high_hz / 1000 : 0;
@@ -294,10 +258,8 @@ HighResult find_optimal_high_threshold(const CallMatrix &m, const double *tf, do
         int silence = 0;
         for (int64_t f = limit; f >= 0; --f) {                                   // js:2002-2048: from the peak back to the call's start
             bool in_frame = false;
-            // the frame's bins above the threshold from the top down: the highest by search, any further ones (below a
-            // harmonic that is skipped) by walking on
-            for (int64_t b = rows.last_above(f, min_bin, thr); b >= min_bin; --b) {
-                if (!(at(f, b) > thr)) continue;
+            // the frame's bins above the threshold from the top down (further ones only below a harmonic that is skipped)
+            for (int64_t b = rows.last_above(f, min_bin, thr_f); b >= min_bin; b = last_gt(rows.row(f), min_bin, b - 1, thr_f)) {
                 const double cand = edge(f, b, thr);
                 if (has_ref && cand / 1000 - ref_khz > 10.0) continue;           // js:2022-2026: a harmonic, look further down
                 if (!found || cand > high_hz) { high_hz = cand; hbin = b; hframe = f; found = true; }
@@ -448,9 +410,13 @@ void measure_frequency_parameters(const CallMatrix &m, const double *tf, size_t 
     // STEP 0 (js:3004-3045)
     double peak = -INFINITY;
     int64_t pf = 0, pb = 0;
-    for (int64_t f = 0; f < F; ++f)
-        for (int64_t b = 0; b < nb; ++b)
-            if (at(f, b) > peak) { peak = at(f, b); pb = b; pf = f; }
+    for (int64_t f = 0; f < F; ++f) {                                            // the first maximum of the matrix
+        const float *row = m.db + (size_t)f * m.bins;
+        if (!((double)row_max(row, (size_t)nb) > peak)) continue;
+        float v;
+        pb = first_max(row, (size_t)nb, &v);
+        peak = (double)v; pf = f;
+    }
     double peak_hz = fb(pb);
     if (pb > 0 && pb < nb - 1) {
         const double d0 = at(pf, pb - 1), d1 = at(pf, pb), d2 = at(pf, pb + 1), a = (d2 - 2 * d1 + d0) / 2;
@@ -463,9 +429,10 @@ void measure_frequency_parameters(const CallMatrix &m, const double *tf, size_t 
 
     // STEP 0.5 (js:3059-3089)
     {
-        int64_t lo = nb, hi = 0;
-        for (int64_t b = 0; b < nb; ++b)
-            if (at(pf, b) > peak - 12) { if (b < lo) lo = b; if (b > hi) hi = b; }
+        const float *row = m.db + (size_t)pf * m.bins;
+        const float thr = float_below(peak - 12);
+        int64_t lo = first_gt(row, 0, nb - 1, thr), hi = last_gt(row, 0, nb - 1, thr);
+        if (lo < 0) { lo = nb; hi = 0; }
         if (hi >= lo && (double)(hi - lo) * freq_res / 1000 > 20.0) { c.discarded = true; return; }
     }
 
@@ -511,11 +478,8 @@ void measure_frequency_parameters(const CallMatrix &m, const double *tf, size_t 
     // STEP 2.5 (js:3218-3305)
     const double high_thr = peak + used_high;
     int64_t new_start = 0;
-    for (int64_t f = 0; f < F; ++f) {
-        bool any = false;
-        for (int64_t b = 0; b < nb; ++b) if (at(f, b) > high_thr) { any = true; break; }
-        if (any) { new_start = f; break; }
-    }
+    for (int64_t f = 0; f < F; ++f)
+        if (first_gt(m.db + (size_t)f * m.bins, 0, nb - 1, float_below(high_thr)) >= 0) { new_start = f; break; }
     if (new_start < NT) c.start_time_s = tf[new_start];
     double start_hz = high_hz;
     int64_t start_bin = high_bin, start_frame = high_frame;
@@ -614,9 +578,9 @@ void measure_frequency_parameters(const CallMatrix &m, const double *tf, size_t 
         std::vector<double> freq;
         std::vector<int64_t> frame;
         for (int64_t f = last_start > 0 ? last_start : 0; f <= char_end; ++f) {
-            double best = -INFINITY;
-            int64_t bin = 0;
-            for (int64_t b = 0; b < nb; ++b) if (at(f, b) > best) { best = at(f, b); bin = b; }
+            float best;
+            int64_t bin = first_max(m.db + (size_t)f * m.bins, (size_t)nb, &best);
+            if (bin < 0) bin = 0;
             freq.push_back(fb(bin));
             frame.push_back(f);
         }
@@ -648,10 +612,9 @@ void measure_frequency_parameters(const CallMatrix &m, const double *tf, size_t 
     std::vector<int64_t> frames;
     if (search_end - search_start + 1 > 2)
         for (int64_t f = search_start; f <= search_end; ++f) {
-            int64_t best = -1;
-            double power = -INFINITY;
-            for (int64_t b = min_bin; b <= max_bin; ++b) if (at(f, b) > power) { power = at(f, b); best = b; }
-            if (best != -1) { contour.push_back(fb(best) / 1000); frames.push_back(f); }
+            float power;
+            int64_t best = max_bin >= min_bin ? first_max(m.db + (size_t)f * m.bins + min_bin, (size_t)(max_bin - min_bin + 1), &power) : -1;
+            if (best != -1) { best += min_bin; contour.push_back(fb(best) / 1000); frames.push_back(f); }
         }
     if (contour.size() >= 5) {
         const int64_t n = (int64_t)contour.size();
@@ -668,7 +631,10 @@ void measure_frequency_parameters(const CallMatrix &m, const double *tf, size_t 
             d2.push_back((d1[i + 1] - d1[i]) / (dt > 0 ? dt : 0.001));
         }
         const int64_t n1 = (int64_t)d1.size(), n2 = (int64_t)d2.size();
-        auto curvature = [&](int64_t i) { return std::fabs(d2[i]) / (std::pow(1 + d1[i] * d1[i], 1.5) + 1e-10); };
+        // one value per contour point, asked for by the knee search and again by the heel search: worked out once
+        std::vector<double> curv((size_t)n2);
+        for (int64_t i = 0; i < n2; ++i) curv[(size_t)i] = std::fabs(d2[i]) / (std::pow(1 + d1[i] * d1[i], 1.5) + 1e-10);
+        auto curvature = [&](int64_t i) { return curv[(size_t)i]; };
         auto knee_shape = [&](int64_t k) {                                       // js:3671-3694: steep downward sweep that flattens
             if (k <= 0 || k >= n1) return false;
             const double in = d1[k - 1], out = d1[k];

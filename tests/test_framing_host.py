@@ -33,6 +33,43 @@ def test_refine_end_bit_exact(golden):
         fr.refine_end_using_oscillogram(np.zeros(100, np.float32), 8000, 0, 100)       # 0.1 ms window has no hop
 
 
+def test_refine_end_against_the_oracle_on_awkward_spans():
+    """The product sums the 0.1 ms windows several at a time and evaluates the dB only where the walk needs it; the
+    restatement does what the reference does, window after window.  Same answer on: decaying tone bursts, spans whose
+    windows have EXACTLY equal energies (the first of them is the peak), spans below -60 dB, silence, denormals, and
+    samples that are NaN or infinite."""
+    from oracle import framing_oracle as fo
+    sr = 384000
+    rng = np.random.default_rng(11)
+    n = 12000
+    t = np.arange(n) / sr
+    burst = (np.sin(2 * np.pi * 45000 * t) * np.exp(-np.maximum(t - 0.008, 0) * 2500) * (t > 0.004)).astype(np.float32)
+    square = np.where((np.arange(n) // 19) % 2 == 0, 0.5, -0.5).astype(np.float32)             # every window: 38 x 0.25
+    square_then_quiet = square.copy()
+    square_then_quiet[6000:] = 1e-5 * rng.standard_normal(n - 6000).astype(np.float32)
+    quiet = (2e-4 * rng.standard_normal(n)).astype(np.float32)                                   # loudest window below -60 dB
+    quiet_flat = np.full(n, 1e-4, np.float32)                                                    # equal energies, quiet
+    tiny = np.full(n, 1e-30, np.float32)
+    denormal = np.full(n, 1e-42, np.float32)
+    noisy_burst = (0.7 * burst + 1e-3 * rng.standard_normal(n)).astype(np.float32)
+    with_nan = noisy_burst.copy(); with_nan[5000] = np.nan
+    with_inf = noisy_burst.copy(); with_inf[7000] = np.inf
+    two_equal_peaks = np.zeros(n, np.float32); two_equal_peaks[2000:2038] = 0.5; two_equal_peaks[4000:4038] = 0.5
+    signals = {"burst": burst, "square": square, "square_then_quiet": square_then_quiet, "quiet": quiet, "quiet_flat": quiet_flat,
+               "zeros": np.zeros(n, np.float32), "tiny": tiny, "denormal": denormal, "noisy_burst": noisy_burst, "with_nan": with_nan,
+               "with_inf": with_inf, "two_equal_peaks": two_equal_peaks}
+    ranges = [(0, n), (1000, 9000), (1536, 6100), (-50, n + 50), (3000, 3100), (3000, 3300), (1999, 4100), (1981, 4057)]
+    ranges += [(int(a), int(a + b)) for a, b in zip(rng.integers(0, n - 400, 12), rng.integers(200, 9000, 12))]
+    moved = 0
+    for name, x in signals.items():
+        for a, b in ranges:
+            want = fo.refine_end_using_oscillogram(x, sr, a, b)
+            got = fr.refine_end_using_oscillogram(x, sr, a, b)
+            assert got == want, (name, a, b, got, want)
+            moved += want != b
+    assert moved >= 20
+
+
 def test_frame_calls_bit_exact(golden):
     # segments and time stamps from the CPU oracle's spectrogram, framing through the C ABI
     g, meta = golden

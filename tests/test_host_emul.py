@@ -22,7 +22,7 @@ def emul():
     lib = os.path.join(EMUL_DIR, "libemul.so")
     srcs = [os.path.join(EMUL_DIR, f) for f in os.listdir(EMUL_DIR) if f.endswith(".cpp")]
     deps = srcs + [os.path.join(HERE, "..", "spectrogram_amd", "csrc", h)
-                   for h in ("sono_core.h", "sono_tables.h", "sono_tile_core.h")
+                   for h in ("sono_core.h", "sono_tables.h", "sono_tile_core.h", "sono_rowscan.h")
                    if os.path.exists(os.path.join(HERE, "..", "spectrogram_amd", "csrc", h))]
     if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -412,3 +412,63 @@ def test_quantiser_rounding_rule_is_pinned(emul):
     assert q((1.0 * 1024) ** 2) == 255
     top = (10.0 ** (-20.0 / 20.0) * 1024) ** 2
     assert q(top * 1.001) == 255 and q(top * 0.98) == 254
+
+
+def test_row_scans_answer_what_the_scalar_loops_answer(emul):
+    """sono_rowscan.h (four entries per comparison) against the loops of the reference it stands for
+    (batCallDetector.js:2509-2522, 2002-2038, 3004-3020): rows with NaNs, infinities, signed zeros, ties, every length
+    from 0 to 40 and every sub-range, thresholds given as doubles that are not floats."""
+    L = emul
+    L.rowscan_float_below.restype = C.c_float
+    L.rowscan_float_below.argtypes = [C.c_double]
+    L.rowscan_row_max.restype = C.c_float
+    L.rowscan_row_max.argtypes = [C.c_void_p, C.c_ulonglong]
+    for f in (L.rowscan_first_gt, L.rowscan_last_gt):
+        f.restype = C.c_longlong
+        f.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, C.c_float]
+    L.rowscan_first_max.restype = C.c_longlong
+    L.rowscan_first_max.argtypes = [C.c_void_p, C.c_ulonglong, C.c_void_p]
+    rng = np.random.default_rng(5)
+    # the float handed to the scans decides exactly as the double threshold would
+    for thr in list(rng.normal(-60, 30, 200)) + [-57.25, 0.0, -0.0, 1e300, -1e300, float("inf"), float("-inf"), 3.0000001, -3.0000001]:
+        tf = L.rowscan_float_below(thr)
+        with np.errstate(over="ignore"):
+            probe = np.float32(thr)
+        for x in (probe, np.nextafter(probe, np.float32(np.inf)), np.nextafter(probe, np.float32(-np.inf))):
+            assert (float(x) > thr) == (float(x) > tf), (thr, x, tf)
+    assert np.isnan(L.rowscan_float_below(float("nan")))
+    specials = np.asarray([np.nan, np.inf, -np.inf, 0.0, -0.0, -40.0, -40.0, -39.999996], np.float32)
+    checked = 0
+    for trial in range(400):
+        n = int(rng.integers(0, 41))
+        row = np.round(rng.normal(-50, 8, n)).astype(np.float32)                 # rounded: plenty of ties
+        for k in range(int(rng.integers(0, 4))):
+            if n:
+                row[rng.integers(0, n)] = specials[rng.integers(0, len(specials))]
+        if trial % 7 == 0:
+            row[:] = np.nan
+        if trial % 11 == 0:
+            row[:] = -np.inf
+        row = np.ascontiguousarray(row)
+        # first maximum, as "if (v > best) {best = v; at = b}" from best = -inf leaves it
+        best, at = -np.inf, -1
+        for b, v in enumerate(row):
+            if v > best:
+                best, at = v, b
+        val = np.zeros(1, np.float32)
+        got = L.rowscan_first_max(_p(row), n, _p(val))
+        assert got == at and (val[0] == np.float32(best)), (row, got, at)
+        if at >= 0:
+            assert np.signbit(val[0]) == np.signbit(row[at])
+        m = L.rowscan_row_max(_p(row), n)
+        assert m == np.float32(best)
+        for t in (-50.0, -45.5, float(row[n // 2]) if n else 0.0, -np.inf, np.inf, np.nan):
+            t32 = np.float32(t)
+            for lo, hi in [(0, n - 1), (n // 3, n - 1), (0, n // 2), (n // 4, (3 * n) // 4), (2, 1), (n - 1, n - 1)]:
+                if lo < 0 or hi >= n:
+                    continue
+                above = [b for b in range(lo, hi + 1) if row[b] > t32]
+                assert L.rowscan_first_gt(_p(row), lo, hi, t32) == (above[0] if above else -1)
+                assert L.rowscan_last_gt(_p(row), lo, hi, t32) == (above[-1] if above else -1)
+                checked += 1
+    assert checked > 5000
