@@ -92,6 +92,8 @@ uint32_t sono_host_threads(void);
  *   "balance_debug"  (SONO_BALANCE_DEBUG)  print the XCDs' times and the next ranges to stderr
  *   "no_streaming"   (SONO_NO_STREAMING)   long host-pointer calls as one copy each way instead of the chunk pipeline
  *   "bank_two_kernels" (no variable)       filter banks as magnitude matrix + bank kernel even where the fused form exists
+ *   "host_measure"   (SONO_HOST_MEASURE)   sono_process_full_file / sono_measure_roi_calls copy the calls' dB matrices to the
+ *                                          host and measure them on host threads instead of on the GPU
  * None of them changes a result bit (the tests compare the forms).  SONO_EINVAL for an unknown name.
  * Like every call on an engine: not while another thread is inside a call on the same engine. */
 int sono_engine_set_option(sono_engine *e, const char *name, int value);
@@ -573,8 +575,10 @@ int sono_frame_roi_calls(const float *x, const float *x_filtered, size_t n, cons
 
 /* The measurement stage (sono_measure_frequency_parameters) for calls sono_frame_roi_calls returned, all at once:
  * the calls' frames are transformed again from the recording (x, x_filtered as for sono_frame_roi_calls) in one ragged
- * launch -- bit for bit the dB values of the region's own transform -- and the calls are measured on `threads`
- * host threads (0 = up to 16).  out[i] belongs to calls[i]; its times are relative to the call's region, as
+ * launch -- bit for bit the dB values of the region's own transform -- and the calls are measured where those
+ * matrices lie, on the GPU, one wave per call (the same source as sono_measure_frequency_parameters, same numbers);
+ * with the engine option "host_measure", or when a call has more than 4096 frames, the matrices are copied to the
+ * host and measured on `threads` host threads (0 = the process's budget, sono_host_threads).  out[i] belongs to calls[i]; its times are relative to the call's region, as
  * processFullFile has them at that point (batCallDetector.js:786-797; add rois[roi].start / sample_rate for file
  * time, js:822-825).  Table, band and hop must be those of the sono_analyze_rois call. */
 int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filtered, size_t n, const sono_segment *rois, size_t n_rois,

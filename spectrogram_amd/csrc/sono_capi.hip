@@ -205,6 +205,7 @@ int sono_engine_create(uint32_t fft_size, const char *window, int has_alpha, flo
     e->tables.tile.balance.fixed = env_flag("SONO_FIXED_TILES");
     e->tables.tile.balance.debug = env_flag("SONO_BALANCE_DEBUG");
     e->no_streaming = env_flag("SONO_NO_STREAMING");
+    e->host_measure = env_flag("SONO_HOST_MEASURE");
     if (rc == SONO_OK && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
         rc = hip_fail(hipGetLastError(), "hipStreamCreate");
     if (rc == SONO_OK) rc = sono::noalloc_init_device(dev);      // this GPU's fixed scratch of sono_detect_runs_static_dev
@@ -225,6 +226,7 @@ void sono_engine_destroy(sono_engine *e)
     e->d_count.release(); e->d_select_tmp.release();
     e->h_in.release(); e->h_out.release();
     for (auto &slot : e->measure_slot) slot.release();
+    e->d_measure_tables.release(); e->d_measure_scratch.release();
     for (auto &slot : e->upload_slot) slot.release();
     std::free(e->filtered); e->filtered = nullptr; e->filtered_cap = 0;
     for (auto &slot : e->ragged) {
@@ -255,6 +257,7 @@ int sono_engine_set_option(sono_engine *e, const char *name, int value)
     else if (n == "balance_debug") e->tables.tile.balance.debug = on;
     else if (n == "no_streaming") e->no_streaming = on;
     else if (n == "bank_two_kernels") e->bank_two_kernels = on;
+    else if (n == "host_measure") e->host_measure = on;
     else return fail(SONO_EINVAL, "sono_engine_set_option: unknown option '" + n + "'");
     return SONO_OK;
 }
@@ -269,6 +272,7 @@ int sono_engine_get_option(const sono_engine *e, const char *name, int *value)
     else if (n == "balance_debug") *value = e->tables.tile.balance.debug;
     else if (n == "no_streaming") *value = e->no_streaming;
     else if (n == "bank_two_kernels") *value = e->bank_two_kernels;
+    else if (n == "host_measure") *value = e->host_measure;
     else return fail(SONO_EINVAL, "sono_engine_get_option: unknown option '" + n + "'");
     return SONO_OK;
 }
@@ -316,6 +320,7 @@ int sono_engine_release_memory(sono_engine *e)
     e->d_db.release(); e->d_flags.release(); e->d_edges.release(); e->d_runs.release(); e->d_select_tmp.release();
     e->h_in.release(); e->h_out.release(); e->full_file_calls.clear(); e->full_file_calls.shrink_to_fit();
     for (auto &slot : e->measure_slot) slot.release();
+    e->d_measure_tables.release(); e->d_measure_scratch.release();
     for (auto &slot : e->upload_slot) slot.release();
     std::free(e->filtered); e->filtered = nullptr; e->filtered_cap = 0;
     e->frame_tables.clear(); e->frame_tables.shrink_to_fit();

@@ -22,6 +22,7 @@
 #include "sono_engine.h"
 #include "sono_framing.h"
 #include "sono_measure.h"
+#include "sono_measure_dev.h"
 #include "sono_tile.h"
 
 using sono::DeviceGuard;
@@ -31,6 +32,8 @@ namespace {
 
 constexpr size_t kBatchFrames = (size_t)1 << 19;      // frames whose magnitudes are in HBM at one time (1 GiB at fft 1024)
 constexpr size_t kMeasureFrames = (size_t)1 << 17;    // frames whose dB matrices cross to the host at one time
+constexpr size_t kDeviceMeasureFrames = (size_t)1 << 21;   // frames of one batch measured on the GPU (4 GiB of magnitudes at fft 1024)
+constexpr uint64_t kDeviceCallFrames = 4096;          // longest call the GPU measures (0.34 s at 384 kHz and hop 32); longer ones on the host
 
 struct Band { uint32_t hop, noverlap, min_bin, nb; bool ok; };
 
@@ -589,6 +592,28 @@ static int measure_roi_calls(sono_engine *e, const float *x, const float *x_filt
     hipStream_t s = e->stream;
     if (threads == 0) threads = sono::host_threads();
     StageTimer timer("sono_measure_roi_calls");
+    // Where the calls are measured.  On the GPU (sono_measure_dev.hip, one wave per call) the dB matrices stay in HBM
+    // and 280 bytes per call come back; on host threads every matrix crosses the link first -- twice the bytes of
+    // the recording itself for an hour of bat passes -- which is what the stage then waits for.  The host does it when
+    // the caller keeps the matrices anyway, asks for it (engine option "host_measure"), or a call is longer than the
+    // GPU's per-wave work area is laid out for.
+    uint64_t longest = 0;
+    for (size_t c = 0; c < n_calls; ++c) longest = std::max<uint64_t>(longest, calls[c].end_frame - calls[c].start_frame + 1);
+    const bool on_gpu = !keep && !e->host_measure && longest <= kDeviceCallFrames && t->num_zones <= SONO_MAX_ZONES;
+    // a wave per call: batches of tens of thousands of calls keep every wave slot of the GPU busy; towards the host the
+    // batch is what two slots of pinned staging memory hold
+    const size_t batch_frames = on_gpu ? kDeviceMeasureFrames : kMeasureFrames;
+    const float *d_freq = nullptr;
+    const double *d_zonal = nullptr;
+    if (on_gpu) {
+        const size_t fbytes = ((size_t)b.nb * sizeof(float) + 255) / 256 * 256, zbytes = n_rois * SONO_MAX_ZONES * sizeof(double);
+        HIP_TRY(e->d_measure_tables.reserve(fbytes + zbytes));
+        d_freq = (const float *)e->d_measure_tables.p;
+        d_zonal = (const double *)((const char *)e->d_measure_tables.p + fbytes);
+        HIP_TRY(hipMemcpyAsync((void *)d_freq, freq_bins.data(), (size_t)b.nb * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync((void *)d_zonal, t->zonal, zbytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));                    // both sources are the caller's pageable memory
+    }
     // Batches of at most kMeasureFrames frames go through two slots of staging memory: while the host threads measure
     // the calls of one batch, the next one is packed, uploaded, transformed and copied back.
     struct Batch {
@@ -599,13 +624,14 @@ static int measure_roi_calls(sono_engine *e, const float *x, const float *x_filt
         if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
     auto prepare = [&](Batch &bt, size_t c0, sono_engine::MeasureSlot &slot) -> int {
         bt.c0 = bt.c1 = c0; bt.frames = bt.samples = 0;
-        while (bt.c1 < n_calls && (bt.c1 == c0 || bt.frames + slices[bt.c1].count <= kMeasureFrames)) {
+        while (bt.c1 < n_calls && (bt.c1 == c0 || bt.frames + slices[bt.c1].count <= batch_frames)) {
             bt.frames += (size_t)slices[bt.c1].count;
             bt.samples += (size_t)(slices[bt.c1].count - 1) * b.hop + N;
             ++bt.c1;
         }
         const size_t cnt = bt.c1 - c0;
-        if (!slot.h_out.reserve(bt.frames * b.nb * sizeof(float)) || (!d_rec && !slot.h_in.reserve(bt.samples * sizeof(float))))
+        if (!slot.h_out.reserve(on_gpu ? cnt * sizeof(sono_call_measurement) : bt.frames * b.nb * sizeof(float)) ||
+            (!d_rec && !slot.h_in.reserve(bt.samples * sizeof(float))) || (on_gpu && !slot.h_jobs.reserve(cnt * sizeof(sono::MeasureJob))))
             return fail(SONO_ENOMEM, "sono_measure_roi_calls: cannot allocate host staging memory");
         bt.off.resize(cnt); bt.len.resize(cnt); bt.row.resize(cnt);
         size_t pos = 0, rows = 0;
@@ -636,13 +662,44 @@ static int measure_roi_calls(sono_engine *e, const float *x, const float *x_filt
         if (rc) return rc;
         rc = sono_detect_power_db_dev(e, (const float *)e->d_mags.p, bt.frames, bins, b.min_bin, b.nb, (float *)slot.d_db.p, nullptr);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(slot.h_out.p, slot.d_db.p, bt.frames * b.nb * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (!on_gpu) {
+            HIP_TRY(hipMemcpyAsync(slot.h_out.p, slot.d_db.p, bt.frames * b.nb * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(slot.done, s));
+            return SONO_OK;
+        }
+        // the batch's calls, measured where their matrices lie (js:786-797)
+        sono::MeasureJob *jobs = (sono::MeasureJob *)slot.h_jobs.p;
+        unsigned int most = 1;
+        for (size_t i = 0; i < cnt; ++i) {
+            const sono_roi_call &k = calls[c0 + i];
+            const uint64_t F = t->row0[k.roi + 1] - t->row0[k.roi];
+            const uint64_t call_frames = k.end_frame - k.start_frame + 1;
+            jobs[i] = {bt.row[i] + slices[c0 + i].lead, k.start_frame, (unsigned int)call_frames,
+                       (unsigned int)(k.end_frame + 1 < F ? call_frames + 1 : call_frames), (unsigned int)k.roi, 0u, k.duration_ms};
+            most = std::max(most, (unsigned int)call_frames);
+        }
+        const unsigned int waves = sono::measure_waves(cnt, e->tables.tile.cus);
+        const size_t per_wave = sono::measure_scratch_per_wave(most, b.nb);
+        HIP_TRY(slot.d_jobs.reserve(cnt * sizeof(sono::MeasureJob)));
+        HIP_TRY(slot.d_results.reserve(cnt * sizeof(sono_call_measurement)));
+        HIP_TRY(e->d_measure_scratch.reserve((size_t)waves * per_wave));
+        HIP_TRY(hipMemcpyAsync(slot.d_jobs.p, jobs, cnt * sizeof(sono::MeasureJob), hipMemcpyHostToDevice, s));
+        sono::MeasureArgs ma{(const float *)slot.d_db.p, b.nb, d_freq, d_zonal, t->num_zones, SONO_MAX_ZONES,
+                             (const sono::MeasureJob *)slot.d_jobs.p, cnt, (double)b.hop, (double)N / 2, sample_rate, fhigh_khz, res,
+                             (debug_mode & SONO_DEBUG_MODE) != 0, (debug_mode & SONO_TIME_EXPANSION) != 0,
+                             (char *)e->d_measure_scratch.p, per_wave, most, (sono_call_measurement *)slot.d_results.p};
+        HIP_TRY(sono::launch_measure_calls(ma, waves, s));
+        HIP_TRY(hipMemcpyAsync(slot.h_out.p, slot.d_results.p, cnt * sizeof(sono_call_measurement), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(slot.done, s));
         return SONO_OK;
     };
     // measureFrequencyParameters per call (js:786-797), the batch's calls shared out over host threads
     auto measure = [&](const Batch &bt, const float *db) {
         const size_t c0 = bt.c0, cnt = bt.c1 - bt.c0;
+        if (on_gpu) {                                        // what came back is the measurements themselves
+            std::memcpy(out + c0, db, cnt * sizeof(sono_call_measurement));
+            return;
+        }
         std::atomic<size_t> next{0};
         auto work = [&]() {
             std::vector<double> tf;

@@ -163,14 +163,19 @@ struct sono_engine {
     struct MeasureSlot {
         sono::HostBuf h_in, h_out;          // packed samples of the batch's calls; their dB matrices
         sono::DevBuf d_in, d_db;
-        hipEvent_t done = nullptr;          // recorded behind the copy of the dB matrices to h_out
+        sono::HostBuf h_jobs;               // measurement on the GPU: the batch's calls ...
+        sono::DevBuf d_jobs, d_results;     // ... on the device, and what the kernel measured (copied to h_out instead of the dB)
+        hipEvent_t done = nullptr;          // recorded behind the copy of the dB matrices (or of the results) to h_out
         void release()
         {
             h_in.release(); h_out.release(); d_in.release(); d_db.release();
+            h_jobs.release(); d_jobs.release(); d_results.release();
             if (done) { (void)hipEventDestroy(done); done = nullptr; }
         }
     };
     MeasureSlot measure_slot[2];
+    sono::DevBuf d_measure_tables, d_measure_scratch;   // measurement on the GPU: frequency axis + zonal floors; the waves' work areas
+    bool host_measure = false;              // engine option "host_measure": the calls' dB matrices go to the host and are measured there
     // pinned pieces of upload_host_array, each guarded by an event recorded behind its copy to the device
     struct UploadSlot {
         sono::HostBuf buf;

@@ -310,6 +310,76 @@ def test_full_file_in_time_expansion_mode():
     e.free()
 
 
+def _mixed_calls(sr, seconds, seed):
+    """Pulses of many shapes over noise: steep and shallow sweeps, with and without a second harmonic, quiet and loud,
+    short and long, a constant-frequency tone with a sweep at its end -- enough to walk the measurement through its
+    branches (both threshold searches' stops, the safety re-scan, knee and heel, discards)."""
+    rng = np.random.default_rng(seed)
+    x = (0.004 * rng.standard_normal(int(seconds * sr))).astype(np.float32)
+    k = int(0.02 * sr)
+    i = 0
+    while k < len(x) - int(0.06 * sr):
+        n = int(sr * [0.0025, 0.004, 0.008, 0.015, 0.03][i % 5])
+        t = np.arange(n) / sr
+        f0 = [95000, 70000, 52000, 40000, 28000, 84000][i % 6]
+        f1 = f0 * [0.35, 0.5, 0.75, 0.97, 1.0][(i // 2) % 5]
+        u = t / t[-1]
+        phase = 2 * np.pi * (f0 * t + (f1 - f0) * t[-1] * (u ** 1.6) / 1.6)
+        amp = [0.5, 0.12, 0.03, 0.3][i % 4]
+        pulse = amp * np.hanning(n) ** [1.0, 0.3][(i // 3) % 2] * np.sin(phase)
+        if i % 3 == 1:
+            pulse += 0.4 * amp * np.hanning(n) * np.sin(2 * phase)
+        x[k:k + n] += pulse.astype(np.float32)
+        k += n + int(sr * [0.012, 0.05, 0.031, 0.08][i % 4])
+        i += 1
+    return x
+
+
+def test_measurement_on_the_gpu_equals_the_host_stage():
+    """The calls' measurement runs on the GPU where their dB matrices lie (one wave per call, sono_measure_dev.hip); the
+    engine option "host_measure" sends the matrices to the host threads instead.  Both are the same source
+    (sono_measure_core.h): every field of every call, the discards and the reference's TypeError equal bit for bit."""
+    import spectrogram_amd.framing as frm
+    from spectrogram_amd import measure as ms
+    sr = 384000
+    e = sa.SpectrogramEngine(1024, "hann")
+    seen = threw = 0
+    for seed, seconds, band in ((3, 20.0, (10.0, 128.0)), (4, 8.0, (18.0, 100.0))):
+        x = _mixed_calls(sr, seconds, seed)
+        for cfg in ({"debugMode": True}, {"debugMode": True, "timeExpansion": True}, {}):
+            got = []
+            for host in (True, False):
+                e.set_option("host_measure", host)
+                try:
+                    got.append(frm.process_full_file_table(e, x, sr, band[0], band[1], {"threshold_dB": -50.0}, cfg, file_id=2))
+                except ms.ReferenceThrows:
+                    got.append("throws")
+            if isinstance(got[0], str) or isinstance(got[1], str):
+                assert got[0] == got[1] == "throws", cfg
+                threw += 1
+                continue
+            assert got[0].shape == got[1].shape and got[0].shape[0] > 20, got[0].shape
+            assert np.array_equal(got[0].view(np.uint64), got[1].view(np.uint64)), cfg         # NaNs included
+            seen += got[0].shape[0]
+    assert seen > 200, (seen, threw)
+    # the 16-bit entry point takes the same way
+    q = np.clip(np.round(_mixed_calls(sr, 6.0, 9) * 32768), -32768, 32767).astype(np.int16)
+    e.set_option("host_measure", True)
+    host = frm.process_full_file_table(e, q, sr, 10.0, 128.0, {"threshold_dB": -50.0}, {"debugMode": True})
+    e.set_option("host_measure", False)
+    gpu = frm.process_full_file_table(e, q, sr, 10.0, 128.0, {"threshold_dB": -50.0}, {"debugMode": True})
+    assert len(gpu) > 20 and np.array_equal(host.view(np.uint64), gpu.view(np.uint64))
+    # a call longer than the GPU's work area is laid out for is measured on the host, in the same run
+    t = np.arange(int(0.5 * sr)) / sr
+    long_call = (0.003 * np.random.default_rng(1).standard_normal(int(0.8 * sr))).astype(np.float32)
+    long_call[20000:20000 + len(t)] += (0.3 * np.hanning(len(t)) ** 0.2 * np.sin(2 * np.pi * 45000 * t)).astype(np.float32)
+    rows = frm.process_full_file_table(e, long_call, sr, 10.0, 128.0, {"threshold_dB": -50.0}, {"debugMode": True})
+    e.set_option("host_measure", True)
+    assert np.array_equal(rows.view(np.uint64), frm.process_full_file_table(e, long_call, sr, 10.0, 128.0, {"threshold_dB": -50.0},
+                                                                             {"debugMode": True}).view(np.uint64))
+    e.free()
+
+
 def test_rms_based_snr(golden):
     g, meta = golden
     e = sa.SpectrogramEngine(1024, "hann")
