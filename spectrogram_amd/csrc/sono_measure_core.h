@@ -271,6 +271,11 @@ SONO_MC HighResult find_high(const CallMatrix &m, Ops &ops, Work &w, const doubl
             bool in_frame = false;
             // the frame's bins above the threshold from the top down (further ones only below a harmonic that is skipped)
             for (int64_t b = ops.last_gt(row(f), min_bin, nb - 1, thr_f); b >= min_bin; b = ops.last_gt(row(f), min_bin, b - 1, thr_f)) {
+                // A frame whose edge lies a whole bin below the best one so far changes nothing (the frequency axis rises
+                // with the bin index): its candidate is below fb(b + 1) <= fb(hbin) <= high_hz, so it neither is the new
+                // maximum nor -- being lower than a candidate that was no harmonic -- a harmonic.  Its edge (two more
+                // entries of the matrix and a division) is not worked out.
+                if (found && b + 1 <= hbin) { in_frame = true; break; }
                 const double cand = edge(f, b, thr);
                 if (has_ref && cand / 1000 - ref_khz > 10.0) continue;           // js:2022-2026: a harmonic, look further down
                 if (!found || cand > high_hz) { high_hz = cand; hbin = b; hframe = f; found = true; }

@@ -19,63 +19,85 @@ namespace sono {
 namespace {
 
 constexpr int kWavesPerBlock = 4;
+#ifndef SONO_MEASURE_WAVES_PER_SIMD
+#define SONO_MEASURE_WAVES_PER_SIMD 4      // 128 registers a lane: a few spill, and twice the calls in flight pays for them
+#endif
 
+// The scans load UNCONDITIONALLY (the index is clamped into the range and the entry discarded afterwards where it
+// lay outside): a load under a branch of its own is waited for before the next one is issued, and four chunks of a row
+// are fetched together so that their trips to memory overlap.  Indices are 32-bit inside (a row has at most 65 535
+// entries): 64-bit integer arithmetic costs the vector unit several instructions per operation.
 struct WaveOps {
     unsigned int lane;
-    // Four chunks of 64 entries are loaded before the first of them is looked at: the loads overlap, and a 316-bin row
-    // is answered after at most two round trips to memory instead of five.
-    __device__ int64_t first_gt(const float *p, int64_t lo, int64_t hi, float t) const
+    __device__ int64_t first_gt(const float *p, int64_t lo64, int64_t hi64, float t) const
     {
-        for (int64_t base = lo; base <= hi; base += 256) {
-            float v[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { const int64_t i = base + 64 * c + lane; v[c] = i <= hi ? p[i] : -INFINITY; }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const unsigned long long mask = __ballot(v[c] > t);
-                if (mask) return base + 64 * c + (int64_t)__builtin_ctzll(mask);
-            }
+        const int lo = (int)lo64, hi = (int)hi64, l = (int)lane;
+        for (int base = lo; base <= hi; base += 256) {
+            const int i0 = base + l, i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192;
+            const float v0 = p[i0 < hi ? i0 : hi], v1 = p[i1 < hi ? i1 : hi], v2 = p[i2 < hi ? i2 : hi], v3 = p[i3 < hi ? i3 : hi];
+            unsigned long long mask = __ballot(i0 <= hi && v0 > t);
+            if (mask) return base + __builtin_ctzll(mask);
+            mask = __ballot(i1 <= hi && v1 > t);
+            if (mask) return base + 64 + __builtin_ctzll(mask);
+            mask = __ballot(i2 <= hi && v2 > t);
+            if (mask) return base + 128 + __builtin_ctzll(mask);
+            mask = __ballot(i3 <= hi && v3 > t);
+            if (mask) return base + 192 + __builtin_ctzll(mask);
         }
         return -1;
     }
-    __device__ int64_t last_gt(const float *p, int64_t lo, int64_t hi, float t) const
+    __device__ int64_t last_gt(const float *p, int64_t lo64, int64_t hi64, float t) const
     {
-        for (int64_t base = hi; base >= lo; base -= 256) {
-            float v[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { const int64_t i = base - 64 * c - lane; v[c] = i >= lo ? p[i] : -INFINITY; }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const unsigned long long mask = __ballot(v[c] > t);
-                if (mask) return base - 64 * c - (int64_t)__builtin_ctzll(mask);
-            }
+        const int lo = (int)lo64, hi = (int)hi64, l = (int)lane;
+        for (int base = hi; base >= lo; base -= 256) {
+            const int i0 = base - l, i1 = i0 - 64, i2 = i0 - 128, i3 = i0 - 192;
+            const float v0 = p[i0 > lo ? i0 : lo], v1 = p[i1 > lo ? i1 : lo], v2 = p[i2 > lo ? i2 : lo], v3 = p[i3 > lo ? i3 : lo];
+            unsigned long long mask = __ballot(i0 >= lo && v0 > t);
+            if (mask) return base - __builtin_ctzll(mask);
+            mask = __ballot(i1 >= lo && v1 > t);
+            if (mask) return base - 64 - __builtin_ctzll(mask);
+            mask = __ballot(i2 >= lo && v2 > t);
+            if (mask) return base - 128 - __builtin_ctzll(mask);
+            mask = __ballot(i3 >= lo && v3 > t);
+            if (mask) return base - 192 - __builtin_ctzll(mask);
         }
         return -1;
     }
-    __device__ float row_max(const float *p, size_t n) const
+    __device__ float row_max(const float *p, size_t n64) const
     {
+        const int n = (int)n64, l = (int)lane;
         float m = -INFINITY;
-        for (size_t i = lane; i < n; i += 64) { const float v = p[i]; if (v > m) m = v; }      // a NaN is never above
+        for (int base = 0; base < n; base += 256) {
+            const int i0 = base + l, i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192, last = n - 1;
+            const float v0 = p[i0 < last ? i0 : last], v1 = p[i1 < last ? i1 : last], v2 = p[i2 < last ? i2 : last],
+                        v3 = p[i3 < last ? i3 : last];                 // a repeated last entry changes no maximum
+            if (v0 > m) m = v0;                                        // a NaN is never above
+            if (v1 > m) m = v1;
+            if (v2 > m) m = v2;
+            if (v3 > m) m = v3;
+        }
         for (int o = 32; o >= 1; o >>= 1) { const float v = __shfl_xor(m, o); if (v > m) m = v; }
         return m;
     }
-    __device__ int64_t first_max(const float *p, size_t n, float *value) const
+    __device__ int64_t first_max(const float *p, size_t n64, float *value) const
     {
-        const float m = row_max(p, n);
+        const float m = row_max(p, n64);
         *value = -INFINITY;
         if (!(m > -INFINITY)) return -1;
-        for (size_t base = 0; base < n; base += 256) {
-            float v[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { const size_t i = base + 64 * c + lane; v[c] = i < n ? p[i] : -INFINITY; }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const unsigned long long mask = __ballot(v[c] == m);         // m is above -INFINITY here
-                if (mask) {
-                    const int64_t at = (int64_t)base + 64 * c + (int64_t)__builtin_ctzll(mask);
-                    *value = p[at];                          // the entry met first (a -0 before a +0 stays a -0)
-                    return at;
-                }
+        const int n = (int)n64, l = (int)lane, last = n - 1;
+        for (int base = 0; base < n; base += 256) {
+            const int i0 = base + l, i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192;
+            const float v0 = p[i0 < last ? i0 : last], v1 = p[i1 < last ? i1 : last], v2 = p[i2 < last ? i2 : last],
+                        v3 = p[i3 < last ? i3 : last];
+            int at = -1;
+            unsigned long long mask = __ballot(i0 <= last && v0 == m);
+            if (mask) at = base + __builtin_ctzll(mask);
+            else if ((mask = __ballot(i1 <= last && v1 == m))) at = base + 64 + __builtin_ctzll(mask);
+            else if ((mask = __ballot(i2 <= last && v2 == m))) at = base + 128 + __builtin_ctzll(mask);
+            else if ((mask = __ballot(i3 <= last && v3 == m))) at = base + 192 + __builtin_ctzll(mask);
+            if (at >= 0) {
+                *value = p[at];                              // the entry met first (a -0 before a +0 stays a -0)
+                return at;
             }
         }
         return -1;                                           // not reached: m is one of the entries
@@ -100,7 +122,7 @@ struct WaveOps {
     }
 };
 
-__global__ __launch_bounds__(64 * kWavesPerBlock, 4) void measure_calls_kernel(MeasureArgs a)
+__global__ __launch_bounds__(64 * kWavesPerBlock, SONO_MEASURE_WAVES_PER_SIMD) void measure_calls_kernel(MeasureArgs a)
 {
     __shared__ mcore::LowM s_low[kWavesPerBlock][mcore::kThresholds];
     __shared__ mcore::HighM s_high[kWavesPerBlock][mcore::kThresholds];

@@ -150,3 +150,40 @@ def test_fused_band_energy_equals_the_two_pass_form(N, lo, hi):
     with pytest.raises(sa.SonoError):
         e.stft_band_active_dev(dx.data_ptr(), S, stride, per, V, lo, B, target, act[1].data_ptr(), 0, 0)
     e.free()
+
+
+def test_db_matrix_is_the_library_logarithm_rounded_to_f32():
+    """dB = f32(10 * log10(max(mag^2 / N, 1e-16))) with the logarithm in double (batCallDetector.js:1353-1360).  The
+    kernel takes a short way to the logarithm and falls back to the long one wherever the f32 could differ: against
+    numpy's double logarithm the f32 is the same everywhere, except where that double lies within 1e-12 dB of a rounding
+    boundary of f32 (then either neighbour is what a double logarithm, a unit in the last place off, may give)."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(21)
+    F, bins, min_bin, nb = 4096, 512, 27, 316
+    mags = np.exp(rng.uniform(-45, 12, (F, bins))).astype(np.float32)
+    mags[0, :] = 0.0
+    mags[1, :] = np.float32(1e-42)                                           # denormal
+    mags[2, 30:40] = np.nan
+    mags[3, 30:40] = np.inf
+    mags[4, :] = np.float32(32.0) * (1 + rng.uniform(-3e-6, 3e-6, bins)).astype(np.float32)        # psd next to 1: 0 dB
+    mags[5, :] = np.float32(3.2e-7) * (1 + rng.uniform(-1e-3, 1e-3, bins)).astype(np.float32)      # psd next to the 1e-16 floor
+    mags[6, :] = np.ldexp(np.float32(1.0), rng.integers(-60, 20, bins)).astype(np.float32)         # exact powers of two
+    e = sa.SpectrogramEngine(1024, "hann")
+    d_m = torch.from_numpy(mags).cuda()
+    d_db = torch.empty((F, nb), dtype=torch.float32, device="cuda")
+    rc = sa.lib().sono_detect_power_db_dev(e._handle(), C.c_void_p(d_m.data_ptr()), F, bins, min_bin, nb, C.c_void_p(d_db.data_ptr()), None)
+    assert rc == 0
+    e.synchronize()
+    got = d_db.cpu().numpy()
+    m = mags[:, min_bin:min_bin + nb].astype(np.float64)
+    psd = (m * m) / 1024.0
+    psd = np.where(psd > 1e-16, psd, 1e-16)
+    with np.errstate(divide="ignore"):
+        y = 10.0 * np.log10(psd)
+    want = y.astype(np.float32)
+    differ = got.view(np.uint32) != want.view(np.uint32)
+    ambiguous = (y - 1e-12).astype(np.float32) != (y + 1e-12).astype(np.float32)
+    assert not (differ & ~ambiguous).any(), np.argwhere(differ & ~ambiguous)[:5]
+    assert differ.sum() <= 4 and (got[2, 3:13] == -160.0).all() and np.isinf(got[3, 3:13]).all() and (got[0] == -160.0).all()
+    e.free()
