@@ -30,7 +30,7 @@ using sono::fail;
 
 namespace {
 
-constexpr size_t kBatchFrames = (size_t)1 << 19;      // frames whose magnitudes are in HBM at one time (1 GiB at fft 1024)
+constexpr size_t kBatchFrames = (size_t)1 << 21;      // frames whose magnitudes are in HBM at one time (4 GiB at fft 1024)
 constexpr size_t kMeasureFrames = (size_t)1 << 17;    // frames whose dB matrices cross to the host at one time
 constexpr size_t kDeviceMeasureFrames = (size_t)1 << 21;   // frames of one batch measured on the GPU (4 GiB of magnitudes at fft 1024)
 constexpr uint64_t kDeviceCallFrames = 4096;          // longest call the GPU measures (0.34 s at 384 kHz and hop 32); longer ones on the host
@@ -107,13 +107,18 @@ struct HostSamples {
     const float *x = nullptr;
     const int16_t *q = nullptr;
     uint32_t channels = 1, channel = 0;
+    // The high-passed regions as the GPU packed them, one after the other (sono_process_full_file): region r's samples
+    // start at packed[packed_at[r]] where packed_at[r] >= 0.  Takes the place of an x_filtered laid out like the recording.
+    const float *packed = nullptr;
+    const int64_t *packed_at = nullptr;
 };
 // -> sample 0 of region r as floats: the high-passed copy where the region went through the filter, the caller's
 // floats, or the region's 16-bit samples converted into `tmp` (exact: a division by a power of two).
 const float *region_samples(const HostSamples &hs, const float *x_filtered, const sono_segment *rois, const sono_roi_table *t,
                             size_t r, double sample_rate, std::vector<float> &tmp)
 {
-    const float *src = region_audio(hs.x, x_filtered, t, r, sample_rate);
+    if (hs.packed && hs.packed_at[r] >= 0) return hs.packed + hs.packed_at[r];
+    const float *src = region_audio(hs.x, hs.packed ? nullptr : x_filtered, t, r, sample_rate);
     if (src) return src + rois[r].start;
     const size_t len = (size_t)(rois[r].end - rois[r].start);
     tmp.resize(len);
@@ -199,8 +204,12 @@ int sono_roi_rows(const sono_segment *rois, size_t n_rois, uint32_t fft_size, do
 // afterwards gets what region_audio() would pick on the host.
 static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segment *rois, size_t n_rois, double sample_rate,
                         double flow_khz, double fhigh_khz, double hop_percent, int auto_highpass, sono_roi_table *out,
-                        size_t frames_cap, float *x_filtered, float *d_rec)
+                        size_t frames_cap, float *x_filtered, float *d_rec, std::vector<int64_t> *packed_at = nullptr)
 {
+    // packed_at (with d_rec): the filtered samples come back as ONE copy into the engine's pinned h_filtered, packed
+    // region after region as the filter kernel wrote them, and packed_at[r] says where region r's begin (-1: not
+    // filtered) -- nothing is scattered to the samples' places in a recording-sized host array.
+    if (packed_at) packed_at->assign(n_rois, -1);
     if (!e || !out || (n && !x && !d_rec) || (n_rois && !rois)) return fail(SONO_EINVAL, "sono_analyze_rois: NULL argument");
     if (!(sample_rate > 0)) return fail(SONO_EINVAL, "sono_analyze_rois: sample_rate must be positive");
     if (n_rois && (!out->row0 || !out->zonal || !out->highpass_khz))
@@ -361,7 +370,31 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
     int copy_status = SONO_OK;
     hipStream_t down = nullptr;
     hipEvent_t filtered = nullptr;
-    if (x_filtered) {
+    if (packed_at) {
+        for (size_t k = 0; k < jobs.size(); ++k) (*packed_at)[job_region[k]] = (int64_t)jobs[k].dst;
+        if (!e->h_filtered.reserve(filtered_samples * sizeof(float)))
+            return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
+        HIP_TRY(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&filtered, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(filtered, s));
+        HIP_TRY(hipStreamWaitEvent(down, filtered, 0));
+        // In pieces, each queued when the one before it has arrived: the second pass's own small copies to the host
+        // share the copy engine and would otherwise wait behind the whole of it.
+        const int device = e->device;
+        copier = std::thread([&, device]() {
+            if (hipSetDevice(device) != hipSuccess) { copy_status = SONO_EDEVICE; return; }
+            const size_t piece = (size_t)8 << 20;                // samples
+            for (size_t at = 0; at < filtered_samples; at += piece) {
+                const size_t count = std::min(piece, filtered_samples - at);
+                if (hipMemcpyAsync((float *)e->h_filtered.p + at, (const float *)e->d_runs.p + at, count * sizeof(float),
+                                   hipMemcpyDeviceToHost, down) != hipSuccess || hipStreamSynchronize(down) != hipSuccess) {
+                    (void)hipGetLastError();
+                    copy_status = SONO_EDEVICE;
+                    return;
+                }
+            }
+        });
+    } else if (x_filtered) {
         HIP_TRY(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&filtered, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(filtered, s));
@@ -833,31 +866,27 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
     std::vector<float> hp(n_rois + 1);
     std::vector<double> zonal((n_rois + 1) * SONO_MAX_ZONES);
     sono_roi_table t{row0.data(), peak_db, peak_bin, left, right, ilo, ihi, zonal.data(), hp.data(), 0, 0, 0, 0};
-    // The samples of the regions that get the automatic high-pass land here, at their places in the recording; nothing
-    // else of it is ever read (region_audio), so it needs no clearing, and the engine keeps it from call to call: the
-    // first touch of a fresh page costs more than the copy into it.
-    if (e->filtered_cap < n) {
-        std::free(e->filtered);
-        e->filtered = (float *)std::malloc((n ? n : 1) * sizeof(float));
-        e->filtered_cap = e->filtered ? n : 0;
-    }
-    float *xf = e->filtered;
-    if (!xf) return fail(SONO_ENOMEM, "sono_process_full_file: cannot allocate the filtered recording");
+    // The samples of the regions that went through the automatic high-pass come back packed (HostSamples::packed): the
+    // framing stage reads a region's samples from there, and nothing the size of the recording is kept on the host.
+    std::vector<int64_t> packed_at;
     lap("merge, tables");
-    rc = analyze_rois(e, x, n, rois.data(), n_rois, sample_rate, flow_khz, fhigh_khz, opt->hop_percent, 1, &t, total, xf, d_rec);
+    rc = analyze_rois(e, x, n, rois.data(), n_rois, sample_rate, flow_khz, fhigh_khz, opt->hop_percent, 1, &t, total, nullptr, d_rec, &packed_at);
     if (rc) return rc;
     lap("region analysis (GPU)");
     // framing (js:677-794), measurement (js:797) and what follows it (js:802-827)
     std::vector<sono_roi_call> framed;       // sized by the framing: a bound from the frame count would be hundreds of MB of fresh pages
     size_t n_calls = 0;
-    rc = frame_roi_calls(hs, xf, n, rois.data(), n_rois, &t, sample_rate, N, opt->call_threshold_db,
+    HostSamples framed_from = hs;
+    framed_from.packed = (const float *)e->h_filtered.p;
+    framed_from.packed_at = packed_at.data();
+    rc = frame_roi_calls(framed_from, nullptr, n, rois.data(), n_rois, &t, sample_rate, N, opt->call_threshold_db,
                          opt->min_call_duration_ms, nullptr, 0, &n_calls, &framed);
     if (rc) return rc;
     lap("framing (host)");
     std::vector<sono_call_measurement> meas(n_calls + 1);
     const bool keep_slices = (opt->debug_mode & SONO_KEEP_CALL_SPECTROGRAMS) != 0;
     std::vector<sono::FullFileSlice> slices(keep_slices ? n_calls : 0);
-    rc = measure_roi_calls(e, x, xf, n, rois.data(), n_rois, &t, framed.data(), n_calls, sample_rate, flow_khz, fhigh_khz,
+    rc = measure_roi_calls(e, x, nullptr, n, rois.data(), n_rois, &t, framed.data(), n_calls, sample_rate, flow_khz, fhigh_khz,
                            opt->hop_percent, opt->debug_mode, opt->threads, meas.data(), keep_slices ? &slices : nullptr, d_rec);
     if (rc) return rc;
     e->full_file_axes = {t.hop, t.min_bin, t.num_bins, sample_rate};

@@ -154,8 +154,7 @@ struct sono_engine {
     // device scratch of the detector front end (sono_capi_detect.hip)
     sono::DevBuf d_db, d_flags, d_edges, d_runs, d_count, d_select_tmp;
     sono::DevBuf d_rec;                     // sono_process_full_file: the whole recording, resident from the fast scan on
-    float *filtered = nullptr;              // ... and the host copy of its high-passed regions (pageable, kept, never cleared)
-    size_t filtered_cap = 0;                // in samples
+    sono::HostBuf h_filtered;               // ... and the host copy of its high-passed regions, packed region after region (pinned, kept)
     std::vector<uint32_t> frame_tables;     // ... and the per-frame records of its regions (six 4-byte arrays)
     std::vector<sono_segment> scan_segments;   // ... and the fast scan's segments (one per half frame at most)
     sono::HostBuf h_in, h_out;              // staging of the whole-file passes (packed samples; records / dB matrices)
