@@ -135,19 +135,27 @@ int peaks_pass(sono_engine *e, const float *d_src, const std::vector<uint64_t> &
 {
     const uint32_t N = e->N, bins = N / 2;
     HIP_TRY(e->d_mags.reserve(frames * bins * sizeof(float)));
-    HIP_TRY(e->d_db.reserve(frames * b.nb * sizeof(float)));
     HIP_TRY(e->d_out.reserve(frames * sizeof(sono::FramePeak)));
     sono_ragged_batch rb{d_src, off.size(), off.data(), len.data()};
     int rc = sono_stft_mag_f32_ragged_dev(e, &rb, b.noverlap, (float *)e->d_mags.p, nullptr);
     if (rc) return rc;
-    rc = sono_detect_power_db_dev(e, (const float *)e->d_mags.p, frames, bins, b.min_bin, b.nb, (float *)e->d_db.p, nullptr);
-    if (rc) return rc;
-    HIP_TRY(sono::launch_frame_peaks((const float *)e->d_db.p, frames, b.nb, (sono::FramePeak *)e->d_out.p, e->stream));
+    if (sono::db_peaks_fits(b.nb)) {
+        // nobody reads the dB matrix of a region but the peak records (and the noise floors, which convert their six
+        // frames per region themselves): it is never written
+        HIP_TRY(sono::launch_db_peaks((const float *)e->d_mags.p, frames, bins, b.min_bin, b.nb, N, (sono::FramePeak *)e->d_out.p, e->stream));
+    } else {
+        HIP_TRY(e->d_db.reserve(frames * b.nb * sizeof(float)));
+        rc = sono_detect_power_db_dev(e, (const float *)e->d_mags.p, frames, bins, b.min_bin, b.nb, (float *)e->d_db.p, nullptr);
+        if (rc) return rc;
+        HIP_TRY(sono::launch_frame_peaks((const float *)e->d_db.p, frames, b.nb, (sono::FramePeak *)e->d_out.p, e->stream));
+    }
     if (!e->h_out.reserve((frames ? frames : 1) * sizeof(sono::FramePeak)))
         return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
     const sono::FramePeak *feat = (const sono::FramePeak *)e->h_out.p;
     HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, frames * sizeof(sono::FramePeak), hipMemcpyDeviceToHost, e->stream));
+    StageTimer timer("peaks_pass");
     HIP_TRY(hipStreamSynchronize(e->stream));
+    timer.lap("wait for kernels and copy");
     // records -> the table's six arrays, the regions shared out over host threads
     std::vector<size_t> first(off.size() + 1, 0);
     for (size_t i = 0; i < off.size(); ++i) {
@@ -175,6 +183,7 @@ int peaks_pass(sono_engine *e, const float *d_src, const std::vector<uint64_t> &
     for (unsigned int w = 1; w < threads; ++w) pool.emplace_back(work);
     work();
     for (std::thread &th : pool) th.join();
+    timer.lap("records to tables");
     return SONO_OK;
 }
 
@@ -328,8 +337,12 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
             HIP_TRY(hipMemcpyAsync(d_fr, fr.data(), tb, hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemcpyAsync(d_used, used.data(), ub, hipMemcpyHostToDevice, s));
             HIP_TRY(hipMemcpyAsync(d_zone, zone_of_bin.data(), b.nb, hipMemcpyHostToDevice, s));
-            HIP_TRY(sono::launch_zone_floors_regions((const float *)e->d_db.p, d_fr, d_used, cnt, b.nb, d_zone, (uint32_t)zones,
-                                                     SONO_MAX_ZONES, d_floors, s));
+            if (sono::db_peaks_fits(b.nb))
+                HIP_TRY(sono::launch_zone_floors_regions_mags((const float *)e->d_mags.p, N / 2, b.min_bin, N, d_fr, d_used, cnt, b.nb,
+                                                              d_zone, (uint32_t)zones, SONO_MAX_ZONES, d_floors, s));
+            else
+                HIP_TRY(sono::launch_zone_floors_regions((const float *)e->d_db.p, d_fr, d_used, cnt, b.nb, d_zone, (uint32_t)zones,
+                                                         SONO_MAX_ZONES, d_floors, s));
             HIP_TRY(hipMemcpyAsync(out->zonal + r0 * SONO_MAX_ZONES, d_floors, fb, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             timer.lap("zonal floors");

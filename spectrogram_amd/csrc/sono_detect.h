@@ -39,6 +39,11 @@ hipError_t launch_frame_features(const float *d_db, size_t frames, uint32_t nb, 
 // vertical-click filter (batCallDetector.js:3059-3088).
 struct FramePeak { int32_t bin; float db, left, right; int32_t lo12, hi12; };
 hipError_t launch_frame_peaks(const float *d_db, size_t frames, uint32_t nb, FramePeak *d_out, hipStream_t s);
+// launch_power_db + launch_frame_peaks in one pass over the magnitudes, the dB values staying in registers, for bands
+// of up to 512 bins (db_peaks_fits): the same records.
+bool db_peaks_fits(uint32_t nb);
+hipError_t launch_db_peaks(const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin, uint32_t nb, uint32_t fft_size,
+                           FramePeak *d_out, hipStream_t s);
 
 // First / last frame of every maximal run of non-zero flags, as two flag arrays.
 hipError_t launch_run_edges(const uint8_t *d_active, size_t frames, uint8_t *d_is_start, uint8_t *d_is_end,
@@ -63,6 +68,11 @@ hipError_t launch_zone_floors_regions(const float *d_db, const unsigned long lon
                                       const unsigned int *d_rows_used, size_t regions, uint32_t nb,
                                       const uint8_t *d_zone_of_bin, uint32_t num_zones, uint32_t zone_stride,
                                       double *d_floors, hipStream_t s);
+// ... from the magnitude matrix (rows of `bins` entries, the band starting at min_bin), every value converted on the way in
+hipError_t launch_zone_floors_regions_mags(const float *d_mags, uint32_t bins, uint32_t min_bin, uint32_t fft_size,
+                                           const unsigned long long *d_first_row, const unsigned int *d_rows_used, size_t regions,
+                                           uint32_t nb, const uint8_t *d_zone_of_bin, uint32_t num_zones, uint32_t zone_stride,
+                                           double *d_floors, hipStream_t s);
 
 // Butterworth high-pass of many regions at once, one lane per region
 // (applyHighpassFilter at its default order 4 = two identical second-order sections,

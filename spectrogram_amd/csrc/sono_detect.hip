@@ -95,34 +95,47 @@ const DbTable &db_table()
     return t;
 }
 
-__global__ __launch_bounds__(kThreads) void power_db_kernel(const float *mags, size_t frames, uint32_t bins,
-                                                            uint32_t min_bin, uint32_t nb, double fft_size, double scale, DbTable table,
-                                                            float *db)
+// How a magnitude becomes a dB value: the transform's size, 1 / size where that is exact (else 0: divide), the table.
+struct DbLaw { double fft_size, scale; DbTable table; };
+DbLaw db_law(uint32_t fft_size)
 {
-    __shared__ double s_inv_c[64], s_log10_c[64];
+    return DbLaw{(double)fft_size, (fft_size & (fft_size - 1)) == 0 ? 1.0 / (double)fft_size : 0.0, db_table()};
+}
+// The table in LDS, for every thread of the workgroup (call once, by all threads, before db_of_mag).
+__device__ __forceinline__ void stage_db_table(const DbTable &table, double *s_inv_c, double *s_log10_c)
+{
     if (threadIdx.x < 64) { s_inv_c[threadIdx.x] = table.inv_c[threadIdx.x]; s_log10_c[threadIdx.x] = table.log10_c[threadIdx.x]; }
     __syncthreads();
+}
+__device__ __forceinline__ float db_of_mag(float mag, double fft_size, double scale, const double *s_inv_c, const double *s_log10_c)
+{
+    const double m = (double)mag;
+    double psd = scale != 0.0 ? (m * m) * scale : (m * m) / fft_size;
+    psd = psd > 1e-16 ? psd : 1e-16;                                             // a NaN ends here as well
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(psd);
+    const int e = (int)((bits >> 52) & 0x7ffu);
+    if (e != 0x7ff) {                                                            // finite (and normal: at least 1e-16)
+        const int i = (int)((bits >> 46) & 63u);
+        const double mant = __longlong_as_double((long long)((bits & 0xFFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
+        const double r = fma(mant, s_inv_c[i], -1.0);
+        double p = 1.0 / 7;
+        p = fma(p, r, -1.0 / 6); p = fma(p, r, 1.0 / 5); p = fma(p, r, -1.0 / 4); p = fma(p, r, 1.0 / 3);
+        p = fma(p, r, -0.5); p = fma(p, r, 1.0);
+        p *= r;                                                                  // log1p(r)
+        const double y = 10.0 * ((double)(e - 1023) * 0.30102999566398119521 + (s_log10_c[i] + p * 0.43429448190325182765));
+        const float lo = (float)(y - 1e-12), hi = (float)(y + 1e-12);
+        if (lo == hi) return lo;
+    }
+    return (float)(10.0 * log10(psd));
+}
+
+__global__ __launch_bounds__(kThreads) void power_db_kernel(const float *mags, size_t frames, uint32_t bins,
+                                                            uint32_t min_bin, uint32_t nb, DbLaw law, float *db)
+{
+    __shared__ double s_inv_c[64], s_log10_c[64];
+    stage_db_table(law.table, s_inv_c, s_log10_c);
     const int lane = threadIdx.x & 63;
-    auto to_db = [&](float mag) {
-        const double m = (double)mag;
-        double psd = scale != 0.0 ? (m * m) * scale : (m * m) / fft_size;          // scale = 1 / N where that is exact
-        psd = psd > 1e-16 ? psd : 1e-16;                                         // a NaN ends here as well
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(psd);
-        const int e = (int)((bits >> 52) & 0x7ffu);
-        if (e != 0x7ff) {                                                        // finite (and normal: at least 1e-16)
-            const int i = (int)((bits >> 46) & 63u);
-            const double mant = __longlong_as_double((long long)((bits & 0xFFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
-            const double r = fma(mant, s_inv_c[i], -1.0);
-            double p = 1.0 / 7;
-            p = fma(p, r, -1.0 / 6); p = fma(p, r, 1.0 / 5); p = fma(p, r, -1.0 / 4); p = fma(p, r, 1.0 / 3);
-            p = fma(p, r, -0.5); p = fma(p, r, 1.0);
-            p *= r;                                                              // log1p(r)
-            const double y = 10.0 * ((double)(e - 1023) * 0.30102999566398119521 + (s_log10_c[i] + p * 0.43429448190325182765));
-            const float lo = (float)(y - 1e-12), hi = (float)(y + 1e-12);
-            if (lo == hi) return lo;
-        }
-        return (float)(10.0 * log10(psd));
-    };
+    auto to_db = [&](float mag) { return db_of_mag(mag, law.fft_size, law.scale, s_inv_c, s_log10_c); };
     for_each_row(frames, [&](size_t f) {
         const float *src = mags + f * bins + min_bin;
         float *dst = db + f * nb;
@@ -276,6 +289,59 @@ __global__ __launch_bounds__(kThreads) void frame_peaks_kernel(const float *db, 
             r.db = best;
             r.left = best_bin > 0 ? row[best_bin - 1] : NAN;
             r.right = best_bin >= 0 && (uint32_t)best_bin + 1 < nb ? row[best_bin + 1] : NAN;
+            out[f] = r;
+        }
+    });
+}
+
+// frame_peaks_kernel on the dB values of a magnitude row that never leave the registers: power_db_kernel and
+// frame_peaks_kernel in one pass for rows of up to 64 * kRowRegs bins, when nobody else needs the dB matrix (the region
+// analysis: 2.5 KB of traffic per frame less).  Same values, same record.
+__global__ __launch_bounds__(kThreads) void db_peaks_kernel(const float *mags, size_t frames, uint32_t bins, uint32_t min_bin,
+                                                            uint32_t nb, DbLaw law, FramePeak *out)
+{
+    __shared__ double s_inv_c[64], s_log10_c[64];
+    stage_db_table(law.table, s_inv_c, s_log10_c);
+    const int lane = threadIdx.x & 63;
+    auto to_db = [&](float mag) { return db_of_mag(mag, law.fft_size, law.scale, s_inv_c, s_log10_c); };
+    for_each_row(frames, [&](size_t f) {
+        const float *src = mags + f * bins + min_bin;
+        float v[kRowRegs];
+        load_row(src, nb, lane, 0.0f, v);
+#pragma unroll
+        for (int k = 0; k < kRowRegs; ++k) v[k] = (uint32_t)lane + 64u * k < nb ? to_db(v[k]) : NAN;
+        float best = -INFINITY;
+        int best_bin = -1;
+#pragma unroll
+        for (int k = 0; k < kRowRegs; ++k)
+            if (v[k] > best) { best = v[k]; best_bin = lane + 64 * k; }         // strict >, b ascends: the lane's first maximum; NaN (the fill) never wins
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int ob = __shfl_xor(best_bin, o, 64);
+            const bool take = ob >= 0 && (best_bin < 0 || ov > best || (ov == best && ob < best_bin));
+            if (take) { best = ov; best_bin = ob; }
+        }
+        const double thr = (double)best - 12;                                    // js:3061-3073
+        int lo = 0x7FFFFFFF, hi = -1;
+#pragma unroll
+        for (int k = 0; k < kRowRegs; ++k)
+            if ((double)v[k] > thr) { const int b = lane + 64 * k; if (b < lo) lo = b; hi = b; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int ol = __shfl_xor(lo, o, 64), oh = __shfl_xor(hi, o, 64);
+            lo = ol < lo ? ol : lo;
+            hi = oh > hi ? oh : hi;
+        }
+        // the peak's neighbours: converted again by all lanes (the same magnitudes, hence the same dB values)
+        const float left = best_bin > 0 ? to_db(src[best_bin - 1]) : NAN;
+        const float right = best_bin >= 0 && (uint32_t)best_bin + 1 < nb ? to_db(src[best_bin + 1]) : NAN;
+        if (lane == 0) {
+            FramePeak r;
+            r.lo12 = lo == 0x7FFFFFFF ? -1 : lo;
+            r.hi12 = hi;
+            r.bin = best_bin;
+            r.db = best;
+            r.left = left;
+            r.right = right;
             out[f] = r;
         }
     });
@@ -450,21 +516,29 @@ __global__ __launch_bounds__(kThreads) void band_linear_sum_kernel(const float *
     if (threadIdx.x == 0 && a != 0.0) atomicAdd(&sums[1], a);
 }
 
+// FROM_MAGS: `db` is the magnitude matrix (rows of `bins` entries, the band starting at min_bin) and every value is
+// converted on the way in; else the dB matrix itself (rows of nb entries).
+template <bool FROM_MAGS>
 __global__ __launch_bounds__(kThreads) void zone_floors_regions_kernel(const float *db, const unsigned long long *first_row,
                                                                        const unsigned int *rows_used, uint32_t nb,
                                                                        const uint8_t *zone_of_bin, uint32_t num_zones,
-                                                                       uint32_t zone_stride, double *floors)
+                                                                       uint32_t zone_stride, double *floors, uint32_t bins,
+                                                                       uint32_t min_bin, DbLaw law)
 {
     extern __shared__ unsigned int s_hist[];
+    __shared__ double s_inv_c[64], s_log10_c[64];
+    if constexpr (FROM_MAGS) stage_db_table(law.table, s_inv_c, s_log10_c);
     const size_t r = blockIdx.x;
     const uint32_t cells = num_zones * (uint32_t)kZoneHistBins;
     for (uint32_t i = threadIdx.x; i < cells; i += kThreads) s_hist[i] = 0u;
     __syncthreads();
-    const float *base = db + first_row[r] * nb;
+    const float *base = db + first_row[r] * (FROM_MAGS ? bins : nb);
     const size_t count = (size_t)rows_used[r] * nb;
     for (size_t i = threadIdx.x; i < count; i += kThreads) {
         const uint32_t zone = zone_of_bin[i % nb];
-        float v = base[i];
+        float v;
+        if constexpr (FROM_MAGS) v = db_of_mag(base[(i / nb) * bins + min_bin + i % nb], law.fft_size, law.scale, s_inv_c, s_log10_c);
+        else v = base[i];
         if (zone >= num_zones || v != v) continue;
         v = v < -100.0f ? -100.0f : v;                              // js:1857
         float fl = floorf(v);                                       // js:1867
@@ -527,8 +601,20 @@ hipError_t launch_zone_floors_regions(const float *d_db, const unsigned long lon
 {
     if (regions == 0 || num_zones == 0) return hipSuccess;
     const size_t lds = (size_t)num_zones * kZoneHistBins * sizeof(unsigned int);
-    hipLaunchKernelGGL(zone_floors_regions_kernel, dim3((unsigned int)regions), dim3(kThreads), lds, s, d_db, d_first_row,
-                       d_rows_used, nb, d_zone_of_bin, num_zones, zone_stride, d_floors);
+    hipLaunchKernelGGL(zone_floors_regions_kernel<false>, dim3((unsigned int)regions), dim3(kThreads), lds, s, d_db, d_first_row,
+                       d_rows_used, nb, d_zone_of_bin, num_zones, zone_stride, d_floors, nb, 0u, DbLaw{});
+    return hipGetLastError();
+}
+
+hipError_t launch_zone_floors_regions_mags(const float *d_mags, uint32_t bins, uint32_t min_bin, uint32_t fft_size,
+                                           const unsigned long long *d_first_row, const unsigned int *d_rows_used, size_t regions,
+                                           uint32_t nb, const uint8_t *d_zone_of_bin, uint32_t num_zones, uint32_t zone_stride,
+                                           double *d_floors, hipStream_t s)
+{
+    if (regions == 0 || num_zones == 0) return hipSuccess;
+    const size_t lds = (size_t)num_zones * kZoneHistBins * sizeof(unsigned int);
+    hipLaunchKernelGGL(zone_floors_regions_kernel<true>, dim3((unsigned int)regions), dim3(kThreads), lds, s, d_mags, d_first_row,
+                       d_rows_used, nb, d_zone_of_bin, num_zones, zone_stride, d_floors, bins, min_bin, db_law(fft_size));
     return hipGetLastError();
 }
 
@@ -607,8 +693,7 @@ hipError_t launch_power_db(const float *d_mags, size_t frames, uint32_t bins, ui
     const size_t count = frames * (size_t)nb;
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(power_db_kernel, dim3(rows_grid_capped(frames)), dim3(kThreads), 0, s,
-                       d_mags, frames, bins, min_bin, nb, (double)fft_size,
-                       (fft_size & (fft_size - 1)) == 0 ? 1.0 / (double)fft_size : 0.0, db_table(), d_db);
+                       d_mags, frames, bins, min_bin, nb, db_law(fft_size), d_db);
     return hipGetLastError();
 }
 
@@ -644,6 +729,17 @@ hipError_t launch_frame_peaks(const float *d_db, size_t frames, uint32_t nb, Fra
 {
     if (frames == 0) return hipSuccess;
     hipLaunchKernelGGL(frame_peaks_kernel, dim3(rows_grid_capped(frames)), dim3(kThreads), 0, s, d_db, frames, nb, d_out);
+    return hipGetLastError();
+}
+
+bool db_peaks_fits(uint32_t nb) { return nb <= 64u * kRowRegs; }
+
+hipError_t launch_db_peaks(const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin, uint32_t nb, uint32_t fft_size,
+                           FramePeak *d_out, hipStream_t s)
+{
+    if (frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(db_peaks_kernel, dim3(rows_grid_capped(frames)), dim3(kThreads), 0, s, d_mags, frames, bins, min_bin, nb,
+                       db_law(fft_size), d_out);
     return hipGetLastError();
 }
 
