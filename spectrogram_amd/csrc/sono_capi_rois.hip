@@ -127,11 +127,11 @@ const float *region_samples(const HostSamples &hs, const float *x_filtered, cons
     return tmp.data();
 }
 
-// One pass over a set of regions whose samples sit at d_src + off[i]: magnitudes -> dB crop -> per-frame peak.
-// feat_rows[i] = where region i's records go in the host arrays.
-int peaks_pass(sono_engine *e, const float *d_src, const std::vector<uint64_t> &off, const std::vector<uint64_t> &len,
-               const std::vector<uint64_t> &feat_rows, const Band &b, size_t frames, const sono_roi_table *t,
-               std::vector<uint64_t> *first_row_out)
+// One pass over a set of regions whose samples sit at d_src + off[i]: magnitudes -> dB crop -> per-frame peak, in two
+// halves so that the next batch can be on the GPU while the host files this one's records.
+// peaks_enqueue: the launches and the copy of the records into `records` (pinned), nothing waited for.
+int peaks_enqueue(sono_engine *e, const float *d_src, const std::vector<uint64_t> &off, const std::vector<uint64_t> &len,
+                  const Band &b, size_t frames, sono::HostBuf &records)
 {
     const uint32_t N = e->N, bins = N / 2;
     HIP_TRY(e->d_mags.reserve(frames * bins * sizeof(float)));
@@ -149,24 +149,26 @@ int peaks_pass(sono_engine *e, const float *d_src, const std::vector<uint64_t> &
         if (rc) return rc;
         HIP_TRY(sono::launch_frame_peaks((const float *)e->d_db.p, frames, b.nb, (sono::FramePeak *)e->d_out.p, e->stream));
     }
-    if (!e->h_out.reserve((frames ? frames : 1) * sizeof(sono::FramePeak)))
+    if (!records.reserve((frames ? frames : 1) * sizeof(sono::FramePeak)))
         return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
-    const sono::FramePeak *feat = (const sono::FramePeak *)e->h_out.p;
-    HIP_TRY(hipMemcpyAsync(e->h_out.p, e->d_out.p, frames * sizeof(sono::FramePeak), hipMemcpyDeviceToHost, e->stream));
-    StageTimer timer("peaks_pass");
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    timer.lap("wait for kernels and copy");
-    // records -> the table's six arrays, the regions shared out over host threads
-    std::vector<size_t> first(off.size() + 1, 0);
-    for (size_t i = 0; i < off.size(); ++i) {
-        first[i + 1] = first[i] + sono_frames_for((size_t)len[i], N, b.noverlap);
-        if (first_row_out) (*first_row_out)[i] = first[i];
-    }
+    HIP_TRY(hipMemcpyAsync(records.p, e->d_out.p, frames * sizeof(sono::FramePeak), hipMemcpyDeviceToHost, e->stream));
+    return SONO_OK;
+}
+
+// peaks_collect: the records (arrived: the caller has waited) -> the table's six arrays, the regions shared out over
+// host threads.  feat_rows[i] = where region i's records go in the host arrays.
+void peaks_collect(sono_engine *e, const std::vector<uint64_t> &len, const std::vector<uint64_t> &feat_rows, const Band &b,
+                   size_t frames, const sono_roi_table *t, const sono::HostBuf &records)
+{
+    const uint32_t N = e->N;
+    const sono::FramePeak *feat = (const sono::FramePeak *)records.p;
+    std::vector<size_t> first(len.size() + 1, 0);
+    for (size_t i = 0; i < len.size(); ++i) first[i + 1] = first[i] + sono_frames_for((size_t)len[i], N, b.noverlap);
     std::atomic<size_t> next{0};
     const size_t step = 64;                                  // regions per grab
     auto work = [&]() {
-        for (size_t i0 = next.fetch_add(step); i0 < off.size(); i0 = next.fetch_add(step))
-            for (size_t i = i0; i < std::min(i0 + step, off.size()); ++i) {
+        for (size_t i0 = next.fetch_add(step); i0 < len.size(); i0 = next.fetch_add(step))
+            for (size_t i = i0; i < std::min(i0 + step, len.size()); ++i) {
                 const size_t row = first[i], F = first[i + 1] - first[i];
                 for (size_t f = 0; f < F; ++f) {
                     t->peak_db[feat_rows[i] + f] = feat[row + f].db;
@@ -183,8 +185,6 @@ int peaks_pass(sono_engine *e, const float *d_src, const std::vector<uint64_t> &
     for (unsigned int w = 1; w < threads; ++w) pool.emplace_back(work);
     work();
     for (std::thread &th : pool) th.join();
-    timer.lap("records to tables");
-    return SONO_OK;
 }
 
 }  // namespace
@@ -278,94 +278,123 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
     std::vector<sono::HighpassJob> jobs;                     // every region that gets the high-pass
     std::vector<size_t> job_region;
     size_t filtered_samples = 0;
-    size_t r0 = 0;
-    while (r0 < n_rois) {
-        // ---- first pass, one batch: regions r0 .. r1-1 -------------------------------------------
-        size_t r1 = r0, frames = 0, samples = 0;
-        while (r1 < n_rois && (r1 == r0 || frames + (out->row0[r1 + 1] - out->row0[r1]) <= kBatchFrames)) {
-            frames += (size_t)(out->row0[r1 + 1] - out->row0[r1]);
-            samples += (size_t)(rois[r1].end - rois[r1].start);
-            ++r1;
+    // Two batches are in flight: while the GPU works on one, the host files the records of the one before and decides
+    // about its regions' high-pass.  (Without the resident recording a batch's samples are packed and uploaded first,
+    // through one staging area, and the batches follow each other.)
+    struct PeakBatch {
+        size_t r0 = 0, r1 = 0, frames = 0, samples = 0;
+        std::vector<uint64_t> off, len, rows;
+        std::vector<unsigned long long> first_row;           // of each region in the batch's matrices
+        std::vector<unsigned int> used;                      // frames of each region that count for its noise floors (js:622-627)
+    };
+    std::vector<PeakBatch> plan;
+    for (size_t r0 = 0; r0 < n_rois;) {
+        PeakBatch pb;
+        pb.r0 = pb.r1 = r0;
+        while (pb.r1 < n_rois && (pb.r1 == r0 || pb.frames + (out->row0[pb.r1 + 1] - out->row0[pb.r1]) <= kBatchFrames)) {
+            pb.frames += (size_t)(out->row0[pb.r1 + 1] - out->row0[pb.r1]);
+            pb.samples += (size_t)(rois[pb.r1].end - rois[pb.r1].start);
+            ++pb.r1;
         }
-        const size_t cnt = r1 - r0;
-        std::vector<uint64_t> off(cnt), len(cnt), rows(cnt), first_row(cnt);
+        const size_t cnt = pb.r1 - r0;
+        pb.off.resize(cnt); pb.len.resize(cnt); pb.rows.resize(cnt); pb.first_row.resize(cnt); pb.used.resize(cnt);
         for (size_t i = 0; i < cnt; ++i) {
             const sono_segment &g = rois[r0 + i];
-            off[i] = src_off[r0 + i]; len[i] = g.end - g.start; rows[i] = out->row0[r0 + i];
+            const size_t F = (size_t)(out->row0[r0 + i + 1] - out->row0[r0 + i]);
+            pb.off[i] = src_off[r0 + i]; pb.len[i] = g.end - g.start; pb.rows[i] = out->row0[r0 + i];
+            pb.first_row[i] = out->row0[r0 + i] - out->row0[r0];
+            pb.used[i] = (unsigned int)(F < 6 ? F : 6);
         }
+        r0 = pb.r1;
+        plan.push_back(std::move(pb));
+    }
+    for (sono_engine::MeasureSlot &slot : e->measure_slot)          // the measurement stage's slots are free until it starts
+        if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    auto enqueue = [&](size_t k) -> int {
+        PeakBatch &pb = plan[k];
+        sono_engine::MeasureSlot &slot = e->measure_slot[k & 1];
+        const size_t cnt = pb.r1 - pb.r0;
         if (!d_rec) {
             // pack the batch's samples and upload them in one copy
-            if (!e->h_in.reserve((samples ? samples : 1) * sizeof(float)))
+            if (!e->h_in.reserve((pb.samples ? pb.samples : 1) * sizeof(float)))
                 return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
             float *packed = (float *)e->h_in.p;
             size_t pos = 0;
             std::vector<CopyJob> copies(cnt);
             for (size_t i = 0; i < cnt; ++i) {
-                copies[i] = {packed + pos, x + rois[r0 + i].start, (size_t)len[i] * sizeof(float)};
-                pos += (size_t)len[i];
+                copies[i] = {packed + pos, x + rois[pb.r0 + i].start, (size_t)pb.len[i] * sizeof(float)};
+                pos += (size_t)pb.len[i];
             }
             parallel_copy(copies);
-            timer.lap("pack samples");
-            HIP_TRY(hipMemcpyAsync(d_all + src_off[r0], packed, samples * sizeof(float), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(d_all + src_off[pb.r0], packed, pb.samples * sizeof(float), hipMemcpyHostToDevice, s));
         }
-        if (frames == 0) {
-            HIP_TRY(hipStreamSynchronize(s));                // the staging area is reused by the next batch
-            for (size_t r = r0; r < r1; ++r) for (size_t z = 0; z < SONO_MAX_ZONES; ++z) out->zonal[r * SONO_MAX_ZONES + z] = -102.0;
-            r0 = r1;
-            continue;
-        }
-        rc = peaks_pass(e, d_all, off, len, rows, b, frames, out, &first_row);
+        if (pb.frames == 0) return SONO_OK;
+        int rc = peaks_enqueue(e, d_all, pb.off, pb.len, b, pb.frames, slot.h_out);
         if (rc) return rc;
-        timer.lap("upload, STFT, dB, peaks");
         // ---- noise floors of every region's first six frames (js:622-627), from the unfiltered spectrogram ----
-        {
-            std::vector<unsigned long long> fr(cnt);
-            std::vector<unsigned int> used(cnt);
-            for (size_t i = 0; i < cnt; ++i) {
-                const size_t F = (size_t)(out->row0[r0 + i + 1] - out->row0[r0 + i]);
-                fr[i] = first_row[i];
-                used[i] = (unsigned int)(F < 6 ? F : 6);
-            }
-            const size_t tb = cnt * sizeof(unsigned long long), ub = cnt * sizeof(unsigned int);
-            const size_t fb = cnt * SONO_MAX_ZONES * sizeof(double);
-            HIP_TRY(e->d_edges.reserve(tb + ub + b.nb + 8 + fb));
-            char *base = (char *)e->d_edges.p;
-            double *d_floors = (double *)base;
-            unsigned long long *d_fr = (unsigned long long *)(base + fb);
-            unsigned int *d_used = (unsigned int *)(base + fb + tb);
-            uint8_t *d_zone = (uint8_t *)(base + fb + tb + ub);
-            HIP_TRY(hipMemcpyAsync(d_fr, fr.data(), tb, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipMemcpyAsync(d_used, used.data(), ub, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipMemcpyAsync(d_zone, zone_of_bin.data(), b.nb, hipMemcpyHostToDevice, s));
-            if (sono::db_peaks_fits(b.nb))
-                HIP_TRY(sono::launch_zone_floors_regions_mags((const float *)e->d_mags.p, N / 2, b.min_bin, N, d_fr, d_used, cnt, b.nb,
-                                                              d_zone, (uint32_t)zones, SONO_MAX_ZONES, d_floors, s));
-            else
-                HIP_TRY(sono::launch_zone_floors_regions((const float *)e->d_db.p, d_fr, d_used, cnt, b.nb, d_zone, (uint32_t)zones,
-                                                         SONO_MAX_ZONES, d_floors, s));
-            HIP_TRY(hipMemcpyAsync(out->zonal + r0 * SONO_MAX_ZONES, d_floors, fb, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            timer.lap("zonal floors");
+        const size_t tb = cnt * sizeof(unsigned long long), ub = cnt * sizeof(unsigned int);
+        const size_t fb = cnt * SONO_MAX_ZONES * sizeof(double);
+        HIP_TRY(e->d_edges.reserve(tb + ub + b.nb + 8 + fb));
+        if (!slot.h_jobs.reserve(fb)) return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
+        char *base = (char *)e->d_edges.p;
+        double *d_floors = (double *)base;
+        unsigned long long *d_fr = (unsigned long long *)(base + fb);
+        unsigned int *d_used = (unsigned int *)(base + fb + tb);
+        uint8_t *d_zone = (uint8_t *)(base + fb + tb + ub);
+        HIP_TRY(hipMemcpyAsync(d_fr, pb.first_row.data(), tb, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_used, pb.used.data(), ub, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_zone, zone_of_bin.data(), b.nb, hipMemcpyHostToDevice, s));
+        if (sono::db_peaks_fits(b.nb))
+            HIP_TRY(sono::launch_zone_floors_regions_mags((const float *)e->d_mags.p, N / 2, b.min_bin, N, d_fr, d_used, cnt, b.nb,
+                                                          d_zone, (uint32_t)zones, SONO_MAX_ZONES, d_floors, s));
+        else
+            HIP_TRY(sono::launch_zone_floors_regions((const float *)e->d_db.p, d_fr, d_used, cnt, b.nb, d_zone, (uint32_t)zones,
+                                                     SONO_MAX_ZONES, d_floors, s));
+        HIP_TRY(hipMemcpyAsync(slot.h_jobs.p, d_floors, fb, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(slot.done, s));
+        return SONO_OK;
+    };
+    auto collect = [&](size_t k) -> int {
+        PeakBatch &pb = plan[k];
+        sono_engine::MeasureSlot &slot = e->measure_slot[k & 1];
+        const size_t cnt = pb.r1 - pb.r0;
+        if (pb.frames == 0) {
+            HIP_TRY(hipStreamSynchronize(s));                // the staging area is reused by the next batch
+            for (size_t r = pb.r0; r < pb.r1; ++r) for (size_t z = 0; z < SONO_MAX_ZONES; ++z) out->zonal[r * SONO_MAX_ZONES + z] = -102.0;
+            return SONO_OK;
         }
+        HIP_TRY(hipEventSynchronize(slot.done));
+        timer.lap("wait for STFT, dB, peaks, noise floors");
+        peaks_collect(e, pb.len, pb.rows, b, pb.frames, out, slot.h_out);
+        std::memcpy(out->zonal + pb.r0 * SONO_MAX_ZONES, slot.h_jobs.p, cnt * SONO_MAX_ZONES * sizeof(double));
         // ---- automatic high-pass (js:631-671): regions whose loudest bin lies at 30 kHz or above ----
         for (size_t i = 0; auto_highpass && i < cnt; ++i) {
-            const size_t F = (size_t)(out->row0[r0 + i + 1] - out->row0[r0 + i]);
+            const size_t F = (size_t)(out->row0[pb.r0 + i + 1] - out->row0[pb.r0 + i]);
             if (F == 0) continue;
             float best = -INFINITY;
             int32_t bin = 0;
             for (size_t f = 0; f < F; ++f)                                         // first maximum in frame order (js:635-644)
-                if (out->peak_db[rows[i] + f] > best) { best = out->peak_db[rows[i] + f]; bin = out->peak_bin[rows[i] + f]; }
+                if (out->peak_db[pb.rows[i] + f] > best) { best = out->peak_db[pb.rows[i] + f]; bin = out->peak_bin[pb.rows[i] + f]; }
             if (bin < 0) bin = 0;
             const double cutoff = sono::host_auto_highpass_khz((double)freq_bins[bin] / 1000);          // js:646-647
-            out->highpass_khz[r0 + i] = (float)cutoff;
+            out->highpass_khz[pb.r0 + i] = (float)cutoff;
             if (!(cutoff > 0)) continue;
             const int c = cutoff == 20.0 ? 0 : cutoff == 25.0 ? 1 : 2;
             if (!corner_ok[c]) continue;
-            jobs.push_back({off[i], filtered_samples, len[i], (unsigned int)c, 0u});
-            job_region.push_back(r0 + i);
-            filtered_samples += (size_t)len[i];
+            jobs.push_back({pb.off[i], filtered_samples, pb.len[i], (unsigned int)c, 0u});
+            job_region.push_back(pb.r0 + i);
+            filtered_samples += (size_t)pb.len[i];
         }
-        r0 = r1;
+        timer.lap("records to tables, high-pass choice");
+        return SONO_OK;
+    };
+    const bool overlap = d_rec != nullptr;
+    if (overlap && !plan.empty()) { rc = enqueue(0); if (rc) { (void)hipStreamSynchronize(s); return rc; } }
+    for (size_t k = 0; k < plan.size(); ++k) {
+        if (!overlap) rc = enqueue(k);
+        else rc = k + 1 < plan.size() ? enqueue(k + 1) : SONO_OK;
+        if (rc == SONO_OK) rc = collect(k);
+        if (rc) { (void)hipStreamSynchronize(s); return rc; }
     }
     if (jobs.empty()) return SONO_OK;
     // ---- the high-pass of all regions that need it, one launch; the filtered samples packed job after job ----
@@ -437,22 +466,36 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
             }
         });
     }
-    // ---- second pass over the filtered regions, in batches ----
-    size_t k0 = 0;
-    rc = SONO_OK;
-    while (k0 < jobs.size() && rc == SONO_OK) {
-        size_t k1 = k0, frames2 = 0;
-        std::vector<uint64_t> off2, len2, rows2;
+    // ---- second pass over the filtered regions, in batches, two in flight like the first ----
+    struct FilteredBatch { std::vector<uint64_t> off, len, rows; size_t frames = 0; };
+    std::vector<FilteredBatch> plan2;
+    for (size_t k0 = 0; k0 < jobs.size();) {
+        FilteredBatch fbatch;
+        size_t k1 = k0;
         while (k1 < jobs.size()) {
             const size_t r = job_region[k1], F = (size_t)(out->row0[r + 1] - out->row0[r]);
-            if (k1 > k0 && frames2 + F > kBatchFrames) break;
-            off2.push_back(jobs[k1].dst); len2.push_back(jobs[k1].len); rows2.push_back(out->row0[r]);
-            frames2 += F;
+            if (k1 > k0 && fbatch.frames + F > kBatchFrames) break;
+            fbatch.off.push_back(jobs[k1].dst); fbatch.len.push_back(jobs[k1].len); fbatch.rows.push_back(out->row0[r]);
+            fbatch.frames += F;
             ++k1;
         }
-        rc = peaks_pass(e, (const float *)e->d_runs.p, off2, len2, rows2, b, frames2, out, nullptr);
         k0 = k1;
+        plan2.push_back(std::move(fbatch));
     }
+    auto enqueue2 = [&](size_t k) -> int {
+        sono_engine::MeasureSlot &slot = e->measure_slot[k & 1];
+        int rc2 = peaks_enqueue(e, (const float *)e->d_runs.p, plan2[k].off, plan2[k].len, b, plan2[k].frames, slot.h_out);
+        if (rc2) return rc2;
+        HIP_TRY(hipEventRecord(slot.done, s));
+        return SONO_OK;
+    };
+    rc = plan2.empty() ? SONO_OK : enqueue2(0);
+    for (size_t k = 0; k < plan2.size() && rc == SONO_OK; ++k) {
+        if (k + 1 < plan2.size()) rc = enqueue2(k + 1);
+        if (rc == SONO_OK && hipEventSynchronize(e->measure_slot[k & 1].done) != hipSuccess) rc = sono::hip_fail(hipGetLastError(), "hipEventSynchronize");
+        if (rc == SONO_OK) peaks_collect(e, plan2[k].len, plan2[k].rows, b, plan2[k].frames, out, e->measure_slot[k & 1].h_out);
+    }
+    if (rc) (void)hipStreamSynchronize(s);
     timer.lap("second pass");
     if (copier.joinable()) copier.join();
     if (filtered) (void)hipEventDestroy(filtered);
