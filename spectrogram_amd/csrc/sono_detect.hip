@@ -309,7 +309,10 @@ __global__ __launch_bounds__(kThreads) void db_peaks_kernel(const float *mags, s
         float v[kRowRegs];
         load_row(src, nb, lane, 0.0f, v);
 #pragma unroll
-        for (int k = 0; k < kRowRegs; ++k) v[k] = (uint32_t)lane + 64u * k < nb ? to_db(v[k]) : NAN;
+        for (int k = 0; k < kRowRegs; ++k) {
+            if (64u * k < nb) v[k] = to_db(v[k]);                                // a chunk of 64 bins that the band reaches: all lanes or none
+            if ((uint32_t)lane + 64u * k >= nb) v[k] = NAN;
+        }
         float best = -INFINITY;
         int best_bin = -1;
 #pragma unroll
@@ -331,9 +334,18 @@ __global__ __launch_bounds__(kThreads) void db_peaks_kernel(const float *mags, s
             lo = ol < lo ? ol : lo;
             hi = oh > hi ? oh : hi;
         }
-        // the peak's neighbours: converted again by all lanes (the same magnitudes, hence the same dB values)
-        const float left = best_bin > 0 ? to_db(src[best_bin - 1]) : NAN;
-        const float right = best_bin >= 0 && (uint32_t)best_bin + 1 < nb ? to_db(src[best_bin + 1]) : NAN;
+        // the peak's neighbours, from the lanes that hold them
+        auto value_at = [&](int bin) {
+            float r = NAN;
+#pragma unroll
+            for (int k = 0; k < kRowRegs; ++k) {
+                const float held = __shfl(v[k], bin & 63, 64);
+                if ((bin >> 6) == k) r = held;
+            }
+            return r;
+        };
+        const float left = best_bin > 0 ? value_at(best_bin - 1) : NAN;
+        const float right = best_bin >= 0 && (uint32_t)best_bin + 1 < nb ? value_at(best_bin + 1) : NAN;
         if (lane == 0) {
             FramePeak r;
             r.lo12 = lo == 0x7FFFFFFF ? -1 : lo;

@@ -10,7 +10,7 @@ python -m spectrogram_amd.build --asan > /tmp/sono_asan_build.log 2>&1 || { tail
 RT="$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)"
 # the emulation library: same sources the tests build with g++, here with clang and the sanitizers
 /opt/rocm/lib/llvm/bin/clang++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -fsanitize=address -fsanitize=undefined -shared-libsan \
-    -fno-omit-frame-pointer -o tests/host_emul/libemul_asan.so tests/host_emul/emul_generic.cpp tests/host_emul/emul_tile.cpp
+    -fno-omit-frame-pointer -o tests/host_emul/libemul_asan.so tests/host_emul/emul_generic.cpp tests/host_emul/emul_tile.cpp tests/host_emul/rowscan_check.cpp
 export SONO_LIB_PATH="$ROOT/spectrogram_amd/lib/libsonostft_asan.so" SONO_EMUL_LIB="$ROOT/tests/host_emul/libemul_asan.so"
 export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1
 LD_PRELOAD="$RT${LD_PRELOAD:+:$LD_PRELOAD}" python -m pytest -x -q tests/test_measure_host.py tests/test_framing_host.py tests/test_host_emul.py \
