@@ -1,8 +1,11 @@
 // The row scans of the measurement stage (spectrogram_amd/csrc/sono_rowscan.h) behind plain C functions, so that the
 // CPU suite can put them beside the scalar loops they stand for.
+#include "../../spectrogram_amd/csrc/sono_measure_core.h"
 #include "../../spectrogram_amd/csrc/sono_rowscan.h"
 
 extern "C" {
+
+double measure_pow15(double x) { return sono::mcore::pow15(x); }
 
 float rowscan_float_below(double thr) { return sono::float_below(thr); }
 long long rowscan_first_gt(const float *p, long long lo, long long hi, float t) { return sono::first_gt(p, lo, hi, t); }
