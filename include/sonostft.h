@@ -94,6 +94,11 @@ uint32_t sono_host_threads(void);
  *   "bank_two_kernels" (no variable)       filter banks as magnitude matrix + bank kernel even where the fused form exists
  *   "host_measure"   (SONO_HOST_MEASURE)   sono_process_full_file / sono_measure_roi_calls copy the calls' dB matrices to the
  *                                          host and measure them on host threads instead of on the GPU
+ *   "no_upload_overlap" (SONO_NO_UPLOAD_OVERLAP) sono_process_full_file uploads the whole recording before it scans and
+ *                                          analyses it, instead of working on the pieces that have arrived while the next
+ *                                          ones cross the link
+ *   "small_upload_pieces" (no variable)    those pieces are 64 fft sizes long instead of 2^26 samples (tests: many pieces
+ *                                          and several groups of regions from a few seconds of audio)
  * None of them changes a result bit (the tests compare the forms).  SONO_EINVAL for an unknown name.
  * Like every call on an engine: not while another thread is inside a call on the same engine. */
 int sono_engine_set_option(sono_engine *e, const char *name, int value);

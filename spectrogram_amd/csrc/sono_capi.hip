@@ -206,6 +206,7 @@ int sono_engine_create(uint32_t fft_size, const char *window, int has_alpha, flo
     e->tables.tile.balance.debug = env_flag("SONO_BALANCE_DEBUG");
     e->no_streaming = env_flag("SONO_NO_STREAMING");
     e->host_measure = env_flag("SONO_HOST_MEASURE");
+    e->no_upload_overlap = env_flag("SONO_NO_UPLOAD_OVERLAP");
     if (rc == SONO_OK && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
         rc = hip_fail(hipGetLastError(), "hipStreamCreate");
     if (rc == SONO_OK) rc = sono::noalloc_init_device(dev);      // this GPU's fixed scratch of sono_detect_runs_static_dev
@@ -258,6 +259,8 @@ int sono_engine_set_option(sono_engine *e, const char *name, int value)
     else if (n == "no_streaming") e->no_streaming = on;
     else if (n == "bank_two_kernels") e->bank_two_kernels = on;
     else if (n == "host_measure") e->host_measure = on;
+    else if (n == "no_upload_overlap") e->no_upload_overlap = on;
+    else if (n == "small_upload_pieces") e->small_upload_pieces = on;
     else return fail(SONO_EINVAL, "sono_engine_set_option: unknown option '" + n + "'");
     return SONO_OK;
 }
@@ -273,6 +276,8 @@ int sono_engine_get_option(const sono_engine *e, const char *name, int *value)
     else if (n == "no_streaming") *value = e->no_streaming;
     else if (n == "bank_two_kernels") *value = e->bank_two_kernels;
     else if (n == "host_measure") *value = e->host_measure;
+    else if (n == "no_upload_overlap") *value = e->no_upload_overlap;
+    else if (n == "small_upload_pieces") *value = e->small_upload_pieces;
     else return fail(SONO_EINVAL, "sono_engine_get_option: unknown option '" + n + "'");
     return SONO_OK;
 }

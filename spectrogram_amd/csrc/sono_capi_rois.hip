@@ -857,62 +857,24 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filter
                              debug_mode, threads, out, nullptr, nullptr);
 }
 
-static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
-                             const sono_full_file_options *opt, sono_full_file_call *out, size_t cap, size_t *count)
+// What processFullFile does with regions once it has them (batCallDetector.js:609-827): analysis, call framing,
+// measurement, follow-up.  The regions are rois[0 .. n_rois) of a recording that lies in HBM at d_rec (at least up to
+// the last region's end); a kept call names its region as roi_base + its index here.  Appends to the engine's call list;
+// calls_seen counts the framed calls of the recording so far (the reference's TypeError is reported by that number).
+struct StageTimes { double analysis = 0, framing = 0, measurement = 0; };
+static int process_regions(sono_engine *e, const HostSamples &hs, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
+                           const sono_full_file_options *opt, const sono_segment *rois, size_t n_rois, size_t roi_base,
+                           size_t *calls_seen, float *d_rec, StageTimes &times)
 {
-    const float *x = hs.x;
-    if (count) *count = 0;
-    if (!e || !opt || (n && !hs.x && !hs.q) || (cap && !out)) return fail(SONO_EINVAL, "sono_process_full_file: NULL argument");
-    if (hs.q && (hs.channels == 0 || hs.channel >= hs.channels)) return fail(SONO_EINVAL, "sono_process_full_file_pcm16: channel out of range");
-    e->full_file_calls.clear();
-    e->full_file_slices.clear();
-    if (!(sample_rate > 0)) return fail(SONO_EINVAL, "sono_process_full_file: sample_rate must be positive");
+    if (n_rois == 0) return SONO_OK;
     const uint32_t N = e->N;
-    StageTimer timer("sono_process_full_file");
-    auto lap = [&](const char *what) { timer.lap(what); };
-    // fast scan -> merge & pad (batCallDetector.js:594-601)
-    // The recording goes to HBM once and stays there: the fast scan, the regions' and the calls' transforms all read it
-    // where it lies (sono_fast_scan_segments, sono_analyze_rois and sono_measure_roi_calls, called one by one, each
-    // upload what they need).
-    std::vector<sono_segment> &raw = e->scan_segments;      // kept by the engine: tens of MB of fresh pages per call otherwise
-    size_t n_raw = 0;
-    if (n < N) return SONO_OK;                                                      // no frame, no segment (js:595-598)
-    if (raw.size() < n / std::max<size_t>(N / 2, 1) + 2) raw.resize(n / std::max<size_t>(N / 2, 1) + 2);
-    DeviceGuard guard(e->device);
-    HIP_TRY(e->d_rec.reserve(n * sizeof(float)));
-    float *d_rec = (float *)e->d_rec.p;
-    int rc;
-    if (hs.q) {
-        // 16-bit sample frames cross the link as they are (half the bytes of the float recording) and become the
-        // resident float recording on the device: everything below reads the same floats as the f32 entry point
-        // would have uploaded (value / 32768 is exact).
-        // In pieces of at most 512 MB through one staging buffer: copy and conversion follow each other on the
-        // engine's stream, so a piece is converted before the next one overwrites it, and no second whole copy of a
-        // night-long recording has to fit beside the float one.
-        const size_t frame_bytes = (size_t)hs.channels * sizeof(int16_t);
-        const size_t piece_frames = std::max<size_t>(1, ((size_t)512 << 20) / frame_bytes);
-        HIP_TRY(e->d_in.reserve(std::min(n, piece_frames) * frame_bytes));
-        for (size_t f0 = 0; f0 < n; f0 += piece_frames) {
-            const size_t cnt = std::min(piece_frames, n - f0);
-            rc = sono::upload_host_array(e, e->d_in.p, hs.q + f0 * hs.channels, cnt * frame_bytes, e->stream);
-            if (rc) return rc;
-            HIP_TRY(sono::launch_pcm_to_f32(e->d_in.p, cnt, hs.channels, hs.channel, 16, 0, d_rec + f0, e->stream));
-        }
-    } else {
-        rc = sono::upload_host_array(e, d_rec, x, n * sizeof(float), e->stream);
-        if (rc) return rc;
-    }
-    rc = sono::fast_scan_resident(e, d_rec, n, sample_rate, flow_khz, fhigh_khz, opt->threshold_db, raw.data(), raw.size(), &n_raw);
-    if (rc) return rc;
-    lap("upload, fast scan");
-    if (n_raw == 0) return SONO_OK;                                                 // js:595-598
-    std::vector<sono_segment> rois(n_raw);
-    size_t n_rois = 0;
-    rc = sono_merge_and_pad_segments(raw.data(), n_raw, n, sample_rate, opt->padding_ms, rois.data(), rois.size(), &n_rois);
-    if (rc) return rc;
+    const float *x = hs.x;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+    auto t0 = now();
     // per-region analysis, all regions at once (js:609-711)
     std::vector<uint64_t> row0(n_rois + 1);
-    rc = sono_roi_rows(rois.data(), n_rois, N, opt->hop_percent, row0.data());
+    int rc = sono_roi_rows(rois, n_rois, N, opt->hop_percent, row0.data());
     if (rc) return rc;
     const size_t total = (size_t)row0[n_rois];
     // six per-frame arrays, every entry of which the analysis writes: one block the engine keeps (fresh pages again)
@@ -925,35 +887,33 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
     // The samples of the regions that went through the automatic high-pass come back packed (HostSamples::packed): the
     // framing stage reads a region's samples from there, and nothing the size of the recording is kept on the host.
     std::vector<int64_t> packed_at;
-    lap("merge, tables");
-    rc = analyze_rois(e, x, n, rois.data(), n_rois, sample_rate, flow_khz, fhigh_khz, opt->hop_percent, 1, &t, total, nullptr, d_rec, &packed_at);
+    rc = analyze_rois(e, x, n, rois, n_rois, sample_rate, flow_khz, fhigh_khz, opt->hop_percent, 1, &t, total, nullptr, d_rec, &packed_at);
     if (rc) return rc;
-    lap("region analysis (GPU)");
+    times.analysis += ms_since(t0); t0 = now();
     // framing (js:677-794), measurement (js:797) and what follows it (js:802-827)
     std::vector<sono_roi_call> framed;       // sized by the framing: a bound from the frame count would be hundreds of MB of fresh pages
     size_t n_calls = 0;
     HostSamples framed_from = hs;
     framed_from.packed = (const float *)e->h_filtered.p;
     framed_from.packed_at = packed_at.data();
-    rc = frame_roi_calls(framed_from, nullptr, n, rois.data(), n_rois, &t, sample_rate, N, opt->call_threshold_db,
+    rc = frame_roi_calls(framed_from, nullptr, n, rois, n_rois, &t, sample_rate, N, opt->call_threshold_db,
                          opt->min_call_duration_ms, nullptr, 0, &n_calls, &framed);
     if (rc) return rc;
-    lap("framing (host)");
+    times.framing += ms_since(t0); t0 = now();
     std::vector<sono_call_measurement> meas(n_calls + 1);
     const bool keep_slices = (opt->debug_mode & SONO_KEEP_CALL_SPECTROGRAMS) != 0;
     std::vector<sono::FullFileSlice> slices(keep_slices ? n_calls : 0);
-    rc = measure_roi_calls(e, x, nullptr, n, rois.data(), n_rois, &t, framed.data(), n_calls, sample_rate, flow_khz, fhigh_khz,
+    rc = measure_roi_calls(e, x, nullptr, n, rois, n_rois, &t, framed.data(), n_calls, sample_rate, flow_khz, fhigh_khz,
                            opt->hop_percent, opt->debug_mode, opt->threads, meas.data(), keep_slices ? &slices : nullptr, d_rec);
     if (rc) return rc;
     e->full_file_axes = {t.hop, t.min_bin, t.num_bins, sample_rate};
-    lap("measurement (GPU + threads)");
     std::vector<sono_full_file_call> &kept = e->full_file_calls;
     for (size_t i = 0; i < n_calls; ++i) {
         sono_call_measurement &m = meas[i];
         if (m.reference_throws) {
             kept.clear();
             e->full_file_slices.clear();
-            return fail(SONO_EREFERENCE, "sono_process_full_file: the reference raises a TypeError on call " + std::to_string(i) +
+            return fail(SONO_EREFERENCE, "sono_process_full_file: the reference raises a TypeError on call " + std::to_string(*calls_seen + i) +
                                              " of this recording outside its debug mode (batCallDetector.js:2261, 2815)");
             }
         if (m.discarded || m.duration_ms <= 1.0) continue;                          // js:802-810
@@ -966,7 +926,7 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
         if (keep_slices) e->full_file_slices.push_back(std::move(slices[i]));
         sono_full_file_call &o = kept.back();
         o.m = m;
-        o.roi = framed[i].roi; o.start_frame = framed[i].start_frame; o.end_frame = framed[i].end_frame;
+        o.roi = roi_base + framed[i].roi; o.start_frame = framed[i].start_frame; o.end_frame = framed[i].end_frame;
         o.highpass_khz = hp[framed[i].roi];
         o.flow_hz = m.low_freq_khz * 1000;                                          // js:813-814
         o.fhigh_khz = m.high_freq_khz;
@@ -974,6 +934,200 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
         const double bw = m.bandwidth_khz;                                          // CallTypeClassifier.classify, js:48-56
         o.call_type = (!(bw == bw) || bw == 0 || bw < 5) ? SONO_CALL_CF : bw > 20 ? SONO_CALL_FM : SONO_CALL_CF_FM;
         o.quality = o.snr_db < 10 ? 0 : o.snr_db < 15 ? 1 : o.snr_db < 20 ? 2 : o.snr_db < 30 ? 3 : 4;    // getQualityRating, js:375-387
+    }
+    *calls_seen += n_calls;
+    times.measurement += ms_since(t0);
+    return SONO_OK;
+}
+
+// The recording's way to the GPU, piece by piece, on a thread and a stream of its own: piece p has arrived (and, for
+// 16-bit samples, been converted into the resident float recording) when arrived[p] has completed.
+struct PieceUpload {
+    sono_engine *e;
+    const HostSamples &hs;
+    size_t n, piece;                         // samples of the recording; samples per piece (a multiple of the fft size)
+    float *d_rec;
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> arrived;
+    std::atomic<size_t> queued{0};           // pieces whose event has been recorded
+    std::atomic<int> status{SONO_OK};
+    std::thread worker;
+    PieceUpload(sono_engine *e_, const HostSamples &hs_, size_t n_, size_t piece_, float *d) : e(e_), hs(hs_), n(n_), piece(piece_), d_rec(d) {}
+    size_t pieces() const { return (n + piece - 1) / piece; }
+    int start()
+    {
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        arrived.assign(pieces(), nullptr);
+        for (hipEvent_t &ev : arrived) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        if (hs.q) HIP_TRY(e->d_in.reserve(std::min(n, piece) * (size_t)hs.channels * sizeof(int16_t)));
+        const int device = e->device;
+        // half the process's host threads fill the pinned pieces (enough for the link's rate): the other stages' host
+        // work runs beside this thread's
+        const unsigned int copy_threads = std::max(1u, sono::host_threads() / 2);
+        worker = std::thread([this, device, copy_threads]() {
+            if (hipSetDevice(device) != hipSuccess) { status = SONO_EDEVICE; queued = pieces(); return; }
+            for (size_t p = 0; p < pieces(); ++p) {
+                const size_t f0 = p * piece, cnt = std::min(piece, n - f0);
+                int rc;
+                if (hs.q) {
+                    // 16-bit sample frames cross the link as they are (half the bytes of the float recording) and become
+                    // the resident float recording on the device: everything reads the same floats as the f32 entry
+                    // point would have uploaded (value / 32768 is exact).  One staging buffer: copy and conversion follow
+                    // each other on this stream, so a piece is converted before the next one overwrites it.
+                    const size_t frame_bytes = (size_t)hs.channels * sizeof(int16_t);
+                    rc = sono::upload_host_array(e, e->d_in.p, hs.q + f0 * hs.channels, cnt * frame_bytes, stream, copy_threads);
+                    if (rc == SONO_OK && sono::launch_pcm_to_f32(e->d_in.p, cnt, hs.channels, hs.channel, 16, 0, d_rec + f0, stream) != hipSuccess)
+                        rc = SONO_EDEVICE;
+                } else {
+                    rc = sono::upload_host_array(e, d_rec + f0, hs.x + f0, cnt * sizeof(float), stream, copy_threads);
+                }
+                if (rc == SONO_OK && hipEventRecord(arrived[p], stream) != hipSuccess) rc = SONO_EDEVICE;
+                if (rc != SONO_OK) { (void)hipGetLastError(); status = rc; queued = pieces(); return; }
+                queued = p + 1;
+            }
+        });
+        return SONO_OK;
+    }
+    // -> once piece p's event has been recorded (or the upload has failed): makes stream `s` wait for it
+    int wait_on(size_t p, hipStream_t s)
+    {
+        while (queued.load() <= p) std::this_thread::yield();
+        if (status.load() != SONO_OK) return fail(status.load(), "sono_process_full_file: the upload of the recording failed");
+        HIP_TRY(hipStreamWaitEvent(s, arrived[p], 0));
+        return SONO_OK;
+    }
+    ~PieceUpload()
+    {
+        if (worker.joinable()) worker.join();
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        for (hipEvent_t ev : arrived) if (ev) (void)hipEventDestroy(ev);
+    }
+};
+
+static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
+                             const sono_full_file_options *opt, sono_full_file_call *out, size_t cap, size_t *count)
+{
+    if (count) *count = 0;
+    if (!e || !opt || (n && !hs.x && !hs.q) || (cap && !out)) return fail(SONO_EINVAL, "sono_process_full_file: NULL argument");
+    if (hs.q && (hs.channels == 0 || hs.channel >= hs.channels)) return fail(SONO_EINVAL, "sono_process_full_file_pcm16: channel out of range");
+    e->full_file_calls.clear();
+    e->full_file_slices.clear();
+    if (!(sample_rate > 0)) return fail(SONO_EINVAL, "sono_process_full_file: sample_rate must be positive");
+    const uint32_t N = e->N, hop = N / 2, bins = N / 2;                              // the fast scan's hop, js:882-886
+    StageTimer timer("sono_process_full_file");
+    if (n < N) return SONO_OK;                                                      // no frame, no segment (js:595-598)
+    // The fast scan's band and threshold (fastScanSegmentsWasm, js:889-909)
+    const double freq_res = sample_rate / (double)N;
+    const double lo = std::floor(flow_khz * 1000.0 / freq_res), hi = std::ceil(fhigh_khz * 1000.0 / freq_res);
+    const size_t F = sono_frames_for(n, N, N - hop);
+    if (!(hi >= lo) || hi < 0.0) return SONO_OK;                                    // empty band: no frame can be active
+    const uint32_t min_bin = lo > 0.0 ? (lo > 4.0e9 ? 0xFFFFFFFFu : (uint32_t)lo) : 0u;
+    const uint32_t max_bin = hi > 4.0e9 ? 0xFFFFFFFFu : (uint32_t)hi;
+    const double target = std::pow(10.0, opt->threshold_db / 10.0) * (double)N * 0.25;
+    DeviceGuard guard(e->device);
+    HIP_TRY(e->d_rec.reserve(n * sizeof(float)));
+    float *d_rec = (float *)e->d_rec.p;
+    StageTimes times;
+    size_t calls_seen = 0;
+    int rc;
+    // The recording goes to HBM once and stays there: the fast scan, the regions' and the calls' transforms all read it
+    // where it lies.  It goes there in pieces, and what can be done with the pieces that have arrived is done while the
+    // next ones cross the link: the scan's flags are local to a frame, its runs and the merged, padded regions are final
+    // as soon as the scan has moved a padding's length past them, and a region's analysis, framing and measurement need
+    // that region's samples only.  (A band that reaches the last bin makes the reference's flat index run into the next
+    // frame's row, js:918-921: that scan wants the whole matrix, and the recording then goes up in one piece.)
+    const bool whole = e->no_upload_overlap || max_bin >= bins;
+    // samples per piece, a multiple of four hops of the scan (a wave of the scan's kernel takes four frames): 128 MB of
+    // 16-bit samples; in one go, still no more than 512 MB at a time through the staging buffer
+    const size_t piece = e->small_upload_pieces ? (size_t)64 * N : whole ? (size_t)1 << 28 : (size_t)1 << 26;
+    PieceUpload up(e, hs, n, piece, d_rec);
+    rc = up.start();
+    if (rc) return rc;
+    if (whole) {
+        rc = up.wait_on(up.pieces() - 1, e->stream);
+        if (rc) return rc;
+        std::vector<sono_segment> &raw = e->scan_segments;  // kept by the engine: tens of MB of fresh pages per call otherwise
+        size_t n_raw = 0;
+        if (raw.size() < n / std::max<size_t>(hop, 1) + 2) raw.resize(n / std::max<size_t>(hop, 1) + 2);
+        rc = sono::fast_scan_resident(e, d_rec, n, sample_rate, flow_khz, fhigh_khz, opt->threshold_db, raw.data(), raw.size(), &n_raw);
+        if (rc) return rc;
+        timer.lap("upload, fast scan");
+        if (n_raw == 0) return SONO_OK;                                             // js:595-598
+        std::vector<sono_segment> rois(n_raw);
+        size_t n_rois = 0;
+        rc = sono_merge_and_pad_segments(raw.data(), n_raw, n, sample_rate, opt->padding_ms, rois.data(), rois.size(), &n_rois);
+        if (rc) return rc;
+        rc = process_regions(e, hs, n, sample_rate, flow_khz, fhigh_khz, opt, rois.data(), n_rois, 0, &calls_seen, d_rec, times);
+        if (rc) return rc;
+    } else {
+        HIP_TRY(e->d_flags.reserve(F));
+        std::vector<uint8_t> flags(F);
+        const double pad_d = std::round((opt->padding_ms / 1000.0) * sample_rate);   // mergeAndPadSegments, js:1031
+        const int64_t pad = (int64_t)pad_d;
+        bool in_run = false, have_cur = false;
+        uint64_t run_first = 0;
+        int64_t cur_start = 0, cur_end = 0;
+        size_t scanned = 0, roi_base = 0;                   // frames of the scan done; regions handed on
+        std::vector<sono_segment> group;
+        double t_wait = 0, t_scan = 0;
+        auto add_segment = [&](uint64_t first, uint64_t last) {          // a run of active frames (js:930-945), merged as js:1028-1056 does
+            const int64_t s0 = (int64_t)(first * hop), e0 = (int64_t)(last + 1 < F ? (last + 1) * hop + N : (uint64_t)n);
+            const int64_t ns = s0 - pad > 0 ? s0 - pad : 0, ne = e0 + pad < (int64_t)n ? e0 + pad : (int64_t)n;
+            if (have_cur && ns <= cur_end) { cur_end = ne > cur_end ? ne : cur_end; return; }
+            if (have_cur) group.push_back({(uint64_t)cur_start, (uint64_t)cur_end});
+            cur_start = ns; cur_end = ne; have_cur = true;
+        };
+        for (size_t p = 0; p < up.pieces(); ++p) {
+            auto t0 = std::chrono::steady_clock::now();
+            rc = up.wait_on(p, e->stream);
+            if (rc) return rc;
+            const size_t have = std::min(n, (p + 1) * piece);            // samples in HBM once the stream gets there
+            size_t f_end = have >= N ? (have - N) / hop + 1 : 0;         // frames that lie in them
+            if (f_end > F) f_end = F;
+            if (p + 1 < up.pieces()) f_end &= ~(size_t)3;                 // the kernel takes the frames of a launch four to a wave, in pairs: launches start on a multiple of four
+            if (f_end > scanned) {
+                const size_t cnt = f_end - scanned, used = (cnt - 1) * (size_t)hop + N;
+                sono_batch b{d_rec + scanned * hop, 1, used, used};
+                rc = sono_stft_band_active_dev(e, &b, N - hop, min_bin, max_bin, target, (uint8_t *)e->d_flags.p + scanned, nullptr, nullptr);
+                if (rc) return rc;
+                HIP_TRY(hipMemcpyAsync(flags.data() + scanned, (const uint8_t *)e->d_flags.p + scanned, cnt, hipMemcpyDeviceToHost, e->stream));
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                t_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                t0 = std::chrono::steady_clock::now();
+                for (size_t f = scanned; f < f_end; ++f) {
+                    if (flags[f] && !in_run) { in_run = true; run_first = f; }
+                    else if (!flags[f] && in_run) { in_run = false; add_segment(run_first, f - 1); }
+                }
+                scanned = f_end;
+            }
+            const bool last_piece = p + 1 == up.pieces();
+            if (last_piece) {
+                if (in_run) { in_run = false; add_segment(run_first, F - 1); }
+                if (have_cur) { group.push_back({(uint64_t)cur_start, (uint64_t)cur_end}); have_cur = false; }
+            } else if (have_cur) {
+                // whatever comes next starts at the open run's first frame or at the first frame not scanned yet
+                const int64_t next_start = (int64_t)((in_run ? run_first : scanned) * hop) - pad;
+                if (next_start > cur_end) { group.push_back({(uint64_t)cur_start, (uint64_t)cur_end}); have_cur = false; }
+            }
+            t_scan += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            // Regions are handed on some ten thousand at a time: the measurement is one wave per call, and fewer calls
+            // than the GPU has room for waves leave it idle for as long as one call takes.
+            if (!group.empty() && (last_piece || group.size() >= (e->small_upload_pieces ? (size_t)6 : (size_t)12000))) {
+                rc = process_regions(e, hs, n, sample_rate, flow_khz, fhigh_khz, opt, group.data(), group.size(), roi_base, &calls_seen, d_rec, times);
+                if (rc) return rc;
+                roi_base += group.size();
+                group.clear();
+            }
+        }
+        if (timer.on) {
+            std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "waiting for pieces, fast scan", t_wait);
+            std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "runs, regions", t_scan);
+        }
+    }
+    if (timer.on) {
+        std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "region analysis (GPU)", times.analysis);
+        std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "framing (host)", times.framing);
+        std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "measurement (GPU + threads)", times.measurement);
     }
     return sono_full_file_results(e, out, cap, count);
 }

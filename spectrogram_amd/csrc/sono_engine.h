@@ -130,7 +130,7 @@ private:
 // three pinned buffers the engine keeps, copied in by several host threads while the previous piece is on the bus
 // (a plain copy from pageable memory runs at less than half the link's rate).  Returns once the last piece is queued;
 // h_src may be changed after the call returns.  Small arrays take the plain copy.
-int upload_host_array(sono_engine *e, void *d_dst, const void *h_src, size_t bytes, hipStream_t s);
+int upload_host_array(sono_engine *e, void *d_dst, const void *h_src, size_t bytes, hipStream_t s, unsigned int threads = 0);
 
 // fastScanSegmentsWasm (batCallDetector.js:878-949) on a recording that already lies in HBM (sono_capi_detect.hip).
 int fast_scan_resident(sono_engine *e, const float *d_x, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
@@ -174,6 +174,8 @@ struct sono_engine {
     };
     MeasureSlot measure_slot[2];
     sono::DevBuf d_measure_tables, d_measure_scratch;   // measurement on the GPU: frequency axis + zonal floors; the waves' work areas
+    bool no_upload_overlap = false;         // engine option "no_upload_overlap": whole-file detection uploads the recording in one piece, then scans and analyses it
+    bool small_upload_pieces = false;       // engine option "small_upload_pieces": pieces of 64 fft sizes instead of 2^26 samples (tests: many pieces from a short recording)
     bool host_measure = false;              // engine option "host_measure": the calls' dB matrices go to the host and are measured there
     // pinned pieces of upload_host_array, each guarded by an event recorded behind its copy to the device
     struct UploadSlot {

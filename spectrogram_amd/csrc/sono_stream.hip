@@ -173,7 +173,7 @@ struct StreamPipe {
 
 void stream_pipe_destroy(StreamPipe *p) { delete p; }
 
-int upload_host_array(sono_engine *e, void *d_dst, const void *h_src, size_t bytes, hipStream_t s)
+int upload_host_array(sono_engine *e, void *d_dst, const void *h_src, size_t bytes, hipStream_t s, unsigned int threads)
 {
     constexpr size_t kPiece = (size_t)64 << 20;
     if (bytes < 2 * kPiece || no_pinned_upload()) {
@@ -181,7 +181,7 @@ int upload_host_array(sono_engine *e, void *d_dst, const void *h_src, size_t byt
         if (bytes >= 2 * kPiece) HIP_TRY(hipStreamSynchronize(s));
         return SONO_OK;
     }
-    CopyPool pool(host_threads());
+    CopyPool pool(threads ? threads : host_threads());
     size_t piece = 0;
     for (size_t off = 0; off < bytes; off += kPiece, ++piece) {
         sono_engine::UploadSlot &slot = e->upload_slot[piece % 3];

@@ -380,6 +380,48 @@ def test_measurement_on_the_gpu_equals_the_host_stage():
     e.free()
 
 
+def test_upload_beside_the_analysis_changes_nothing(golden):
+    """The recording crosses the link in pieces, and the regions of the pieces that have arrived are analysed, framed and
+    measured while the next pieces are on their way.  With pieces of 64 fft sizes (engine option "small_upload_pieces")
+    a few seconds of audio are cut into dozens of pieces -- runs and regions straddle the cuts, some pieces hold no
+    region at all -- and every call equals the one-piece form's ("no_upload_overlap") bit for bit, region numbers
+    included; so does the reference's TypeError."""
+    import spectrogram_amd.framing as frm
+    from spectrogram_amd import measure as ms
+    g, meta = golden
+    sr = 384000
+    e = sa.SpectrogramEngine(1024, "hann")
+    recordings = [(_mixed_calls(sr, 7.0, 23), sr, 10.0, 128.0, {"threshold_dB": -50.0}, {"debugMode": True}),
+                  (_mixed_calls(sr, 5.0, 24), sr, 15.0, 110.0, {"threshold_dB": -45.0, "padding_ms": 12.0}, {"debugMode": True, "hopPercent": 6.25}),
+                  (np.zeros(3 * sr, np.float32), sr, 10.0, 128.0, {"threshold_dB": -50.0}, {}),
+                  (_mixed_calls(sr, 4.0, 25), sr, 10.0, 128.0, {"threshold_dB": -50.0}, {})]
+    loud = (0.2 * np.sin(2 * np.pi * 40000 * np.arange(2 * sr) / sr)).astype(np.float32)          # one run from the first frame to the last
+    recordings.append((loud, sr, 10.0, 128.0, {"threshold_dB": -50.0}, {"debugMode": True}))
+    (c,) = cases(meta, "fullfile_measured")
+    recordings.append((g[c["name"] + "/x"], c["sr"], c["flow_khz"], c["fhigh_khz"],
+                       {"threshold_dB": c["scan_threshold_db"], "padding_ms": c["padding_ms"]},
+                       {"hopPercent": c["hop_percent"], "callThreshold_dB": c["call_threshold_db"],
+                        "minCallDuration_ms": c["min_call_duration_ms"], "debugMode": True}))
+    rows_seen = 0
+    for x, rate, flow, fhigh, opt, cfg in recordings:
+        for samples in (x, np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)):
+            got = []
+            for pieces in (False, True):
+                e.set_option("no_upload_overlap", not pieces)
+                e.set_option("small_upload_pieces", pieces)
+                try:
+                    native = frm.process_full_file_native(e, samples, rate, flow, fhigh, opt, cfg)
+                    got.append(native)
+                except ms.ReferenceThrows as err:
+                    got.append(str(err))
+            assert got[0] == got[1], (len(x), opt, cfg)
+            rows_seen += len(got[0]) if isinstance(got[0], list) else 0
+    assert rows_seen > 200
+    e.set_option("no_upload_overlap", False)
+    e.set_option("small_upload_pieces", False)
+    e.free()
+
+
 def test_rms_based_snr(golden):
     g, meta = golden
     e = sa.SpectrogramEngine(1024, "hann")
