@@ -313,37 +313,42 @@ __global__ __launch_bounds__(kThreads) void db_peaks_kernel(const float *mags, s
             if (64u * k < nb) v[k] = to_db(v[k]);                                // a chunk of 64 bins that the band reaches: all lanes or none
             if ((uint32_t)lane + 64u * k >= nb) v[k] = NAN;
         }
+        // The row's maximum by one reduction over the lanes, then every question about positions by ballots: which
+        // lanes hold the maximum (the first of them is the peak bin), which lie above peak - 12 dB (the first and the
+        // last of them are the extent).  A ballot answers for 64 bins at once and its answer is the same in every lane,
+        // so no bin numbers travel between lanes.  Same bins as frame_peaks_kernel: strict >, ascending -- the first
+        // maximum; a NaN (also the fill) is never a maximum and never above a threshold.
         float best = -INFINITY;
-        int best_bin = -1;
 #pragma unroll
         for (int k = 0; k < kRowRegs; ++k)
-            if (v[k] > best) { best = v[k]; best_bin = lane + 64 * k; }         // strict >, b ascends: the lane's first maximum; NaN (the fill) never wins
+            if (v[k] > best) best = v[k];
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(best, o, 64);
-            const int ob = __shfl_xor(best_bin, o, 64);
-            const bool take = ob >= 0 && (best_bin < 0 || ov > best || (ov == best && ob < best_bin));
-            if (take) { best = ov; best_bin = ob; }
+            if (ov > best) best = ov;
         }
+        int best_bin = -1, lo = 0x7FFFFFFF, hi = -1;
         const double thr = (double)best - 12;                                    // js:3061-3073
-        int lo = 0x7FFFFFFF, hi = -1;
+        const bool any = best > -INFINITY;                                       // else no entry was ever above the start value
 #pragma unroll
-        for (int k = 0; k < kRowRegs; ++k)
-            if ((double)v[k] > thr) { const int b = lane + 64 * k; if (b < lo) lo = b; hi = b; }
-        for (int o = 32; o > 0; o >>= 1) {
-            const int ol = __shfl_xor(lo, o, 64), oh = __shfl_xor(hi, o, 64);
-            lo = ol < lo ? ol : lo;
-            hi = oh > hi ? oh : hi;
+        for (int k = 0; k < kRowRegs; ++k) {
+            if (64u * k >= nb) continue;
+            const unsigned long long at_peak = __ballot(any && v[k] == best);
+            if (at_peak && best_bin < 0) best_bin = 64 * k + (int)__builtin_ctzll(at_peak);
+            const unsigned long long above = __ballot((double)v[k] > thr);
+            if (above) {
+                if (lo == 0x7FFFFFFF) lo = 64 * k + (int)__builtin_ctzll(above);
+                hi = 64 * k + 63 - (int)__builtin_clzll(above);
+            }
         }
         // the peak's neighbours, from the lanes that hold them
         auto value_at = [&](int bin) {
             float r = NAN;
 #pragma unroll
-            for (int k = 0; k < kRowRegs; ++k) {
-                const float held = __shfl(v[k], bin & 63, 64);
-                if ((bin >> 6) == k) r = held;
-            }
+            for (int k = 0; k < kRowRegs; ++k)
+                if ((bin >> 6) == k) r = __shfl(v[k], bin & 63, 64);
             return r;
         };
+        if (best_bin >= 0) best = value_at(best_bin);                            // the entry met first (a -0 before a +0 stays a -0)
         const float left = best_bin > 0 ? value_at(best_bin - 1) : NAN;
         const float right = best_bin >= 0 && (uint32_t)best_bin + 1 < nb ? value_at(best_bin + 1) : NAN;
         if (lane == 0) {
