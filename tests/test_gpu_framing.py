@@ -1,5 +1,6 @@
 """The call-framing stage with its matrix passes on the GPU, against the golden
 vectors captured from the reference's JavaScript.  Needs an MI355X: -m gpu."""
+import ctypes as C
 import json
 import os
 
@@ -417,6 +418,19 @@ def test_upload_beside_the_analysis_changes_nothing(golden):
             assert got[0] == got[1], (len(x), opt, cfg)
             rows_seen += len(got[0]) if isinstance(got[0], list) else 0
     assert rows_seen > 200
+    # one channel of an interleaved 16-bit recording, piece by piece
+    x = _mixed_calls(sr, 3.0, 26)
+    q = np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)
+    inter = np.stack([np.zeros_like(q), q, (q // 3).astype(np.int16)], axis=1)                    # frames x 3 channels
+    got = []
+    for pieces in (False, True):
+        e.set_option("no_upload_overlap", not pieces)
+        e.set_option("small_upload_pieces", pieces)
+        out, count = frm._full_file_call_array(e, inter, sr, 10.0, 128.0, {"threshold_dB": -50.0}, {"debugMode": True}, 0, False, pcm_channel=1)
+        got.append(bytes(out)[: count * C.sizeof(sa.FullFileCall)])
+    out, count = frm._full_file_call_array(e, q, sr, 10.0, 128.0, {"threshold_dB": -50.0}, {"debugMode": True}, 0, False)
+    mono = bytes(out)[: count * C.sizeof(sa.FullFileCall)]
+    assert count > 10 and got[0] == got[1] == mono
     e.set_option("no_upload_overlap", False)
     e.set_option("small_upload_pieces", False)
     e.free()
