@@ -594,7 +594,9 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filter
 /* processFullFile (batCallDetector.js:584-840) in one call: fast scan, merge & pad, batched region analysis, framing,
  * measurement, and the follow-up of js:802-827 (discarded and <= 1 ms calls dropped, classification, placeholder SNR
  * = peak + 80 dB, quality, region time -> file time).  Calls come in the reference's order (per region, strongest
- * first).  SONO_EREFERENCE: SONO_DEBUG_MODE is not set and the reference would raise on one of the calls (its promise rejects). */
+ * first).  SONO_EREFERENCE: SONO_DEBUG_MODE is not set and the reference would raise on one of the calls (its promise rejects).
+ * The recording is read from the caller's memory by a second thread for the length of the call (it crosses the link
+ * in pieces while the pieces that have arrived are worked on); x must stay unchanged until the call returns. */
 typedef struct sono_full_file_options {
     double threshold_db;            /* options.threshold_dB of the fast scan, reference default -60 */
     double padding_ms;              /* options.padding_ms of mergeAndPadSegments, default 5 */
@@ -602,7 +604,7 @@ typedef struct sono_full_file_options {
     double call_threshold_db;       /* config.callThreshold_dB, default -24 */
     double min_call_duration_ms;    /* config.minCallDuration_ms, default 1 */
     int32_t debug_mode;             /* SONO_DEBUG_MODE | SONO_TIME_EXPANSION | SONO_KEEP_CALL_SPECTROGRAMS */
-    uint32_t threads;               /* host threads of the measurement stage, 0 = up to 16 */
+    uint32_t threads;               /* host threads of the measurement stage where it runs on the host, 0 = the process's budget */
 } sono_full_file_options;
 enum { SONO_CALL_CF = 0, SONO_CALL_FM = 1, SONO_CALL_CF_FM = 2 };
 typedef struct sono_full_file_call {

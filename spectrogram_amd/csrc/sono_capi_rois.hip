@@ -991,7 +991,7 @@ struct PieceUpload {
     // -> once piece p's event has been recorded (or the upload has failed): makes stream `s` wait for it
     int wait_on(size_t p, hipStream_t s)
     {
-        while (queued.load() <= p) std::this_thread::yield();
+        while (queued.load() <= p) std::this_thread::sleep_for(std::chrono::microseconds(50));     // a piece takes milliseconds
         if (status.load() != SONO_OK) return fail(status.load(), "sono_process_full_file: the upload of the recording failed");
         HIP_TRY(hipStreamWaitEvent(s, arrived[p], 0));
         return SONO_OK;
