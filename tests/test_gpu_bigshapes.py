@@ -205,3 +205,29 @@ def test_ten_thousand_files_in_one_launch():
     e.free()
     del x, out, pb, pm
     torch.cuda.empty_cache()
+
+
+def test_whole_file_detection_at_production_piece_size():
+    """Forty minutes of one 16-bit channel through sono_process_full_file_pcm16 as a survey runs it: the recording
+    crosses the link in pieces of 2^26 samples (fourteen of them here) and its 24 000 regions are handed on in two
+    groups while later pieces are still on their way.  Every row of the call table equals the one-piece form's bit for
+    bit; the pulses come every 100 ms, so there are as many calls as tenths of a second."""
+    import torch
+    from spectrogram_amd import framing as frm
+    seconds = 2400
+    n = seconds * SR
+    x = synth.chirp_torch(0, n, SR, stream=0, device="cuda")
+    q = torch.clamp(torch.round(x * 32767.0), -32768, 32767).to(torch.int16).cpu().numpy()
+    del x
+    torch.cuda.empty_cache()
+    e = sa.SpectrogramEngine(1024, "hann")
+    tables = []
+    for whole in (False, True):
+        e.set_option("no_upload_overlap", whole)
+        tables.append(frm.process_full_file_table(e, q, SR, 10.0, 128.0, None, {"debugMode": True}, file_id=7))
+    piecewise, one_piece = tables
+    assert piecewise.shape == one_piece.shape and abs(piecewise.shape[0] - seconds * 10) <= 2
+    assert np.array_equal(piecewise.view(np.uint64), one_piece.view(np.uint64))
+    starts = piecewise[:, 3]                                  # start times rise with the regions
+    assert np.all(np.diff(starts) > 0)
+    e.free()
