@@ -4,8 +4,10 @@
 // The searches are the shared source of sono_measure_core.h.  Every lane of a call's wave runs the search logic on the
 // same values (it is serial: a hundred thresholds, each depending on the last), and the lanes share out the bins of a
 // row whenever the logic asks a question about a whole row -- "the first bin above this threshold", "the maximum and
-// where it is" -- which is where the time goes: a row is read 64 entries per instruction, coalesced, and answered with
-// one ballot.  Everything the logic writes (its per-threshold log in LDS, the contour arrays in the wave's scratch) is
+// where it is": a row is read 64 entries per instruction, coalesced, and answered with one ballot.  (What the kernel's
+// time goes into is the serial logic itself, a few hundred thousand wave instructions per call, most of them the
+// double-precision edge interpolation and harmonic test of the high-frequency search: measured, not the rows' way
+// from memory.)  Everything the logic writes (its per-threshold log in LDS, the contour arrays in the wave's scratch) is
 // written by every lane with the same value, and a lane reads back what it wrote itself, so no ordering between lanes
 // is needed except after the one cooperative write (the per-bin maxima of the safety re-scan), which ends in a fence.
 //
