@@ -50,6 +50,13 @@ struct HostOps {
     int64_t last_gt(const float *p, int64_t lo, int64_t hi, float t) const { return sono::last_gt(p, lo, hi, t); }
     float row_max(const float *p, size_t n) const { return sono::row_max(p, n); }
     int64_t first_max(const float *p, size_t n, float *value) const { return sono::first_max(p, n, value); }
+    template <class F> void for_each(int64_t n, const F &f) const { for (int64_t i = 0; i < n; ++i) f(i); }
+    // one thread walks the frames itself
+    void begin_low(const CallMatrix &, double, int64_t, int64_t) const {}
+    void begin_high(const CallMatrix &, double, int64_t) const {}
+    template <class BelowRef> bool low_walk(int, int64_t, int64_t, int64_t, const BelowRef &, int64_t &) const { return false; }
+    template <class Edge, class Harmonic>
+    bool high_walk(int, int64_t, int64_t, const Edge &, const Harmonic &, double &, int64_t &, int64_t &, bool &) const { return false; }
     // the floors of a call that comes without a zonal map, from the call's own frames f0..f1 (js:2437-2439, 1975-1977)
     const double *zonal_floors(const CallMatrix &m, int64_t f0, int64_t f1, size_t *zones)
     {

@@ -4,7 +4,10 @@
 //   * the GPU: one 64-lane wave per call; the lanes share out the bins of a row for every scan along a row and carry
 //     out everything else (the search logic, all of it in doubles) in step on the same values.
 // What differs between the two is the `Ops` object (row scans, the zonal noise floors of a call without a map);
-// the searches themselves are the same source and so give the same numbers.  Arrays the reference grows as it goes
+// the searches themselves are the same source and so give the same numbers.  An executor may also take over one
+// threshold's walk along the frames (`low_walk`, `high_walk`: the GPU answers it for 64 frames at a time from a table
+// it builds in `begin_low` / `begin_high`); the tests a walk applies to a frame are handed to it as the searches' own
+// expressions, and a walk that declines (returns false) leaves the frame-by-frame loop below to do it.  Arrays the reference grows as it goes
 // (the per-threshold log, the contour) live in a caller-provided Work area of fixed capacity.
 //
 // Compile with -ffp-contract=off: the expressions below reproduce double expression sequences of the reference, and a
@@ -70,19 +73,18 @@ SONO_MC inline double pow15(double x)
     return p + (pe + x * e);
 }
 
-// savitzkyGolay (batCallDetector.js:1610-1640), window 5, order 2; n < 5 copies.
-SONO_MC inline void savitzky_golay(const double *in, size_t n, double *out)
+// savitzkyGolay (batCallDetector.js:1610-1640), window 5, order 2; n < 5 copies.  One output entry: the entries are
+// independent of one another, and an executor may work them out side by side (Ops::for_each).
+SONO_MC inline double savitzky_golay_at(const double *in, int64_t n, int64_t i)
 {
-    if (n < 5) { for (size_t i = 0; i < n; ++i) out[i] = in[i]; return; }        // js:1611
+    if (n < 5) return in[i];                                                     // js:1611
     const double c[5] = {-3, 12, 17, 12, -3};                                    // js:1618
-    for (size_t i = 0; i < n; ++i) {
-        double s = 0.0;
-        for (int j = -2; j <= 2; ++j) {
-            const long long idx = (long long)i + j;
-            if (idx >= 0 && idx < (long long)n) s += in[idx] * c[j + 2];         // js:1631
-        }
-        out[i] = s / 35;                                                         // js:1636, also at the edges
+    double s = 0.0;
+    for (int j = -2; j <= 2; ++j) {
+        const int64_t idx = i + j;
+        if (idx >= 0 && idx < n) s += in[idx] * c[j + 2];                        // js:1631
     }
+    return s / 35;                                                               // js:1636, also at the edges
 }
 
 // findOptimalLowFrequencyThreshold, batCallDetector.js:2413-2909.  zonal: the noise floors to use (never null here).
@@ -105,6 +107,7 @@ SONO_MC LowResult find_low(const CallMatrix &m, Ops &ops, Work &w, const double 
     int n_meas = 0;
     int64_t start_frame = valid_peak, max_bin = nb - 1;                          // js:2449, 2453
     auto last_valid = [&]() { for (int i = n_meas - 1; i >= 0; --i) if (meas[i].found) return i; return -1; };
+    ops.begin_low(m, peak, valid_peak, search_end);
 
     for (int t = -1; t >= -kThresholds; --t) {                                   // js:2461
         const double thr = peak + (double)t;                                     // js:2475
@@ -114,17 +117,18 @@ SONO_MC LowResult find_low(const CallMatrix &m, Ops &ops, Work &w, const double 
         const double ref_khz = has_ref ? meas[ref_i].low_hz / 1000 : 0;          // js:2478-2484
         // forward scan along the call while frames keep a bin above the threshold (one silent frame is bridged)
         int64_t active_end = start_frame;
-        int silence = 0;
-        for (int64_t f = start_frame; f <= search_end; ++f) {                    // js:2509-2546
-            const int64_t b0 = ops.first_gt(row(f), 0, max_bin, thr_f);          // the frame's lowest bin above the threshold
-            const bool has = b0 >= 0;
-            const double lowest = has ? fb(b0) : 0;
-            if (has) {
-                active_end = f;
-                silence = 0;
-                if (has_ref && lowest < ref_khz * 1000) break;                   // js:2529-2537
-            } else if (++silence > 1) {
-                break;
+        auto below_ref = [&](int64_t b0) { return has_ref && fb(b0) < ref_khz * 1000; };           // js:2529-2537
+        if (!ops.low_walk(-t, start_frame, search_end, max_bin, below_ref, active_end)) {
+            int silence = 0;
+            for (int64_t f = start_frame; f <= search_end; ++f) {                // js:2509-2546
+                const int64_t b0 = ops.first_gt(row(f), 0, max_bin, thr_f);      // the frame's lowest bin above the threshold
+                if (b0 >= 0) {
+                    active_end = f;
+                    silence = 0;
+                    if (below_ref(b0)) break;
+                } else if (++silence > 1) {
+                    break;
+                }
             }
         }
         start_frame = active_end;                                                // js:2548
@@ -256,6 +260,7 @@ SONO_MC HighResult find_high(const CallMatrix &m, Ops &ops, Work &w, const doubl
         }
         return c;
     };
+    ops.begin_high(m, peak, limit);
 
     for (int t = -1; t >= -kThresholds; --t) {                                   // js:1965, 1979
         const double thr = peak + (double)t;
@@ -267,7 +272,12 @@ SONO_MC HighResult find_high(const CallMatrix &m, Ops &ops, Work &w, const doubl
         int64_t hbin = 0, hframe = 0;
         bool found = false;
         int silence = 0;
-        for (int64_t f = limit; f >= 0; --f) {                                   // js:2002-2048: from the peak back to the call's start
+        auto edge_at = [&](int64_t f, int64_t b) { return edge(f, b, thr); };
+        auto harmonic = [&](double cand) { return has_ref && cand / 1000 - ref_khz > 10.0; };      // js:2022-2026
+        // A walk answers the threshold when no frame's topmost candidate is a harmonic: every frame then offers that
+        // candidate, and what the loop below keeps is the largest of them, the first one met among equals.
+        const bool walked = ops.high_walk(-t, limit, min_bin, edge_at, harmonic, high_hz, hbin, hframe, found);
+        for (int64_t f = limit; !walked && f >= 0; --f) {                        // js:2002-2048: from the peak back to the call's start
             bool in_frame = false;
             // the frame's bins above the threshold from the top down (further ones only below a harmonic that is skipped)
             for (int64_t b = ops.last_gt(row(f), min_bin, nb - 1, thr_f); b >= min_bin; b = ops.last_gt(row(f), min_bin, b - 1, thr_f)) {
@@ -277,7 +287,7 @@ SONO_MC HighResult find_high(const CallMatrix &m, Ops &ops, Work &w, const doubl
                 // entries of the matrix and a division) is not worked out.
                 if (found && b + 1 <= hbin) { in_frame = true; break; }
                 const double cand = edge(f, b, thr);
-                if (has_ref && cand / 1000 - ref_khz > 10.0) continue;           // js:2022-2026: a harmonic, look further down
+                if (harmonic(cand)) continue;                                    // a harmonic, look further down
                 if (!found || cand > high_hz) { high_hz = cand; hbin = b; hframe = f; found = true; }
                 in_frame = true;
                 break;
@@ -662,20 +672,22 @@ SONO_MC void measure(const CallMatrix &m, Ops &ops, Work &w, const double *tf, s
         }
     if (n >= 5) {
         double *smooth = w.smooth, *d1 = w.d1, *d2 = w.d2, *curv = w.curv;
-        savitzky_golay(contour, (size_t)n, smooth);
+        // The derived arrays are maps over the contour's points (each entry from a few entries of the array before), so
+        // they go through for_each: the host loops, the GPU gives every lane a point.
+        ops.for_each(n, [&](int64_t i) { smooth[i] = savitzky_golay_at(contour, n, i); });
         // A frame number past the time axis reads undefined in the reference, the difference is NaN, and "NaN > 0" picks 0.001.
         auto t_at = [&](int64_t f) { return f < NT ? tf[f] : nan; };
         const int64_t n1 = n - 1, n2 = n - 2;
-        for (int64_t i = 0; i < n1; ++i) {                                       // js:3643-3653, kHz per ms
+        ops.for_each(n1, [&](int64_t i) {                                        // js:3643-3653, kHz per ms
             const double dt = (t_at(frames[i + 1]) - t_at(frames[i])) * 1000;
             d1[i] = (smooth[i + 1] - smooth[i]) / (dt > 0 ? dt : 0.001);
-        }
-        for (int64_t i = 0; i < n2; ++i) {                                       // js:3659-3668; entry i belongs to contour point i + 1
+        });
+        ops.for_each(n2, [&](int64_t i) {                                        // js:3659-3668; entry i belongs to contour point i + 1
             const double dt = ((t_at(frames[i + 2]) - t_at(frames[i])) * 1000) / 2;
             d2[i] = (d1[i + 1] - d1[i]) / (dt > 0 ? dt : 0.001);
-        }
-        // one value per contour point, asked for by the knee search and again by the heel search: worked out once
-        for (int64_t i = 0; i < n2; ++i) curv[i] = fabs(d2[i]) / (pow15(1 + d1[i] * d1[i]) + 1e-10);
+            // one value per contour point, asked for by the knee search and again by the heel search: worked out once
+            curv[i] = fabs(d2[i]) / (pow15(1 + d1[i] * d1[i]) + 1e-10);
+        });
         auto knee_shape = [&](int64_t k) {                                       // js:3671-3694: steep downward sweep that flattens
             if (k <= 0 || k >= n1) return false;
             const double in = d1[k - 1], out = d1[k];

@@ -29,8 +29,144 @@ constexpr int kWavesPerBlock = 4;
 // lay outside): a load under a branch of its own is waited for before the next one is issued, and four chunks of a row
 // are fetched together so that their trips to memory overlap.  Indices are 32-bit inside (a row has at most 65 535
 // entries): 64-bit integer arithmetic costs the vector unit several instructions per operation.
+//
+// The two searches ask, a hundred thresholds in a row, "which is this frame's topmost (lowest) bin above the
+// threshold" of the same frames.  begin_high / begin_low answer that once for every frame and all hundred
+// thresholds: an entry x of a row counts from threshold number T(x) on (the first one it lies above; the thresholds
+// fall), so the topmost bin above threshold t is the largest bin whose T is at most t -- every lane files its bins
+// under their T with a maximum (minimum) in LDS, and a running maximum (minimum) over the hundred slots is the frame's
+// answer per threshold, kept as 16-bit bin numbers, a hundred per frame, in the wave's scratch.  T comes from
+// comparisons with the very floats the frame-by-frame scans compare with, so the table holds what they would return.
+// A walk then takes 64 frames at a time, a lane each: one look-up per frame, the searches' own expressions for the
+// frame's edge and its tests evaluated by every lane for its frame, and the loop's order restored with ballots (where
+// the second silent frame in a row ends it) and one maximum over the wave (the first of equal candidates wins).
 struct WaveOps {
     unsigned int lane;
+    uint16_t *table;                         // the wave's scratch: kThresholds entries per frame
+    float *thr_f;                            // LDS, kThresholds: the thresholds as the scans compare with them
+    int *slot;                               // LDS, kThresholds
+    int table_first;                         // the frame the table's first row belongs to
+    static constexpr unsigned int kNone = 0xffffu;
+
+    // independent entries of an array, a lane each; the lanes read each other's entries afterwards
+    template <class F> __device__ void for_each(int64_t n, const F &f) const
+    {
+        for (int i = (int)lane; i < (int)n; i += 64) f((int64_t)i);
+        __threadfence_block();
+    }
+
+    template <bool TOP> __device__ void build_table(const CallMatrix &m, double peak, int f0, int f1)
+    {
+        const int l = (int)lane, nb = (int)m.bins, last = nb - 1;
+        for (int i = l; i < mcore::kThresholds; i += 64) thr_f[i] = mcore::float_below_thr(peak + (double)(-(i + 1)));
+        __threadfence_block();
+        const float lowest = thr_f[mcore::kThresholds - 1], peak_f = (float)peak;
+        const int none = TOP ? -1 : 0x7fffffff;
+        table_first = f0;
+        auto file = [&](int i, float v) {
+            if (!(i <= last && v > lowest)) return;                              // not above any threshold (NaN: never)
+            int g = (int)(peak_f - v) + 1;                                       // a guess at T, then the comparisons themselves
+            g = g < 1 ? 1 : g > mcore::kThresholds ? mcore::kThresholds : g;
+            while (g > 1 && v > thr_f[g - 2]) --g;
+            while (!(v > thr_f[g - 1])) ++g;                                     // ends at the lowest threshold at the latest
+            if (TOP) atomicMax(&slot[g - 1], i); else atomicMin(&slot[g - 1], i);
+        };
+        for (int f = f0; f <= f1; ++f) {
+            slot[l] = none;
+            if (l + 64 < mcore::kThresholds) slot[l + 64] = none;
+            __threadfence_block();
+            const float *p = m.db + (size_t)f * m.bins;
+            for (int base = 0; base < nb; base += 256) {
+                const int i0 = base + l, i1 = i0 + 64, i2 = i0 + 128, i3 = i0 + 192;
+                const float v0 = p[i0 < last ? i0 : last], v1 = p[i1 < last ? i1 : last], v2 = p[i2 < last ? i2 : last],
+                            v3 = p[i3 < last ? i3 : last];
+                file(i0, v0); file(i1, v1); file(i2, v2); file(i3, v3);
+            }
+            __threadfence_block();
+            // running maximum (minimum) over the slots: lanes 0..63 hold thresholds 1..64, lanes 0..35 also 65..100
+            int a = slot[l], b = l + 64 < mcore::kThresholds ? slot[l + 64] : none;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int va = __shfl_up(a, o), vb = __shfl_up(b, o);
+                if (l >= o) { a = TOP ? max(a, va) : min(a, va); b = TOP ? max(b, vb) : min(b, vb); }
+            }
+            const int first_half = __shfl(a, 63);
+            b = TOP ? max(b, first_half) : min(b, first_half);
+            uint16_t *out = table + (size_t)(f - f0) * mcore::kThresholds;
+            out[l] = (uint16_t)(a == none ? kNone : (unsigned int)a);
+            if (l + 64 < mcore::kThresholds) out[l + 64] = (uint16_t)(b == none ? kNone : (unsigned int)b);
+        }
+        __threadfence_block();                                                   // the lanes read each other's entries next
+    }
+    __device__ void begin_low(const CallMatrix &m, double peak, int64_t first, int64_t last) { build_table<false>(m, peak, (int)first, (int)last); }
+    __device__ void begin_high(const CallMatrix &m, double peak, int64_t last) { build_table<true>(m, peak, 0, (int)last); }
+
+    // One threshold of the low-frequency search (t = 1..100): forwards from start_frame while frames hold a bin above
+    // the threshold at or below max_bin; ends after a frame whose lowest such bin lies below the reference, or at the
+    // second frame in a row without one.  active_end: the last frame that had one.
+    template <class BelowRef>
+    __device__ bool low_walk(int t, int64_t start_frame, int64_t search_end, int64_t max_bin, const BelowRef &below_ref, int64_t &active_end) const
+    {
+        const int l = (int)lane, end = (int)search_end, top = (int)max_bin;
+        unsigned long long silent_before = 0;                                    // bit 0: the frame before this chunk had none
+        for (int base = (int)start_frame; base <= end; base += 64) {
+            const int f = base + l;
+            const bool valid = f <= end;
+            const unsigned int b = table[(size_t)((valid ? f : end) - table_first) * mcore::kThresholds + (t - 1)];
+            const bool has = valid && b != kNone && (int)b <= top;
+            const bool below = has && below_ref((int64_t)b);
+            const unsigned long long vmask = __ballot(valid), hmask = __ballot(has), silent = vmask & ~hmask;
+            const unsigned long long ends = __ballot(below) | (silent & ((silent << 1) | silent_before));
+            const int stop = ends ? __builtin_ctzll(ends) : 64;
+            const unsigned long long seen = stop < 63 ? hmask & ((2ull << stop) - 1) : hmask;         // frames up to the one that ends it
+            if (seen) active_end = base + 63 - __builtin_clzll(seen);
+            if (ends) break;
+            silent_before = silent >> 63;
+        }
+        return true;
+    }
+
+    // One threshold of the high-frequency search: backwards from frame `limit`, every frame offers the upper edge of its
+    // topmost bin above the threshold (at or above min_bin).  Declines when such a candidate is a harmonic (the loop
+    // then looks further down that frame) or not a number.
+    template <class Edge, class Harmonic>
+    __device__ bool high_walk(int t, int64_t limit, int64_t min_bin, const Edge &edge, const Harmonic &harmonic, double &high_hz,
+                              int64_t &hbin, int64_t &hframe, bool &found) const
+    {
+        const int l = (int)lane, low = (int)min_bin;
+        unsigned long long silent_before = 0;
+        bool any = false;
+        double best = 0;
+        int best_bin = 0, best_frame = 0;
+        for (int top = (int)limit; top >= 0; top -= 64) {
+            const int f = top - l;
+            const bool valid = f >= 0;
+            const unsigned int b = table[(size_t)((valid ? f : 0) - table_first) * mcore::kThresholds + (t - 1)];
+            const bool in = valid && b != kNone && (int)b >= low;
+            const unsigned long long vmask = __ballot(valid), imask = __ballot(in), silent = vmask & ~imask;
+            const unsigned long long ends = silent & ((silent << 1) | silent_before);
+            const int stop = ends ? __builtin_ctzll(ends) : 64;
+            const bool offers = in && l < stop;
+            double cand = -INFINITY;
+            bool odd = false;
+            if (offers) {
+                cand = edge((int64_t)f, (int64_t)b);
+                odd = cand != cand || harmonic(cand);
+            }
+            if (__ballot(odd)) return false;
+            double most = cand;
+            for (int o = 32; o >= 1; o >>= 1) { const double v = __shfl_xor(most, o); if (v > most) most = v; }
+            const unsigned long long holders = __ballot(offers && cand == most);
+            if (holders) {
+                const int w = __builtin_ctzll(holders);                          // the first one met: the highest frame
+                if (!any || most > best) { best = most; best_bin = __shfl((int)b, w); best_frame = top - w; any = true; }
+            }
+            if (ends) break;
+            silent_before = silent >> 63;
+        }
+        if (any) { high_hz = best; hbin = best_bin; hframe = best_frame; found = true; }
+        return true;
+    }
+
     __device__ int64_t first_gt(const float *p, int64_t lo64, int64_t hi64, float t) const
     {
         const int lo = (int)lo64, hi = (int)hi64, l = (int)lane;
@@ -140,13 +276,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SONO_MEASURE_WAVES_PER_SIMD) v
     int64_t *frames = (int64_t *)(per_frame + 5 * Fm);
     float *max_spec = (float *)(frames + Fm);
     uint16_t *frame_of = (uint16_t *)(max_spec + a.bins);
+    uint16_t *table = frame_of + (a.bins + 1) / 2 * 2;
     mcore::Work w{s_low[wave], s_high[wave], s_valid[wave], per_frame, per_frame + Fm, per_frame + 2 * Fm, per_frame + 3 * Fm,
                   per_frame + 4 * Fm, frames, max_spec, frame_of};
-    WaveOps ops{lane};
+    // the table's two LDS areas are borrowed from logs that are not in use while a table is built: the high-frequency
+    // search's log (written from its first threshold on, after begin_high) and the list of valid entries (filled after
+    // a search's last threshold)
+    WaveOps ops{lane, table, (float *)s_high[wave], s_valid[wave], 0};
     for (unsigned long long j = wave_global; j < a.n_jobs; j += waves) {
         const MeasureJob k = a.jobs[j];
-        for (unsigned int f = 0; f < k.times; ++f)                                                   // js:1350-1351
-            tf[f] = ((double)(k.start_frame + f) * a.hop + a.half_n) / a.sample_rate;
+        ops.for_each(k.times, [&](int64_t f) {                                                       // js:1350-1351
+            tf[f] = ((double)(k.start_frame + (uint64_t)f) * a.hop + a.half_n) / a.sample_rate;
+        });
         CallMatrix m{a.db + (size_t)k.db_row * a.bins, (size_t)k.frames, a.bins, a.freq_bins,
                      a.zonal + (size_t)k.roi * a.zone_stride, a.zones, a.debug_mode != 0, a.time_expansion != 0};
         CallMeasure cm;
@@ -180,7 +321,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, SONO_MEASURE_WAVES_PER_SIMD) v
 size_t measure_scratch_per_wave(unsigned int max_frames, unsigned int bins)
 {
     const size_t bytes = ((size_t)max_frames + 1) * sizeof(double) + (size_t)max_frames * mcore::work_bytes_per_frame() +
-                         (size_t)bins * mcore::work_bytes_per_bin();
+                         (size_t)(bins + 1) / 2 * 2 * mcore::work_bytes_per_bin() +
+                         (size_t)max_frames * mcore::kThresholds * sizeof(uint16_t);         // the searches' table
     return (bytes + 255) / 256 * 256;
 }
 
