@@ -563,7 +563,7 @@ class SpectrogramEngine:
         _check(lib().sono_engine_synchronize(self._handle()))
 
     def set_option(self, name, value):
-        """Engine switches ("force_generic", "force_any_hop", "fixed_tiles", "balance_debug", "no_streaming", "bank_two_kernels", "host_measure", "no_upload_overlap", "small_upload_pieces"):
+        """Engine switches ("force_generic", "force_any_hop", "fixed_tiles", "balance_debug", "no_streaming", "bank_two_kernels", "host_measure", "no_upload_overlap", "no_measure_overlap", "small_upload_pieces"):
         read from the environment once, when the engine is created; changed here afterwards."""
         _check(lib().sono_engine_set_option(self._handle(), str(name).encode(), int(bool(value))))
 

@@ -207,6 +207,7 @@ int sono_engine_create(uint32_t fft_size, const char *window, int has_alpha, flo
     e->no_streaming = env_flag("SONO_NO_STREAMING");
     e->host_measure = env_flag("SONO_HOST_MEASURE");
     e->no_upload_overlap = env_flag("SONO_NO_UPLOAD_OVERLAP");
+    e->no_measure_overlap = env_flag("SONO_NO_MEASURE_OVERLAP");
     if (rc == SONO_OK && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
         rc = hip_fail(hipGetLastError(), "hipStreamCreate");
     if (rc == SONO_OK) rc = sono::noalloc_init_device(dev);      // this GPU's fixed scratch of sono_detect_runs_static_dev
@@ -218,6 +219,7 @@ int sono_engine_create(uint32_t fft_size, const char *window, int has_alpha, flo
 void sono_engine_destroy(sono_engine *e)
 {
     if (!e) return;
+    if (e->measure_engine) { sono_engine_destroy(e->measure_engine); e->measure_engine = nullptr; }
     DeviceGuard guard(e->device);
     if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
     e->tables.release();
@@ -260,6 +262,7 @@ int sono_engine_set_option(sono_engine *e, const char *name, int value)
     else if (n == "bank_two_kernels") e->bank_two_kernels = on;
     else if (n == "host_measure") e->host_measure = on;
     else if (n == "no_upload_overlap") e->no_upload_overlap = on;
+    else if (n == "no_measure_overlap") e->no_measure_overlap = on;
     else if (n == "small_upload_pieces") e->small_upload_pieces = on;
     else return fail(SONO_EINVAL, "sono_engine_set_option: unknown option '" + n + "'");
     return SONO_OK;
@@ -277,6 +280,7 @@ int sono_engine_get_option(const sono_engine *e, const char *name, int *value)
     else if (n == "bank_two_kernels") *value = e->bank_two_kernels;
     else if (n == "host_measure") *value = e->host_measure;
     else if (n == "no_upload_overlap") *value = e->no_upload_overlap;
+    else if (n == "no_measure_overlap") *value = e->no_measure_overlap;
     else if (n == "small_upload_pieces") *value = e->small_upload_pieces;
     else return fail(SONO_EINVAL, "sono_engine_get_option: unknown option '" + n + "'");
     return SONO_OK;
@@ -315,6 +319,7 @@ int sono_engine_clear_filter_bank(sono_engine *e)
 int sono_engine_release_memory(sono_engine *e)
 {
     if (!e) return fail(SONO_EINVAL, "sono_engine_release_memory: NULL engine");
+    if (e->measure_engine) (void)sono_engine_release_memory(e->measure_engine);
     DeviceGuard guard(e->device);
     (void)hipStreamSynchronize(e->stream);
     e->bank.clear(); e->num_filters = 0; e->use_bank = false; e->bank_taps_ready = false;       // lib.rs:683-692

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <string>
 #include <thread>
@@ -862,51 +863,79 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filter
 // the last region's end); a kept call names its region as roi_base + its index here.  Appends to the engine's call list;
 // calls_seen counts the framed calls of the recording so far (the reference's TypeError is reported by that number).
 struct StageTimes { double analysis = 0, framing = 0, measurement = 0; };
-static int process_regions(sono_engine *e, const HostSamples &hs, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
-                           const sono_full_file_options *opt, const sono_segment *rois, size_t n_rois, size_t roi_base,
-                           size_t *calls_seen, float *d_rec, StageTimes &times)
+// What is left to do for a group of regions once its calls are framed -- their measurement and what follows it -- with
+// everything it reads: it can run beside the next group's analysis.
+struct GroupTail {
+    std::vector<sono_segment> rois;
+    std::vector<uint64_t> row0;
+    std::vector<float> hp;
+    std::vector<double> zonal;
+    sono_roi_table t{};
+    std::vector<sono_roi_call> framed;
+    size_t n_calls = 0, roi_base = 0;
+};
+
+// Analysis and framing of a group of regions (js:609-794) on engine e; the rest of the group's way is left in `g`.
+static int frame_regions(sono_engine *e, const HostSamples &hs, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
+                         const sono_full_file_options *opt, const sono_segment *rois, size_t n_rois, size_t roi_base, float *d_rec,
+                         StageTimes &times, GroupTail &g, const std::function<int()> &after_analysis)
 {
-    if (n_rois == 0) return SONO_OK;
     const uint32_t N = e->N;
     const float *x = hs.x;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
     auto t0 = now();
+    g.rois.assign(rois, rois + n_rois);
+    g.roi_base = roi_base;
     // per-region analysis, all regions at once (js:609-711)
-    std::vector<uint64_t> row0(n_rois + 1);
-    int rc = sono_roi_rows(rois, n_rois, N, opt->hop_percent, row0.data());
+    g.row0.resize(n_rois + 1);
+    int rc = sono_roi_rows(rois, n_rois, N, opt->hop_percent, g.row0.data());
     if (rc) return rc;
-    const size_t total = (size_t)row0[n_rois];
+    const size_t total = (size_t)g.row0[n_rois];
     // six per-frame arrays, every entry of which the analysis writes: one block the engine keeps (fresh pages again)
     if (e->frame_tables.size() < 6 * (total + 1)) e->frame_tables.resize(6 * (total + 1));
     float *peak_db = (float *)e->frame_tables.data(), *left = peak_db + (total + 1), *right = left + (total + 1);
     int32_t *peak_bin = (int32_t *)(right + (total + 1)), *ilo = peak_bin + (total + 1), *ihi = ilo + (total + 1);
-    std::vector<float> hp(n_rois + 1);
-    std::vector<double> zonal((n_rois + 1) * SONO_MAX_ZONES);
-    sono_roi_table t{row0.data(), peak_db, peak_bin, left, right, ilo, ihi, zonal.data(), hp.data(), 0, 0, 0, 0};
+    g.hp.resize(n_rois + 1);
+    g.zonal.resize((n_rois + 1) * SONO_MAX_ZONES);
+    sono_roi_table t{g.row0.data(), peak_db, peak_bin, left, right, ilo, ihi, g.zonal.data(), g.hp.data(), 0, 0, 0, 0};
     // The samples of the regions that went through the automatic high-pass come back packed (HostSamples::packed): the
     // framing stage reads a region's samples from there, and nothing the size of the recording is kept on the host.
     std::vector<int64_t> packed_at;
     rc = analyze_rois(e, x, n, rois, n_rois, sample_rate, flow_khz, fhigh_khz, opt->hop_percent, 1, &t, total, nullptr, d_rec, &packed_at);
     if (rc) return rc;
-    times.analysis += ms_since(t0); t0 = now();
-    // framing (js:677-794), measurement (js:797) and what follows it (js:802-827)
-    std::vector<sono_roi_call> framed;       // sized by the framing: a bound from the frame count would be hundreds of MB of fresh pages
-    size_t n_calls = 0;
+    times.analysis += ms_since(t0);
+    rc = after_analysis();                   // the GPU is free from here on: the framing is the host's
+    if (rc) return rc;
+    t0 = now();
+    // framing (js:677-794); the list is sized by the framing: a bound from the frame count would be hundreds of MB of fresh pages
     HostSamples framed_from = hs;
     framed_from.packed = (const float *)e->h_filtered.p;
     framed_from.packed_at = packed_at.data();
     rc = frame_roi_calls(framed_from, nullptr, n, rois, n_rois, &t, sample_rate, N, opt->call_threshold_db,
-                         opt->min_call_duration_ms, nullptr, 0, &n_calls, &framed);
+                         opt->min_call_duration_ms, nullptr, 0, &g.n_calls, &g.framed);
     if (rc) return rc;
-    times.framing += ms_since(t0); t0 = now();
+    times.framing += ms_since(t0);
+    // the measurement reads the table's per-region entries; its per-frame arrays belong to the engine and the next group
+    g.t = t;
+    g.t.peak_db = nullptr; g.t.peak_bin = nullptr; g.t.peak_left_db = nullptr; g.t.peak_right_db = nullptr; g.t.inst_lo_bin = nullptr; g.t.inst_hi_bin = nullptr;
+    return SONO_OK;
+}
+
+// Measurement (js:797) of a framed group's calls on engine em (its stream, its buffers) and what follows it (js:802-827);
+// the calls kept join the list of engine e.
+static int finish_regions(sono_engine *e, sono_engine *em, const HostSamples &hs, size_t n, double sample_rate, double flow_khz,
+                          double fhigh_khz, const sono_full_file_options *opt, GroupTail &g, size_t *calls_seen, float *d_rec)
+{
+    const size_t n_calls = g.n_calls;
+    const std::vector<sono_roi_call> &framed = g.framed;
     std::vector<sono_call_measurement> meas(n_calls + 1);
     const bool keep_slices = (opt->debug_mode & SONO_KEEP_CALL_SPECTROGRAMS) != 0;
     std::vector<sono::FullFileSlice> slices(keep_slices ? n_calls : 0);
-    rc = measure_roi_calls(e, x, nullptr, n, rois, n_rois, &t, framed.data(), n_calls, sample_rate, flow_khz, fhigh_khz,
-                           opt->hop_percent, opt->debug_mode, opt->threads, meas.data(), keep_slices ? &slices : nullptr, d_rec);
+    int rc = measure_roi_calls(em, hs.x, nullptr, n, g.rois.data(), g.rois.size(), &g.t, framed.data(), n_calls, sample_rate, flow_khz,
+                               fhigh_khz, opt->hop_percent, opt->debug_mode, opt->threads, meas.data(), keep_slices ? &slices : nullptr, d_rec);
     if (rc) return rc;
-    e->full_file_axes = {t.hop, t.min_bin, t.num_bins, sample_rate};
+    e->full_file_axes = {g.t.hop, g.t.min_bin, g.t.num_bins, sample_rate};
     std::vector<sono_full_file_call> &kept = e->full_file_calls;
     for (size_t i = 0; i < n_calls; ++i) {
         sono_call_measurement &m = meas[i];
@@ -917,7 +946,7 @@ static int process_regions(sono_engine *e, const HostSamples &hs, size_t n, doub
                                              " of this recording outside its debug mode (batCallDetector.js:2261, 2815)");
             }
         if (m.discarded || m.duration_ms <= 1.0) continue;                          // js:802-810
-        const double offset = (double)rois[framed[i].roi].start / sample_rate;      // js:737, 822-825
+        const double offset = (double)g.rois[framed[i].roi].start / sample_rate;    // js:737, 822-825
         m.start_time_s += offset;
         m.end_time_s += offset;
         if (m.start_freq_time_s == m.start_freq_time_s) m.start_freq_time_s += offset;
@@ -926,8 +955,8 @@ static int process_regions(sono_engine *e, const HostSamples &hs, size_t n, doub
         if (keep_slices) e->full_file_slices.push_back(std::move(slices[i]));
         sono_full_file_call &o = kept.back();
         o.m = m;
-        o.roi = roi_base + framed[i].roi; o.start_frame = framed[i].start_frame; o.end_frame = framed[i].end_frame;
-        o.highpass_khz = hp[framed[i].roi];
+        o.roi = g.roi_base + framed[i].roi; o.start_frame = framed[i].start_frame; o.end_frame = framed[i].end_frame;
+        o.highpass_khz = g.hp[framed[i].roi];
         o.flow_hz = m.low_freq_khz * 1000;                                          // js:813-814
         o.fhigh_khz = m.high_freq_khz;
         o.snr_db = m.peak_power_db - (-80);                                         // js:818
@@ -936,9 +965,38 @@ static int process_regions(sono_engine *e, const HostSamples &hs, size_t n, doub
         o.quality = o.snr_db < 10 ? 0 : o.snr_db < 15 ? 1 : o.snr_db < 20 ? 2 : o.snr_db < 30 ? 3 : 4;    // getQualityRating, js:375-387
     }
     *calls_seen += n_calls;
-    times.measurement += ms_since(t0);
     return SONO_OK;
 }
+
+// The groups' tails, one at a time and in the groups' order, on a thread of their own: group k's calls are measured
+// (on the engine's companion: a stream and buffers of its own) while group k + 1 is framed on the host.
+struct TailRunner {
+    std::thread worker;
+    std::unique_ptr<GroupTail> group;
+    int rc = SONO_OK;
+    std::string error;
+    double ms = 0;                           // the tails' own time, beside whatever else went on
+    // -> once the tail that is running (if any) has ended; its error becomes this thread's
+    int wait()
+    {
+        if (worker.joinable()) worker.join();
+        group.reset();
+        if (rc != SONO_OK) { const int r = rc; rc = SONO_OK; return fail(r, error); }
+        return SONO_OK;
+    }
+    void start(std::unique_ptr<GroupTail> g, std::function<int(GroupTail &)> fn)
+    {
+        group = std::move(g);
+        GroupTail *gp = group.get();
+        worker = std::thread([this, gp, fn]() {
+            const auto t0 = std::chrono::steady_clock::now();
+            rc = fn(*gp);
+            if (rc != SONO_OK) error = sono_last_error();
+            ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        });
+    }
+    ~TailRunner() { if (worker.joinable()) worker.join(); }
+};
 
 // The recording's way to the GPU, piece by piece, on a thread and a stream of its own: piece p has arrived (and, for
 // 16-bit samples, been converted into the resident float recording) when arrived[p] has completed.
@@ -1040,6 +1098,47 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
     // samples per piece, a multiple of four hops of the scan (a wave of the scan's kernel takes four frames): 128 MB of
     // 16-bit samples; in one go, still no more than 512 MB at a time through the staging buffer
     const size_t piece = e->small_upload_pieces ? (size_t)64 * N : whole ? (size_t)1 << 28 : (size_t)1 << 26;
+    // A group of regions is analysed (GPU, with the host filing what comes back), framed (host threads) and measured
+    // (GPU).  When another group is to follow, a group's measurement waits until that next group has been analysed and
+    // then runs -- on a thread and the engine's companion: a stream and buffers of its own -- beside the next group's
+    // framing.  One such tail at a time, in the groups' order: the calls join the list in the order of the recording.
+    sono_engine *em = nullptr;
+    if (!whole && !e->no_measure_overlap) {
+        if (!e->measure_engine && sono_engine_create(N, e->window_name.c_str(), 1, e->alpha, e->device, &e->measure_engine) != SONO_OK)
+            e->measure_engine = nullptr;                     // without it the tails run in line
+        em = e->measure_engine;
+        if (em) {
+            em->host_measure = e->host_measure;
+            em->tables.force_generic = e->tables.force_generic;
+            em->tables.tile.any_hop = e->tables.tile.any_hop;
+            em->tables.tile.balance.fixed = e->tables.tile.balance.fixed;
+        }
+    }
+    TailRunner tails;
+    std::unique_ptr<GroupTail> pending;                      // framed, not measured yet
+    auto finish = [&, d_rec](sono_engine *on, GroupTail &g) {
+        return finish_regions(e, on, hs, n, sample_rate, flow_khz, fhigh_khz, opt, g, &calls_seen, d_rec);
+    };
+    auto start_pending = [&]() -> int {
+        const int r = tails.wait();                          // the tail before it
+        if (r != SONO_OK) return r;
+        if (pending) tails.start(std::move(pending), [finish, em](GroupTail &gt) { return finish(em, gt); });
+        return SONO_OK;
+    };
+    auto run_group = [&](const sono_segment *rois, size_t n_rois, size_t roi_base, bool more_to_come) -> int {
+        if (n_rois == 0) return SONO_OK;
+        std::unique_ptr<GroupTail> g(new GroupTail());
+        int r = frame_regions(e, hs, n, sample_rate, flow_khz, fhigh_khz, opt, rois, n_rois, roi_base, d_rec, times, *g, start_pending);
+        if (r != SONO_OK) return r;
+        if (em && more_to_come) { pending = std::move(g); return SONO_OK; }
+        r = start_pending();                                 // nothing is pending here unless the framing found it so
+        if (r == SONO_OK) r = tails.wait();
+        if (r != SONO_OK) return r;
+        const auto t0 = std::chrono::steady_clock::now();
+        r = finish(e, *g);
+        times.measurement += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return r;
+    };
     PieceUpload up(e, hs, n, piece, d_rec);
     rc = up.start();
     if (rc) return rc;
@@ -1057,7 +1156,7 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
         size_t n_rois = 0;
         rc = sono_merge_and_pad_segments(raw.data(), n_raw, n, sample_rate, opt->padding_ms, rois.data(), rois.size(), &n_rois);
         if (rc) return rc;
-        rc = process_regions(e, hs, n, sample_rate, flow_khz, fhigh_khz, opt, rois.data(), n_rois, 0, &calls_seen, d_rec, times);
+        rc = run_group(rois.data(), n_rois, 0, false);
         if (rc) return rc;
     } else {
         HIP_TRY(e->d_flags.reserve(F));
@@ -1113,12 +1212,15 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
             // Regions are handed on some ten thousand at a time: the measurement is one wave per call, and fewer calls
             // than the GPU has room for waves leave it idle for as long as one call takes.
             if (!group.empty() && (last_piece || group.size() >= (e->small_upload_pieces ? (size_t)6 : (size_t)12000))) {
-                rc = process_regions(e, hs, n, sample_rate, flow_khz, fhigh_khz, opt, group.data(), group.size(), roi_base, &calls_seen, d_rec, times);
+                rc = run_group(group.data(), group.size(), roi_base, !last_piece);
                 if (rc) return rc;
                 roi_base += group.size();
                 group.clear();
             }
         }
+        rc = start_pending();                                // (the last group measures in line: nothing is left here)
+        if (rc == SONO_OK) rc = tails.wait();
+        if (rc) return rc;
         if (timer.on) {
             std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "waiting for pieces, fast scan", t_wait);
             std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "runs, regions", t_scan);
@@ -1128,6 +1230,7 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
         std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "region analysis (GPU)", times.analysis);
         std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "framing (host)", times.framing);
         std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "measurement (GPU + threads)", times.measurement);
+        std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "measurement beside the rest", tails.ms);
     }
     return sono_full_file_results(e, out, cap, count);
 }

@@ -177,6 +177,8 @@ struct sono_engine {
     bool no_upload_overlap = false;         // engine option "no_upload_overlap": whole-file detection uploads the recording in one piece, then scans and analyses it
     bool small_upload_pieces = false;       // engine option "small_upload_pieces": pieces of 64 fft sizes instead of 2^26 samples (tests: many pieces from a short recording)
     bool host_measure = false;              // engine option "host_measure": the calls' dB matrices go to the host and are measured there
+    bool no_measure_overlap = false;        // engine option "no_measure_overlap": whole-file detection measures a group's calls before it analyses the next group
+    sono_engine *measure_engine = nullptr;  // whole-file detection: the companion (same fft size and window) on whose stream and buffers a group's calls are measured beside the next group's analysis; created on first use
     // pinned pieces of upload_host_array, each guarded by an event recorded behind its copy to the device
     struct UploadSlot {
         sono::HostBuf buf;

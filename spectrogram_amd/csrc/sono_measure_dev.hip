@@ -2,14 +2,18 @@
 // one 64-lane wave per call, so that the calls' dB matrices never have to cross to the host.
 //
 // The searches are the shared source of sono_measure_core.h.  Every lane of a call's wave runs the search logic on the
-// same values (it is serial: a hundred thresholds, each depending on the last), and the lanes share out the bins of a
-// row whenever the logic asks a question about a whole row -- "the first bin above this threshold", "the maximum and
-// where it is": a row is read 64 entries per instruction, coalesced, and answered with one ballot.  (What the kernel's
-// time goes into is the serial logic itself, a few hundred thousand wave instructions per call, most of them the
-// double-precision edge interpolation and harmonic test of the high-frequency search: measured, not the rows' way
-// from memory.)  Everything the logic writes (its per-threshold log in LDS, the contour arrays in the wave's scratch) is
-// written by every lane with the same value, and a lane reads back what it wrote itself, so no ordering between lanes
-// is needed except after the one cooperative write (the per-bin maxima of the safety re-scan), which ends in a fence.
+// same values (it is serial: a hundred thresholds, each depending on the last), and the lanes share out the work
+// wherever the logic asks a question that has parts:
+//   * about a whole row -- "the first bin above this threshold", "the maximum and where it is": a row is read 64
+//     entries per instruction, coalesced, and answered with one ballot;
+//   * about many frames at one threshold -- the walks of the two searches, 64 frames at a time from a table built once
+//     per search (below: WaveOps::build_table, low_walk, high_walk);
+//   * about every point of the contour (its smoothing, derivatives, curvature; the time axis): a lane per point.
+// What one lane writes for the others to read (the tables, the per-point arrays, the per-bin maxima of the safety
+// re-scan) ends in a fence; everything else the logic writes (its per-threshold log in LDS, the contour) is written by
+// every lane with the same value, and a lane reads back what it wrote itself.  What the kernel's time goes into is
+// the serial logic itself, now some 150 000 wave instructions per call (400 000 before the walks took 64 frames at a
+// time), not the rows' way from memory.
 //
 // Built with -ffp-contract=off like the host stage: same expressions, same roundings, same numbers.
 #include <hip/hip_runtime.h>

@@ -386,7 +386,9 @@ def test_upload_beside_the_analysis_changes_nothing(golden):
     measured while the next pieces are on their way.  With pieces of 64 fft sizes (engine option "small_upload_pieces")
     a few seconds of audio are cut into dozens of pieces -- runs and regions straddle the cuts, some pieces hold no
     region at all -- and every call equals the one-piece form's ("no_upload_overlap") bit for bit, region numbers
-    included; so does the reference's TypeError."""
+    included; so does the reference's TypeError.  The groups of regions (six at a time here) measure their calls on a
+    thread and a companion engine beside the next group's framing, or in line ("no_measure_overlap"): same calls, same
+    error."""
     import spectrogram_amd.framing as frm
     from spectrogram_amd import measure as ms
     g, meta = golden
@@ -407,15 +409,17 @@ def test_upload_beside_the_analysis_changes_nothing(golden):
     for x, rate, flow, fhigh, opt, cfg in recordings:
         for samples in (x, np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)):
             got = []
-            for pieces in (False, True):
+            # one piece; pieces, a group's calls measured beside the next group's framing; pieces, one thing at a time
+            for pieces, in_line in ((False, False), (True, False), (True, True)):
                 e.set_option("no_upload_overlap", not pieces)
                 e.set_option("small_upload_pieces", pieces)
+                e.set_option("no_measure_overlap", in_line)
                 try:
                     native = frm.process_full_file_native(e, samples, rate, flow, fhigh, opt, cfg)
                     got.append(native)
                 except ms.ReferenceThrows as err:
                     got.append(str(err))
-            assert got[0] == got[1], (len(x), opt, cfg)
+            assert got[0] == got[1] == got[2], (len(x), opt, cfg)
             rows_seen += len(got[0]) if isinstance(got[0], list) else 0
     assert rows_seen > 200
     # one channel of an interleaved 16-bit recording, piece by piece
@@ -433,6 +437,7 @@ def test_upload_beside_the_analysis_changes_nothing(golden):
     assert count > 10 and got[0] == got[1] == mono
     e.set_option("no_upload_overlap", False)
     e.set_option("small_upload_pieces", False)
+    e.set_option("no_measure_overlap", False)
     e.free()
 
 
