@@ -97,9 +97,10 @@ uint32_t sono_host_threads(void);
  *   "no_upload_overlap" (SONO_NO_UPLOAD_OVERLAP) sono_process_full_file uploads the whole recording before it scans and
  *                                          analyses it, instead of working on the pieces that have arrived while the next
  *                                          ones cross the link
- *   "no_measure_overlap" (SONO_NO_MEASURE_OVERLAP) sono_process_full_file measures a group of regions' calls before it goes
- *                                          on, instead of beside the next group's framing (on a thread and a companion
- *                                          engine -- a stream and buffers of its own, created on first use)
+ *   "no_measure_overlap" (SONO_NO_MEASURE_OVERLAP) sono_process_full_file frames and measures a group of regions' calls
+ *                                          before it goes on, instead of beside the next group's scan and analysis (on a
+ *                                          thread, the measurement on a companion engine -- a stream and buffers of its
+ *                                          own, created on first use)
  *   "small_upload_pieces" (no variable)    those pieces are 64 fft sizes long instead of 2^26 samples (tests: many pieces
  *                                          and several groups of regions from a few seconds of audio)
  * None of them changes a result bit (the tests compare the forms).  SONO_EINVAL for an unknown name.

@@ -231,7 +231,7 @@ void sono_engine_destroy(sono_engine *e)
     for (auto &slot : e->measure_slot) slot.release();
     e->d_measure_tables.release(); e->d_measure_scratch.release();
     for (auto &slot : e->upload_slot) slot.release();
-    e->h_filtered.release();
+    for (auto &buf : e->h_filtered) buf.release();
     for (auto &slot : e->ragged) {
         if (slot.done) { (void)hipEventSynchronize(slot.done); (void)hipEventDestroy(slot.done); }
         slot.buf.release();
@@ -332,8 +332,8 @@ int sono_engine_release_memory(sono_engine *e)
     for (auto &slot : e->measure_slot) slot.release();
     e->d_measure_tables.release(); e->d_measure_scratch.release();
     for (auto &slot : e->upload_slot) slot.release();
-    e->h_filtered.release();
-    e->frame_tables.clear(); e->frame_tables.shrink_to_fit();
+    for (auto &buf : e->h_filtered) buf.release();
+    for (auto &tables : e->frame_tables) { tables.clear(); tables.shrink_to_fit(); }
     e->scan_segments.clear(); e->scan_segments.shrink_to_fit();
     e->full_file_slices.clear(); e->full_file_slices.shrink_to_fit();
     if (e->pipe) { sono::stream_pipe_destroy(e->pipe); e->pipe = nullptr; }

@@ -214,9 +214,10 @@ int sono_roi_rows(const sono_segment *rois, size_t n_rois, uint32_t fft_size, do
 // afterwards gets what region_audio() would pick on the host.
 static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segment *rois, size_t n_rois, double sample_rate,
                         double flow_khz, double fhigh_khz, double hop_percent, int auto_highpass, sono_roi_table *out,
-                        size_t frames_cap, float *x_filtered, float *d_rec, std::vector<int64_t> *packed_at = nullptr)
+                        size_t frames_cap, float *x_filtered, float *d_rec, std::vector<int64_t> *packed_at = nullptr,
+                        sono::HostBuf *packed_to = nullptr)
 {
-    // packed_at (with d_rec): the filtered samples come back as ONE copy into the engine's pinned h_filtered, packed
+    // packed_at (with d_rec): the filtered samples come back into pinned memory the engine keeps (packed_to), packed
     // region after region as the filter kernel wrote them, and packed_at[r] says where region r's begin (-1: not
     // filtered) -- nothing is scattered to the samples' places in a recording-sized host array.
     if (packed_at) packed_at->assign(n_rois, -1);
@@ -415,7 +416,8 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
     hipEvent_t filtered = nullptr;
     if (packed_at) {
         for (size_t k = 0; k < jobs.size(); ++k) (*packed_at)[job_region[k]] = (int64_t)jobs[k].dst;
-        if (!e->h_filtered.reserve(filtered_samples * sizeof(float)))
+        if (!packed_to) packed_to = &e->h_filtered[0];
+        if (!packed_to->reserve(filtered_samples * sizeof(float)))
             return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
         HIP_TRY(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&filtered, hipEventDisableTiming));
@@ -429,7 +431,7 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
             const size_t piece = (size_t)8 << 20;                // samples
             for (size_t at = 0; at < filtered_samples; at += piece) {
                 const size_t count = std::min(piece, filtered_samples - at);
-                if (hipMemcpyAsync((float *)e->h_filtered.p + at, (const float *)e->d_runs.p + at, count * sizeof(float),
+                if (hipMemcpyAsync((float *)packed_to->p + at, (const float *)e->d_runs.p + at, count * sizeof(float),
                                    hipMemcpyDeviceToHost, down) != hipSuccess || hipStreamSynchronize(down) != hipSuccess) {
                     (void)hipGetLastError();
                     copy_status = SONO_EDEVICE;
@@ -863,28 +865,28 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filter
 // the last region's end); a kept call names its region as roi_base + its index here.  Appends to the engine's call list;
 // calls_seen counts the framed calls of the recording so far (the reference's TypeError is reported by that number).
 struct StageTimes { double analysis = 0, framing = 0, measurement = 0; };
-// What is left to do for a group of regions once its calls are framed -- their measurement and what follows it -- with
-// everything it reads: it can run beside the next group's analysis.
+// What is left to do for a group of regions once they are analysed -- the framing of their calls, the calls'
+// measurement and what follows it -- with everything it reads: it can run beside the next group's analysis.  The
+// per-frame records (t's arrays) and the packed filtered samples lie in one of the engine's two sets of buffers;
+// the next group's analysis writes the other.
 struct GroupTail {
     std::vector<sono_segment> rois;
     std::vector<uint64_t> row0;
     std::vector<float> hp;
     std::vector<double> zonal;
     sono_roi_table t{};
-    std::vector<sono_roi_call> framed;
-    size_t n_calls = 0, roi_base = 0;
+    const float *packed = nullptr;           // the high-passed regions' samples, region after region (pinned, the engine's)
+    std::vector<int64_t> packed_at;          // per region: where its samples begin in `packed`, -1 = not filtered
+    size_t roi_base = 0;
 };
 
-// Analysis and framing of a group of regions (js:609-794) on engine e; the rest of the group's way is left in `g`.
-static int frame_regions(sono_engine *e, const HostSamples &hs, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
-                         const sono_full_file_options *opt, const sono_segment *rois, size_t n_rois, size_t roi_base, float *d_rec,
-                         StageTimes &times, GroupTail &g, const std::function<int()> &after_analysis)
+// Analysis of a group of regions (js:609-671) on engine e, into its buffer set `set`; the rest of the group's way is left in `g`.
+static int analyze_regions(sono_engine *e, const HostSamples &hs, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
+                           const sono_full_file_options *opt, const sono_segment *rois, size_t n_rois, size_t roi_base, float *d_rec,
+                           unsigned int set, StageTimes &times, GroupTail &g)
 {
     const uint32_t N = e->N;
-    const float *x = hs.x;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
-    auto t0 = now();
+    const auto t0 = std::chrono::steady_clock::now();
     g.rois.assign(rois, rois + n_rois);
     g.roi_base = roi_base;
     // per-region analysis, all regions at once (js:609-711)
@@ -893,47 +895,50 @@ static int frame_regions(sono_engine *e, const HostSamples &hs, size_t n, double
     if (rc) return rc;
     const size_t total = (size_t)g.row0[n_rois];
     // six per-frame arrays, every entry of which the analysis writes: one block the engine keeps (fresh pages again)
-    if (e->frame_tables.size() < 6 * (total + 1)) e->frame_tables.resize(6 * (total + 1));
-    float *peak_db = (float *)e->frame_tables.data(), *left = peak_db + (total + 1), *right = left + (total + 1);
+    std::vector<uint32_t> &tables = e->frame_tables[set];
+    if (tables.size() < 6 * (total + 1)) tables.resize(6 * (total + 1));
+    float *peak_db = (float *)tables.data(), *left = peak_db + (total + 1), *right = left + (total + 1);
     int32_t *peak_bin = (int32_t *)(right + (total + 1)), *ilo = peak_bin + (total + 1), *ihi = ilo + (total + 1);
     g.hp.resize(n_rois + 1);
     g.zonal.resize((n_rois + 1) * SONO_MAX_ZONES);
-    sono_roi_table t{g.row0.data(), peak_db, peak_bin, left, right, ilo, ihi, g.zonal.data(), g.hp.data(), 0, 0, 0, 0};
+    g.t = sono_roi_table{g.row0.data(), peak_db, peak_bin, left, right, ilo, ihi, g.zonal.data(), g.hp.data(), 0, 0, 0, 0};
     // The samples of the regions that went through the automatic high-pass come back packed (HostSamples::packed): the
     // framing stage reads a region's samples from there, and nothing the size of the recording is kept on the host.
-    std::vector<int64_t> packed_at;
-    rc = analyze_rois(e, x, n, rois, n_rois, sample_rate, flow_khz, fhigh_khz, opt->hop_percent, 1, &t, total, nullptr, d_rec, &packed_at);
+    rc = analyze_rois(e, hs.x, n, rois, n_rois, sample_rate, flow_khz, fhigh_khz, opt->hop_percent, 1, &g.t, total, nullptr, d_rec, &g.packed_at,
+                      &e->h_filtered[set]);
     if (rc) return rc;
-    times.analysis += ms_since(t0);
-    rc = after_analysis();                   // the GPU is free from here on: the framing is the host's
-    if (rc) return rc;
-    t0 = now();
-    // framing (js:677-794); the list is sized by the framing: a bound from the frame count would be hundreds of MB of fresh pages
-    HostSamples framed_from = hs;
-    framed_from.packed = (const float *)e->h_filtered.p;
-    framed_from.packed_at = packed_at.data();
-    rc = frame_roi_calls(framed_from, nullptr, n, rois, n_rois, &t, sample_rate, N, opt->call_threshold_db,
-                         opt->min_call_duration_ms, nullptr, 0, &g.n_calls, &g.framed);
-    if (rc) return rc;
-    times.framing += ms_since(t0);
-    // the measurement reads the table's per-region entries; its per-frame arrays belong to the engine and the next group
-    g.t = t;
-    g.t.peak_db = nullptr; g.t.peak_bin = nullptr; g.t.peak_left_db = nullptr; g.t.peak_right_db = nullptr; g.t.inst_lo_bin = nullptr; g.t.inst_hi_bin = nullptr;
+    g.packed = (const float *)e->h_filtered[set].p;
+    times.analysis += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SONO_OK;
 }
 
-// Measurement (js:797) of a framed group's calls on engine em (its stream, its buffers) and what follows it (js:802-827);
-// the calls kept join the list of engine e.
+// The rest of an analysed group's way: framing (js:677-794, host threads), measurement (js:797) of the calls on engine
+// em (its stream, its buffers) and what follows it (js:802-827); the calls kept join the list of engine e.
 static int finish_regions(sono_engine *e, sono_engine *em, const HostSamples &hs, size_t n, double sample_rate, double flow_khz,
-                          double fhigh_khz, const sono_full_file_options *opt, GroupTail &g, size_t *calls_seen, float *d_rec)
+                          double fhigh_khz, const sono_full_file_options *opt, GroupTail &g, size_t *calls_seen, float *d_rec,
+                          StageTimes &times)
 {
-    const size_t n_calls = g.n_calls;
-    const std::vector<sono_roi_call> &framed = g.framed;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&t0](double &into) {
+        const auto t1 = std::chrono::steady_clock::now();
+        into += std::chrono::duration<double, std::milli>(t1 - t0).count();
+        t0 = t1;
+    };
+    // the list is sized by the framing: a bound from the frame count would be hundreds of MB of fresh pages
+    std::vector<sono_roi_call> framed;
+    size_t n_calls = 0;
+    HostSamples framed_from = hs;
+    framed_from.packed = g.packed;
+    framed_from.packed_at = g.packed_at.data();
+    int rc = frame_roi_calls(framed_from, nullptr, n, g.rois.data(), g.rois.size(), &g.t, sample_rate, e->N, opt->call_threshold_db,
+                             opt->min_call_duration_ms, nullptr, 0, &n_calls, &framed);
+    if (rc) return rc;
+    lap(times.framing);
     std::vector<sono_call_measurement> meas(n_calls + 1);
     const bool keep_slices = (opt->debug_mode & SONO_KEEP_CALL_SPECTROGRAMS) != 0;
     std::vector<sono::FullFileSlice> slices(keep_slices ? n_calls : 0);
-    int rc = measure_roi_calls(em, hs.x, nullptr, n, g.rois.data(), g.rois.size(), &g.t, framed.data(), n_calls, sample_rate, flow_khz,
-                               fhigh_khz, opt->hop_percent, opt->debug_mode, opt->threads, meas.data(), keep_slices ? &slices : nullptr, d_rec);
+    rc = measure_roi_calls(em, hs.x, nullptr, n, g.rois.data(), g.rois.size(), &g.t, framed.data(), n_calls, sample_rate, flow_khz,
+                           fhigh_khz, opt->hop_percent, opt->debug_mode, opt->threads, meas.data(), keep_slices ? &slices : nullptr, d_rec);
     if (rc) return rc;
     e->full_file_axes = {g.t.hop, g.t.min_bin, g.t.num_bins, sample_rate};
     std::vector<sono_full_file_call> &kept = e->full_file_calls;
@@ -965,11 +970,13 @@ static int finish_regions(sono_engine *e, sono_engine *em, const HostSamples &hs
         o.quality = o.snr_db < 10 ? 0 : o.snr_db < 15 ? 1 : o.snr_db < 20 ? 2 : o.snr_db < 30 ? 3 : 4;    // getQualityRating, js:375-387
     }
     *calls_seen += n_calls;
+    lap(times.measurement);
     return SONO_OK;
 }
 
-// The groups' tails, one at a time and in the groups' order, on a thread of their own: group k's calls are measured
-// (on the engine's companion: a stream and buffers of its own) while group k + 1 is framed on the host.
+// The groups' tails, one at a time and in the groups' order, on a thread of their own: group k's calls are framed
+// (host threads) and measured (on the engine's companion: a stream and buffers of its own) while group k + 1 is
+// scanned and analysed.
 struct TailRunner {
     std::thread worker;
     std::unique_ptr<GroupTail> group;
@@ -1098,10 +1105,12 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
     // samples per piece, a multiple of four hops of the scan (a wave of the scan's kernel takes four frames): 128 MB of
     // 16-bit samples; in one go, still no more than 512 MB at a time through the staging buffer
     const size_t piece = e->small_upload_pieces ? (size_t)64 * N : whole ? (size_t)1 << 28 : (size_t)1 << 26;
-    // A group of regions is analysed (GPU, with the host filing what comes back), framed (host threads) and measured
-    // (GPU).  When another group is to follow, a group's measurement waits until that next group has been analysed and
-    // then runs -- on a thread and the engine's companion: a stream and buffers of its own -- beside the next group's
-    // framing.  One such tail at a time, in the groups' order: the calls join the list in the order of the recording.
+    // A group of regions is analysed (GPU, with this thread filing what comes back), its calls are framed (host
+    // threads) and measured (GPU).  When another group is to follow, framing and measurement run on a thread of their
+    // own -- the measurement on the engine's companion: a stream and buffers of its own -- while this thread goes on
+    // with the next pieces' scan and the next group's analysis; the two groups' records and filtered samples lie in the
+    // engine's two sets of buffers.  One such tail at a time, in the groups' order: the calls join the list in the order
+    // of the recording.
     sono_engine *em = nullptr;
     if (!whole && !e->no_measure_overlap) {
         if (!e->measure_engine && sono_engine_create(N, e->window_name.c_str(), 1, e->alpha, e->device, &e->measure_engine) != SONO_OK)
@@ -1115,29 +1124,23 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
         }
     }
     TailRunner tails;
-    std::unique_ptr<GroupTail> pending;                      // framed, not measured yet
-    auto finish = [&, d_rec](sono_engine *on, GroupTail &g) {
-        return finish_regions(e, on, hs, n, sample_rate, flow_khz, fhigh_khz, opt, g, &calls_seen, d_rec);
-    };
-    auto start_pending = [&]() -> int {
-        const int r = tails.wait();                          // the tail before it
-        if (r != SONO_OK) return r;
-        if (pending) tails.start(std::move(pending), [finish, em](GroupTail &gt) { return finish(em, gt); });
-        return SONO_OK;
-    };
+    unsigned int groups = 0;
+    StageTimes tail_times;                                   // a tail's own clock, beside this thread's
     auto run_group = [&](const sono_segment *rois, size_t n_rois, size_t roi_base, bool more_to_come) -> int {
         if (n_rois == 0) return SONO_OK;
         std::unique_ptr<GroupTail> g(new GroupTail());
-        int r = frame_regions(e, hs, n, sample_rate, flow_khz, fhigh_khz, opt, rois, n_rois, roi_base, d_rec, times, *g, start_pending);
+        // the buffer set the tail before the running one read: that tail has ended (a tail starts when the one before it has)
+        int r = analyze_regions(e, hs, n, sample_rate, flow_khz, fhigh_khz, opt, rois, n_rois, roi_base, d_rec, groups++ & 1u, times, *g);
+        const int before = tails.wait();                     // the group before this one: its calls come first
+        if (r == SONO_OK) r = before;
         if (r != SONO_OK) return r;
-        if (em && more_to_come) { pending = std::move(g); return SONO_OK; }
-        r = start_pending();                                 // nothing is pending here unless the framing found it so
-        if (r == SONO_OK) r = tails.wait();
-        if (r != SONO_OK) return r;
-        const auto t0 = std::chrono::steady_clock::now();
-        r = finish(e, *g);
-        times.measurement += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        return r;
+        if (em && more_to_come) {
+            tails.start(std::move(g), [&, em, d_rec](GroupTail &gt) {
+                return finish_regions(e, em, hs, n, sample_rate, flow_khz, fhigh_khz, opt, gt, &calls_seen, d_rec, tail_times);
+            });
+            return SONO_OK;
+        }
+        return finish_regions(e, e, hs, n, sample_rate, flow_khz, fhigh_khz, opt, *g, &calls_seen, d_rec, times);
     };
     PieceUpload up(e, hs, n, piece, d_rec);
     rc = up.start();
@@ -1218,8 +1221,7 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
                 group.clear();
             }
         }
-        rc = start_pending();                                // (the last group measures in line: nothing is left here)
-        if (rc == SONO_OK) rc = tails.wait();
+        rc = tails.wait();                                   // (the last group finishes in line: nothing is running here)
         if (rc) return rc;
         if (timer.on) {
             std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "waiting for pieces, fast scan", t_wait);
@@ -1230,7 +1232,9 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
         std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "region analysis (GPU)", times.analysis);
         std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "framing (host)", times.framing);
         std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "measurement (GPU + threads)", times.measurement);
-        std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "measurement beside the rest", tails.ms);
+        std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "beside the next analysis:", tails.ms);
+        std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "   framing", tail_times.framing);
+        std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "   measurement", tail_times.measurement);
     }
     return sono_full_file_results(e, out, cap, count);
 }

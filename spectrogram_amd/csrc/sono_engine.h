@@ -154,8 +154,11 @@ struct sono_engine {
     // device scratch of the detector front end (sono_capi_detect.hip)
     sono::DevBuf d_db, d_flags, d_edges, d_runs, d_count, d_select_tmp;
     sono::DevBuf d_rec;                     // sono_process_full_file: the whole recording, resident from the fast scan on
-    sono::HostBuf h_filtered;               // ... and the host copy of its high-passed regions, packed region after region (pinned, kept)
-    std::vector<uint32_t> frame_tables;     // ... and the per-frame records of its regions (six 4-byte arrays)
+    // ... and, per group of regions, the host copy of its high-passed regions, packed region after region (pinned, kept),
+    // and the per-frame records of its regions (six 4-byte arrays): two sets, one for the group whose calls are being
+    // framed, one for the group being analysed meanwhile
+    sono::HostBuf h_filtered[2];
+    std::vector<uint32_t> frame_tables[2];
     std::vector<sono_segment> scan_segments;   // ... and the fast scan's segments (one per half frame at most)
     sono::HostBuf h_in, h_out;              // staging of the whole-file passes (packed samples; records / dB matrices)
     // The measurement stage's two slots: one batch is measured on host threads while the next is on the GPU.
@@ -177,7 +180,7 @@ struct sono_engine {
     bool no_upload_overlap = false;         // engine option "no_upload_overlap": whole-file detection uploads the recording in one piece, then scans and analyses it
     bool small_upload_pieces = false;       // engine option "small_upload_pieces": pieces of 64 fft sizes instead of 2^26 samples (tests: many pieces from a short recording)
     bool host_measure = false;              // engine option "host_measure": the calls' dB matrices go to the host and are measured there
-    bool no_measure_overlap = false;        // engine option "no_measure_overlap": whole-file detection measures a group's calls before it analyses the next group
+    bool no_measure_overlap = false;        // engine option "no_measure_overlap": whole-file detection frames and measures a group's calls before it analyses the next group
     sono_engine *measure_engine = nullptr;  // whole-file detection: the companion (same fft size and window) on whose stream and buffers a group's calls are measured beside the next group's analysis; created on first use
     // pinned pieces of upload_host_array, each guarded by an event recorded behind its copy to the device
     struct UploadSlot {

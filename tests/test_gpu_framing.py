@@ -386,9 +386,9 @@ def test_upload_beside_the_analysis_changes_nothing(golden):
     measured while the next pieces are on their way.  With pieces of 64 fft sizes (engine option "small_upload_pieces")
     a few seconds of audio are cut into dozens of pieces -- runs and regions straddle the cuts, some pieces hold no
     region at all -- and every call equals the one-piece form's ("no_upload_overlap") bit for bit, region numbers
-    included; so does the reference's TypeError.  The groups of regions (six at a time here) measure their calls on a
-    thread and a companion engine beside the next group's framing, or in line ("no_measure_overlap"): same calls, same
-    error."""
+    included; so does the reference's TypeError.  The groups of regions (six at a time here) have their calls framed and
+    measured on a thread (the measurement on a companion engine) beside the next group's analysis, or in line
+    ("no_measure_overlap"): same calls, same error."""
     import spectrogram_amd.framing as frm
     from spectrogram_amd import measure as ms
     g, meta = golden
@@ -409,7 +409,7 @@ def test_upload_beside_the_analysis_changes_nothing(golden):
     for x, rate, flow, fhigh, opt, cfg in recordings:
         for samples in (x, np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)):
             got = []
-            # one piece; pieces, a group's calls measured beside the next group's framing; pieces, one thing at a time
+            # one piece; pieces, a group's calls framed and measured beside the next group's analysis; pieces, one thing at a time
             for pieces, in_line in ((False, False), (True, False), (True, True)):
                 e.set_option("no_upload_overlap", not pieces)
                 e.set_option("small_upload_pieces", pieces)
