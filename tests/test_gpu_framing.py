@@ -363,6 +363,18 @@ def test_measurement_on_the_gpu_equals_the_host_stage():
             assert np.array_equal(got[0].view(np.uint64), got[1].view(np.uint64)), cfg         # NaNs included
             seen += got[0].shape[0]
     assert seen > 200, (seen, threw)
+    # a minute of the same over louder noise and a weak tone: more calls that end in the noise, where the searches'
+    # stops and the harmonics' detours are decided
+    x = _mixed_calls(sr, 60.0, 11)
+    rng = np.random.default_rng(12)
+    x += (0.01 * rng.standard_normal(len(x))).astype(np.float32)
+    x += (0.002 * np.sin(2 * np.pi * 61000 * np.arange(len(x)) / sr)).astype(np.float32)
+    got = []
+    for host in (True, False):
+        e.set_option("host_measure", host)
+        got.append(frm.process_full_file_table(e, x, sr, 10.0, 128.0, {"threshold_dB": -50.0}, {"debugMode": True}, file_id=3))
+    assert got[0].shape == got[1].shape and got[0].shape[0] > 400, got[0].shape
+    assert np.array_equal(got[0].view(np.uint64), got[1].view(np.uint64))
     # the 16-bit entry point takes the same way
     q = np.clip(np.round(_mixed_calls(sr, 6.0, 9) * 32768), -32768, 32767).astype(np.int16)
     e.set_option("host_measure", True)
