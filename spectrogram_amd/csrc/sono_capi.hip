@@ -228,10 +228,10 @@ void sono_engine_destroy(sono_engine *e)
     e->d_db.release(); e->d_flags.release(); e->d_edges.release(); e->d_runs.release();
     e->d_count.release(); e->d_select_tmp.release();
     e->h_in.release(); e->h_out.release();
+    e->d_refine.release(); e->h_refine.release();
     for (auto &slot : e->measure_slot) slot.release();
     e->d_measure_tables.release(); e->d_measure_scratch.release();
     for (auto &slot : e->upload_slot) slot.release();
-    for (auto &buf : e->h_filtered) buf.release();
     for (auto &slot : e->ragged) {
         if (slot.done) { (void)hipEventSynchronize(slot.done); (void)hipEventDestroy(slot.done); }
         slot.buf.release();
@@ -328,11 +328,11 @@ int sono_engine_release_memory(sono_engine *e)
     e->d_in.release(); e->d_out.release(); e->d_peak_bin.release(); e->d_peak_mag.release();
     e->d_mags.release(); e->d_bank.release(); e->d_rec.release();
     e->d_db.release(); e->d_flags.release(); e->d_edges.release(); e->d_runs.release(); e->d_select_tmp.release();
-    e->h_in.release(); e->h_out.release(); e->full_file_calls.clear(); e->full_file_calls.shrink_to_fit();
+    e->h_in.release(); e->h_out.release(); e->d_refine.release(); e->h_refine.release();
+    e->full_file_calls.clear(); e->full_file_calls.shrink_to_fit();
     for (auto &slot : e->measure_slot) slot.release();
     e->d_measure_tables.release(); e->d_measure_scratch.release();
     for (auto &slot : e->upload_slot) slot.release();
-    for (auto &buf : e->h_filtered) buf.release();
     for (auto &tables : e->frame_tables) { tables.clear(); tables.shrink_to_fit(); }
     e->scan_segments.clear(); e->scan_segments.shrink_to_fit();
     e->full_file_slices.clear(); e->full_file_slices.shrink_to_fit();

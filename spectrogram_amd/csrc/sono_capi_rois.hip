@@ -108,18 +108,13 @@ struct HostSamples {
     const float *x = nullptr;
     const int16_t *q = nullptr;
     uint32_t channels = 1, channel = 0;
-    // The high-passed regions as the GPU packed them, one after the other (sono_process_full_file): region r's samples
-    // start at packed[packed_at[r]] where packed_at[r] >= 0.  Takes the place of an x_filtered laid out like the recording.
-    const float *packed = nullptr;
-    const int64_t *packed_at = nullptr;
 };
 // -> sample 0 of region r as floats: the high-passed copy where the region went through the filter, the caller's
 // floats, or the region's 16-bit samples converted into `tmp` (exact: a division by a power of two).
 const float *region_samples(const HostSamples &hs, const float *x_filtered, const sono_segment *rois, const sono_roi_table *t,
                             size_t r, double sample_rate, std::vector<float> &tmp)
 {
-    if (hs.packed && hs.packed_at[r] >= 0) return hs.packed + hs.packed_at[r];
-    const float *src = region_audio(hs.x, hs.packed ? nullptr : x_filtered, t, r, sample_rate);
+    const float *src = region_audio(hs.x, x_filtered, t, r, sample_rate);
     if (src) return src + rois[r].start;
     const size_t len = (size_t)(rois[r].end - rois[r].start);
     tmp.resize(len);
@@ -214,13 +209,8 @@ int sono_roi_rows(const sono_segment *rois, size_t n_rois, uint32_t fft_size, do
 // afterwards gets what region_audio() would pick on the host.
 static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segment *rois, size_t n_rois, double sample_rate,
                         double flow_khz, double fhigh_khz, double hop_percent, int auto_highpass, sono_roi_table *out,
-                        size_t frames_cap, float *x_filtered, float *d_rec, std::vector<int64_t> *packed_at = nullptr,
-                        sono::HostBuf *packed_to = nullptr)
+                        size_t frames_cap, float *x_filtered, float *d_rec)
 {
-    // packed_at (with d_rec): the filtered samples come back into pinned memory the engine keeps (packed_to), packed
-    // region after region as the filter kernel wrote them, and packed_at[r] says where region r's begin (-1: not
-    // filtered) -- nothing is scattered to the samples' places in a recording-sized host array.
-    if (packed_at) packed_at->assign(n_rois, -1);
     if (!e || !out || (n && !x && !d_rec) || (n_rois && !rois)) return fail(SONO_EINVAL, "sono_analyze_rois: NULL argument");
     if (!(sample_rate > 0)) return fail(SONO_EINVAL, "sono_analyze_rois: sample_rate must be positive");
     if (n_rois && (!out->row0 || !out->zonal || !out->highpass_khz))
@@ -408,38 +398,14 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
     HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jb, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_coefs, coefs, sizeof(coefs), hipMemcpyHostToDevice, s));
     HIP_TRY(sono::launch_highpass_regions(d_all, (float *)e->d_runs.p, d_jobs, jobs.size(), d_coefs, d_rec != nullptr, s));
-    // The filtered samples go back to the host (in pieces of whole regions through the pinned staging area, then to
-    // their places in x_filtered) on a thread and a stream of their own while this thread runs the second pass.
+    // Where the caller wants them (x_filtered; a whole-file detection does not: it frames its calls on the resident
+    // recording), the filtered samples go back to the host (in pieces of whole regions through the pinned staging area,
+    // then to their places in x_filtered) on a thread and a stream of their own while this thread runs the second pass.
     std::thread copier;
     int copy_status = SONO_OK;
     hipStream_t down = nullptr;
     hipEvent_t filtered = nullptr;
-    if (packed_at) {
-        for (size_t k = 0; k < jobs.size(); ++k) (*packed_at)[job_region[k]] = (int64_t)jobs[k].dst;
-        if (!packed_to) packed_to = &e->h_filtered[0];
-        if (!packed_to->reserve(filtered_samples * sizeof(float)))
-            return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
-        HIP_TRY(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&filtered, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(filtered, s));
-        HIP_TRY(hipStreamWaitEvent(down, filtered, 0));
-        // In pieces, each queued when the one before it has arrived: the second pass's own small copies to the host
-        // share the copy engine and would otherwise wait behind the whole of it.
-        const int device = e->device;
-        copier = std::thread([&, device]() {
-            if (hipSetDevice(device) != hipSuccess) { copy_status = SONO_EDEVICE; return; }
-            const size_t piece = (size_t)8 << 20;                // samples
-            for (size_t at = 0; at < filtered_samples; at += piece) {
-                const size_t count = std::min(piece, filtered_samples - at);
-                if (hipMemcpyAsync((float *)packed_to->p + at, (const float *)e->d_runs.p + at, count * sizeof(float),
-                                   hipMemcpyDeviceToHost, down) != hipSuccess || hipStreamSynchronize(down) != hipSuccess) {
-                    (void)hipGetLastError();
-                    copy_status = SONO_EDEVICE;
-                    return;
-                }
-            }
-        });
-    } else if (x_filtered) {
+    if (x_filtered) {
         HIP_TRY(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&filtered, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(filtered, s));
@@ -521,14 +487,22 @@ int sono_analyze_rois(sono_engine *e, const float *x, size_t n, const sono_segme
 }
 
 
+// Where the oscillogram refinement finds a recording that lies in HBM (sono_process_full_file: the resident recording
+// with the high-passed regions in place): the engine on whose stream and buffers the windows are summed.
+struct ResidentRecording { sono_engine *e; const float *d_rec; };
+
 static int frame_roi_calls(const HostSamples &hs, const float *x_filtered, size_t n, const sono_segment *rois, size_t n_rois,
                            const sono_roi_table *t, double sample_rate, uint32_t fft_size, double call_threshold_db,
                            double min_call_duration_ms, sono_roi_call *out, size_t cap, size_t *count,
-                           std::vector<sono_roi_call> *grown = nullptr)
+                           std::vector<sono_roi_call> *grown = nullptr, const ResidentRecording *resident = nullptr)
 {
     // grown: the calls go into this vector, sized to what was found, instead of out[0..cap)
+    // resident: the samples are read in HBM, not on the host.  The calls' spans follow from the per-frame records alone,
+    // so the regions are walked twice: once to list the spans the refinement will ask about, then -- the window
+    // energies of all of them summed in one launch, 8 bytes per window back instead of the samples themselves --
+    // for the calls.
     if (count) *count = 0;
-    if (!t || (n && !hs.x && !hs.q) || (n_rois && (!rois || !t->row0)) || !(sample_rate > 0) || fft_size == 0)
+    if (!t || (n && !hs.x && !hs.q && !resident) || (n_rois && (!rois || !t->row0)) || !(sample_rate > 0) || fft_size == 0)
         return fail(SONO_EINVAL, "sono_frame_roi_calls: NULL or non-positive argument");
     for (size_t r = 0; r < n_rois; ++r)
         if (t->row0[r + 1] > t->row0[r] && (rois[r].end > n || rois[r].end < rois[r].start))
@@ -538,6 +512,13 @@ static int frame_roi_calls(const HostSamples &hs, const float *x_filtered, size_
     std::vector<std::vector<sono_roi_call>> per_region(n_rois);
     std::atomic<size_t> next{0};
     std::atomic<bool> low_rate{false};
+    // resident: per region the spans with windows to sum (in the order the refinement asks), then where each region's
+    // first span's sums begin
+    std::vector<std::vector<sono::RefinePlan>> spans(resident ? n_rois : 0);
+    std::vector<size_t> sums_at(resident ? n_rois + 1 : 0);
+    std::vector<std::vector<Cand>> kept_of(resident ? n_rois : 0);      // the candidates the echo filter kept, per region
+    const double *sums = nullptr;
+    bool listing = resident != nullptr;                      // first walk: list the spans, make no calls
     auto work = [&]() {
         std::vector<double> tf;
         std::vector<float> converted;
@@ -549,39 +530,58 @@ static int frame_roi_calls(const HostSamples &hs, const float *x_filtered, size_
             const float *pdb = t->peak_db + row;
             tf.resize(F);
             for (size_t f = 0; f < F; ++f) tf[f] = ((double)f * (double)t->hop + (double)fft_size / 2) / sample_rate;    // js:1350-1351
-            float gmax = -INFINITY;
-            for (size_t f = 0; f < F; ++f) if (pdb[f] > gmax) gmax = pdb[f];           // js:1544-1550
-            const double threshold = (double)gmax + call_threshold_db;                  // js:1553
-            cands.clear();
-            size_t f = 0;
-            while (f < F) {                                                             // maximal runs of active frames, js:1556-1595
-                if (!((double)pdb[f] > threshold)) { ++f; continue; }
-                size_t g = f;
-                while (g + 1 < F && (double)pdb[g + 1] > threshold) ++g;
-                if (!(tf[g] - tf[f] < min_call_duration_ms / 1000)) {                   // js:688-689
-                    size_t pk = f;
-                    for (size_t k = f; k <= g; ++k) if (pdb[k] > pdb[pk]) pk = k;       // first maximum, js:695-703
-                    cands.push_back({f, g, pk, (double)pdb[pk], tf[pk]});
+            if (resident && !listing) {
+                kept = kept_of[r];                                                      // found on the first walk
+            } else {
+                float gmax = -INFINITY;
+                for (size_t f = 0; f < F; ++f) if (pdb[f] > gmax) gmax = pdb[f];       // js:1544-1550
+                const double threshold = (double)gmax + call_threshold_db;              // js:1553
+                cands.clear();
+                size_t f = 0;
+                while (f < F) {                                                         // maximal runs of active frames, js:1556-1595
+                    if (!((double)pdb[f] > threshold)) { ++f; continue; }
+                    size_t g = f;
+                    while (g + 1 < F && (double)pdb[g + 1] > threshold) ++g;
+                    if (!(tf[g] - tf[f] < min_call_duration_ms / 1000)) {               // js:688-689
+                        size_t pk = f;
+                        for (size_t k = f; k <= g; ++k) if (pdb[k] > pdb[pk]) pk = k;   // first maximum, js:695-703
+                        cands.push_back({f, g, pk, (double)pdb[pk], tf[pk]});
+                    }
+                    f = g + 1;
                 }
-                f = g + 1;
-            }
-            std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.power > b.power; });   // js:714
-            kept.clear();
-            for (const Cand &c : cands) {                                               // js:720-734
-                bool close = false;
-                for (const Cand &k : kept) if (std::fabs(c.time - k.time) < 0.030) { close = true; break; }
-                if (!close) kept.push_back(c);
+                std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.power > b.power; });   // js:714
+                kept.clear();
+                for (const Cand &c : cands) {                                           // js:720-734
+                    bool close = false;
+                    for (const Cand &k : kept) if (std::fabs(c.time - k.time) < 0.030) { close = true; break; }
+                    if (!close) kept.push_back(c);
+                }
+                if (resident) kept_of[r] = kept;
             }
             const double offset = (double)rois[r].start / sample_rate;                  // js:737
-            const float *audio = kept.empty() ? nullptr : region_samples(hs, x_filtered, rois, t, r, sample_rate, converted);
+            const size_t region_len = (size_t)(rois[r].end - rois[r].start);
+            const float *audio = kept.empty() || resident ? nullptr : region_samples(hs, x_filtered, rois, t, r, sample_rate, converted);
+            size_t asked = 0;                                // spans with windows met so far in this region
+            const sono::RefineFn refine = [&](int64_t start_sample, int64_t end_sample, int64_t *refined) {
+                *refined = end_sample;
+                sono::RefinePlan plan;
+                const int planned = sono::host_refine_plan(region_len, sample_rate, start_sample, end_sample, plan);
+                if (planned <= 0) return planned == 0;
+                if (listing) { spans[r].push_back(plan); return true; }
+                size_t at = sums_at[r];
+                for (size_t k = 0; k < asked; ++k) at += spans[r][k].steps;
+                ++asked;
+                *refined = sono::host_refine_from_sums(plan, sums + at, end_sample);
+                return true;
+            };
             for (const Cand &c : kept) {
                 const sono::FrameRun run{c.s, c.e};
-                if (!sono::host_frame_calls(&run, 1, tf.data(), F, audio,
-                                            (size_t)(rois[r].end - rois[r].start), sample_rate,
-                                            fft_size, 5.0, min_call_duration_ms, true, framed)) {        // js:743-810
+                if (!sono::host_frame_calls(&run, 1, tf.data(), F, audio, region_len, sample_rate,
+                                            fft_size, 5.0, min_call_duration_ms, true, framed, resident ? &refine : nullptr)) {   // js:743-810
                     low_rate = true;
                     return;
                 }
+                if (listing) continue;
                 for (const sono::CallFrame &k : framed) {
                     size_t pk = (size_t)k.start_frame;
                     for (size_t q = pk; q <= (size_t)k.end_frame; ++q) if (pdb[q] > pdb[pk]) pk = q;
@@ -611,11 +611,60 @@ static int frame_roi_calls(const HostSamples &hs, const float *x_filtered, size_
     };
     const unsigned int nt = (unsigned int)std::min<size_t>(sono::host_threads(),
                                                            std::max<size_t>(n_rois / 64, 1));
-    std::vector<std::thread> pool;
-    for (unsigned int w = 1; w < nt; ++w) pool.emplace_back(work);
-    work();
-    for (std::thread &th : pool) th.join();
+    auto walk = [&]() {
+        next = 0;
+        std::vector<std::thread> pool;
+        for (unsigned int w = 1; w < nt; ++w) pool.emplace_back(work);
+        work();
+        for (std::thread &th : pool) th.join();
+    };
+    StageTimer timer("sono_frame_roi_calls");
+    timer.lap("set up");
+    walk();
     if (low_rate) return fail(SONO_EINVAL, "sono_frame_roi_calls: sample rate below 20 kHz (the 0.1 ms window has no hop)");
+    if (resident) {
+        timer.lap("spans listed");
+        // the spans' windows, summed where the samples lie
+        sono_engine *e = resident->e;
+        size_t n_spans = 0, windows = 0;
+        for (size_t r = 0; r < n_rois; ++r) {
+            sums_at[r] = windows;
+            n_spans += spans[r].size();
+            for (const sono::RefinePlan &p : spans[r]) windows += p.steps;
+        }
+        sums_at[n_rois] = windows;
+        if (n_spans) {
+            DeviceGuard guard(e->device);
+            const size_t jobs_bytes = (n_spans * sizeof(sono::WindowJob) + 255) / 256 * 256, sums_bytes = windows * sizeof(double);
+            if (!e->h_refine.reserve(jobs_bytes + sums_bytes))
+                return fail(SONO_ENOMEM, "sono_frame_roi_calls: cannot allocate host staging memory");
+            HIP_TRY(e->d_refine.reserve(jobs_bytes + sums_bytes));
+            sono::WindowJob *jobs = (sono::WindowJob *)e->h_refine.p;
+            uint32_t window = 0, hop = 0;
+            size_t k = 0, at = 0;
+            for (size_t r = 0; r < n_rois; ++r)
+                for (const sono::RefinePlan &p : spans[r]) {
+                    const uint64_t first = rois[r].start + (uint64_t)p.safe_start;
+                    if (first + (uint64_t)(p.steps - 1) * (uint64_t)p.hop + (uint64_t)p.window > rois[r].end)
+                        return fail(SONO_EINVAL, "sono_frame_roi_calls: a span's windows leave its region");
+                    jobs[k++] = {first, at, (uint32_t)p.steps, 0u};
+                    at += p.steps;
+                    window = (uint32_t)p.window; hop = (uint32_t)p.hop;          // the same for every span: they follow from the sample rate
+                }
+            hipStream_t s = e->stream;
+            char *d = (char *)e->d_refine.p;
+            HIP_TRY(hipMemcpyAsync(d, jobs, n_spans * sizeof(sono::WindowJob), hipMemcpyHostToDevice, s));
+            HIP_TRY(sono::launch_window_sums(resident->d_rec, (const sono::WindowJob *)d, n_spans, window, hop, (double *)(d + jobs_bytes), s));
+            HIP_TRY(hipMemcpyAsync((char *)e->h_refine.p + jobs_bytes, d + jobs_bytes, sums_bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            sums = (const double *)((const char *)e->h_refine.p + jobs_bytes);
+        }
+        timer.lap("windows summed (GPU)");
+        listing = false;
+        walk();
+        timer.lap("calls framed");
+        if (low_rate) return fail(SONO_EINVAL, "sono_frame_roi_calls: sample rate below 20 kHz (the 0.1 ms window has no hop)");
+    }
     size_t made = 0;
     if (grown) {
         size_t found = 0;
@@ -629,6 +678,7 @@ static int frame_roi_calls(const HostSamples &hs, const float *x_filtered, size_
             return fail(SONO_ECAPACITY, "sono_frame_roi_calls: output buffer too small");
         for (const sono_roi_call &k : per_region[r]) out[made++] = k;
     }
+    timer.lap("calls joined");
     if (count) *count = made;
     return SONO_OK;
 }
@@ -867,16 +917,14 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filter
 struct StageTimes { double analysis = 0, framing = 0, measurement = 0; };
 // What is left to do for a group of regions once they are analysed -- the framing of their calls, the calls'
 // measurement and what follows it -- with everything it reads: it can run beside the next group's analysis.  The
-// per-frame records (t's arrays) and the packed filtered samples lie in one of the engine's two sets of buffers;
-// the next group's analysis writes the other.
+// per-frame records (t's arrays) lie in one of the engine's two sets of tables; the next group's analysis writes the
+// other.
 struct GroupTail {
     std::vector<sono_segment> rois;
     std::vector<uint64_t> row0;
     std::vector<float> hp;
     std::vector<double> zonal;
     sono_roi_table t{};
-    const float *packed = nullptr;           // the high-passed regions' samples, region after region (pinned, the engine's)
-    std::vector<int64_t> packed_at;          // per region: where its samples begin in `packed`, -1 = not filtered
     size_t roi_base = 0;
 };
 
@@ -902,12 +950,10 @@ static int analyze_regions(sono_engine *e, const HostSamples &hs, size_t n, doub
     g.hp.resize(n_rois + 1);
     g.zonal.resize((n_rois + 1) * SONO_MAX_ZONES);
     g.t = sono_roi_table{g.row0.data(), peak_db, peak_bin, left, right, ilo, ihi, g.zonal.data(), g.hp.data(), 0, 0, 0, 0};
-    // The samples of the regions that went through the automatic high-pass come back packed (HostSamples::packed): the
-    // framing stage reads a region's samples from there, and nothing the size of the recording is kept on the host.
-    rc = analyze_rois(e, hs.x, n, rois, n_rois, sample_rate, flow_khz, fhigh_khz, opt->hop_percent, 1, &g.t, total, nullptr, d_rec, &g.packed_at,
-                      &e->h_filtered[set]);
+    // The automatic high-pass filters its regions where they lie in the resident recording, and there they stay: the
+    // framing stage has the GPU sum the windows it asks about, and no sample returns to the host.
+    rc = analyze_rois(e, hs.x, n, rois, n_rois, sample_rate, flow_khz, fhigh_khz, opt->hop_percent, 1, &g.t, total, nullptr, d_rec);
     if (rc) return rc;
-    g.packed = (const float *)e->h_filtered[set].p;
     times.analysis += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SONO_OK;
 }
@@ -927,11 +973,9 @@ static int finish_regions(sono_engine *e, sono_engine *em, const HostSamples &hs
     // the list is sized by the framing: a bound from the frame count would be hundreds of MB of fresh pages
     std::vector<sono_roi_call> framed;
     size_t n_calls = 0;
-    HostSamples framed_from = hs;
-    framed_from.packed = g.packed;
-    framed_from.packed_at = g.packed_at.data();
-    int rc = frame_roi_calls(framed_from, nullptr, n, g.rois.data(), g.rois.size(), &g.t, sample_rate, e->N, opt->call_threshold_db,
-                             opt->min_call_duration_ms, nullptr, 0, &n_calls, &framed);
+    const ResidentRecording resident{em, d_rec};
+    int rc = frame_roi_calls(hs, nullptr, n, g.rois.data(), g.rois.size(), &g.t, sample_rate, e->N, opt->call_threshold_db,
+                             opt->min_call_duration_ms, nullptr, 0, &n_calls, &framed, &resident);
     if (rc) return rc;
     lap(times.framing);
     std::vector<sono_call_measurement> meas(n_calls + 1);

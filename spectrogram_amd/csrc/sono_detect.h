@@ -104,6 +104,12 @@ hipError_t launch_band_linear_sum(const float *d_db, size_t frames, uint32_t nb,
 hipError_t sort_floats(void *d_temp, size_t &temp_bytes, const float *d_in, float *d_out, size_t count, hipStream_t s);
 
 // Interleaved PCM -> one f32 channel.  Integer samples are divided by 2^(bits-1); 8-bit WAV is unsigned.
+// One span of a recording whose end the oscillogram refinement looks for: its windows' energies go to
+// sums[out .. out + steps); window i covers samples first + i * hop .. + window - 1 of the recording.
+struct WindowJob { uint64_t first, out; uint32_t steps, pad; };
+hipError_t launch_window_sums(const float *d_x, const WindowJob *d_jobs, size_t n_jobs, uint32_t window, uint32_t hop, double *d_sums,
+                              hipStream_t s);
+
 hipError_t launch_pcm_to_f32(const void *d_pcm, size_t frames, uint32_t channels, uint32_t channel, uint32_t bits,
                              int is_float, float *d_out, hipStream_t s);
 

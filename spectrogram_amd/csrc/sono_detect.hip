@@ -791,6 +791,33 @@ __global__ __launch_bounds__(kThreads) void pcm16_mono_to_f32_kernel(const uint3
     }
 }
 
+// The window energies of refineEndUsingOscillogram (batCallDetector.js:1676-1683) for many spans of a recording in
+// HBM: a wave per span, a lane per window, the window's squares added in order in double as the host does
+// (host_window_sums: the square of a float is exact in a double, so a fused multiply-add rounds like the sum alone).
+__global__ __launch_bounds__(kThreads) void window_sums_kernel(const float *x, const WindowJob *jobs, size_t n_jobs, uint32_t window,
+                                                               uint32_t hop, double *sums)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t waves = (size_t)gridDim.x * kRowsPerBlock;
+    for (size_t j = (size_t)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6); j < n_jobs; j += waves) {
+        const WindowJob job = jobs[j];
+        for (uint32_t i = lane; i < job.steps; i += 64) {
+            const float *p = x + job.first + (size_t)i * hop;
+            double acc = 0.0;
+            for (uint32_t k = 0; k < window; ++k) { const double v = (double)p[k]; acc = fma(v, v, acc); }
+            sums[job.out + i] = acc;
+        }
+    }
+}
+
+hipError_t launch_window_sums(const float *d_x, const WindowJob *d_jobs, size_t n_jobs, uint32_t window, uint32_t hop, double *d_sums,
+                              hipStream_t s)
+{
+    if (n_jobs == 0) return hipSuccess;
+    hipLaunchKernelGGL(window_sums_kernel, dim3(rows_grid_capped(n_jobs)), dim3(kThreads), 0, s, d_x, d_jobs, n_jobs, window, hop, d_sums);
+    return hipGetLastError();
+}
+
 hipError_t launch_pcm_to_f32(const void *d_pcm, size_t frames, uint32_t channels, uint32_t channel, uint32_t bits,
                              int is_float, float *d_out, hipStream_t s)
 {

@@ -154,13 +154,13 @@ struct sono_engine {
     // device scratch of the detector front end (sono_capi_detect.hip)
     sono::DevBuf d_db, d_flags, d_edges, d_runs, d_count, d_select_tmp;
     sono::DevBuf d_rec;                     // sono_process_full_file: the whole recording, resident from the fast scan on
-    // ... and, per group of regions, the host copy of its high-passed regions, packed region after region (pinned, kept),
-    // and the per-frame records of its regions (six 4-byte arrays): two sets, one for the group whose calls are being
-    // framed, one for the group being analysed meanwhile
-    sono::HostBuf h_filtered[2];
+    // ... and, per group of regions, the per-frame records of its regions (six 4-byte arrays): two sets, one for the
+    // group whose calls are being framed, one for the group being analysed meanwhile
     std::vector<uint32_t> frame_tables[2];
     std::vector<sono_segment> scan_segments;   // ... and the fast scan's segments (one per half frame at most)
     sono::HostBuf h_in, h_out;              // staging of the whole-file passes (packed samples; records / dB matrices)
+    sono::DevBuf d_refine;                  // call framing on a resident recording: the spans whose windows are summed, and the sums
+    sono::HostBuf h_refine;                 // ... and their host side (pinned, kept)
     // The measurement stage's two slots: one batch is measured on host threads while the next is on the GPU.
     struct MeasureSlot {
         sono::HostBuf h_in, h_out;          // packed samples of the batch's calls; their dB matrices

@@ -23,29 +23,34 @@ void host_savitzky_golay(const double *in, size_t n, double *out)
     }
 }
 
-bool host_refine_end(const float *audio, size_t n, double sample_rate, int64_t start_sample, int64_t end_sample,
-                     int64_t *refined)
+int host_refine_plan(size_t n, double sample_rate, int64_t start_sample, int64_t end_sample, RefinePlan &p)
 {
-    *refined = end_sample;
     const int64_t safe_start = start_sample > 0 ? start_sample : 0;              // js:1650
     const int64_t safe_end = end_sample < (int64_t)n ? end_sample : (int64_t)n;
-    if ((double)(safe_end - safe_start) < sample_rate * 0.0005) return true;     // js:1653
-    const int64_t window = (int64_t)std::floor(sample_rate * (0.1 / 1000));      // js:1660
-    const int64_t sustained = (int64_t)std::floor(sample_rate * (0.5 / 1000));   // js:1663
-    const int64_t hop = window / 2;                                              // js:1664
-    if (hop < 1) return false;
-    // The window energies first (js:1676-1683).  A window's sum runs over its samples in order, one rounding per sample,
-    // so it cannot be split; but the windows are independent, and four of them are summed side by side.
-    const int64_t span = safe_end - window - safe_start;
-    const size_t steps = span > 0 ? (size_t)((span + hop - 1) / hop) : 0;
-    if (steps == 0) return true;
+    if ((double)(safe_end - safe_start) < sample_rate * 0.0005) return 0;        // js:1653
+    p.window = (int64_t)std::floor(sample_rate * (0.1 / 1000));                  // js:1660
+    p.sustained = (int64_t)std::floor(sample_rate * (0.5 / 1000));               // js:1663
+    p.hop = p.window / 2;                                                        // js:1664
+    if (p.hop < 1) return -1;
+    const int64_t span = safe_end - p.window - safe_start;
+    p.steps = span > 0 ? (size_t)((span + p.hop - 1) / p.hop) : 0;
+    p.safe_start = safe_start;
+    return p.steps == 0 ? 0 : 1;
+}
+
+// The window energies (js:1676-1683).  A window's sum runs over its samples in order, one rounding per sample, so it
+// cannot be split; but the windows are independent, and eight of them are summed side by side.
+void host_window_sums(const float *audio, const RefinePlan &p, double *sums)
+{
+    const size_t steps = p.steps;
+    const int64_t window = p.window, hop = p.hop;
     // Every sample lies in two windows: its square (exact in a double: 24-bit factors) is formed once, two per instruction.
     static thread_local std::vector<double> scratch;
     const size_t covered = (size_t)((int64_t)(steps - 1) * hop + window);
-    if (scratch.size() < covered + steps) scratch.resize(covered + steps);
-    double *sq = scratch.data(), *sums = sq + covered;
+    if (scratch.size() < covered) scratch.resize(covered);
+    double *sq = scratch.data();
     {
-        const float *a = audio + safe_start;
+        const float *a = audio + p.safe_start;
         size_t i = 0;
         for (; i + 4 <= covered; i += 4) {
             const __m128 v = _mm_loadu_ps(a + i);
@@ -72,9 +77,17 @@ bool host_refine_end(const float *audio, size_t n, double sample_rate, int64_t s
         for (int64_t j = 0; j < window; ++j) a0 += q0[j];
         sums[k] = a0;
     }
+}
+
+int64_t host_refine_from_sums(const RefinePlan &p, const double *sums, int64_t end_sample)
+{
+    const size_t steps = p.steps;
+    const int64_t window = p.window, hop = p.hop, sustained = p.sustained, safe_start = p.safe_start;
     // dB of one window (js:1685), worked out when it is first asked for: the walk below ends soon after the call does
-    std::vector<float> db_values(steps);                                         // Float32Array, js:1669
-    std::vector<char> have(steps, 0);
+    static thread_local std::vector<float> db_values;                            // Float32Array, js:1669
+    static thread_local std::vector<char> have;
+    if (db_values.size() < steps) db_values.resize(steps);
+    have.assign(steps, 0);
     auto db_exact = [&](size_t i) { return 20 * std::log10(std::sqrt(sums[i] / (double)window) + 1e-9); };
     auto db_at = [&](size_t i) {
         if (!have[i]) { db_values[i] = (float)db_exact(i); have[i] = 1; }
@@ -107,16 +120,30 @@ bool host_refine_end(const float *audio, size_t n, double sample_rate, int64_t s
     for (size_t i = peak_index + 1; i < steps; ++i) {
         const double cur = db_at(i);
         if (cur < min_db) { min_db = cur; min_index = i; }
-        if (min_db < -60 && cur < -60 + 2) { *refined = centre(min_index); return true; }     // js:1714
+        if (min_db < -60 && cur < -60 + 2) return centre(min_index);             // js:1714
         if (cur - min_db > 0.5) {                                                // js:1722-1723
             if (min_db > -32) continue;                                          // js:1728: still inside the signal body
             const size_t limit = steps < i + ahead ? steps : i + ahead;          // js:1744
             bool is_sustained = true;
             for (size_t q = i + 1; q < limit; ++q)
                 if (db_at(q) < min_db + 0.5) { is_sustained = false; break; }
-            if (is_sustained) { *refined = centre(min_index); return true; }     // js:1798
+            if (is_sustained) return centre(min_index);                          // js:1798
         }
     }
+    return end_sample;
+}
+
+bool host_refine_end(const float *audio, size_t n, double sample_rate, int64_t start_sample, int64_t end_sample,
+                     int64_t *refined)
+{
+    *refined = end_sample;
+    RefinePlan p;
+    const int planned = host_refine_plan(n, sample_rate, start_sample, end_sample, p);
+    if (planned <= 0) return planned == 0;
+    static thread_local std::vector<double> sums;
+    if (sums.size() < p.steps) sums.resize(p.steps);
+    host_window_sums(audio, p, sums.data());
+    *refined = host_refine_from_sums(p, sums.data(), end_sample);
     return true;
 }
 
@@ -200,7 +227,7 @@ void host_scan_spectrum(const float *row, const float *fb, size_t n, double thr,
 
 bool host_frame_calls(const FrameRun *segs, size_t count, const double *tf, size_t frames, const float *audio, size_t n,
                       double sample_rate, uint32_t fft_size, double padding_ms, double min_ms, bool full_file_rules,
-                      std::vector<CallFrame> &out)
+                      std::vector<CallFrame> &out, const RefineFn *refine)
 {
     out.clear();
     if (frames < 2) return true;                 // the reference has no defined behaviour for a one-frame matrix
@@ -217,7 +244,8 @@ bool host_frame_calls(const FrameRun *segs, size_t count, const double *tf, size
         const int64_t start_sample = (int64_t)std::floor(tf[safe_start] * sample_rate);       // js:1158-1159
         const int64_t end_sample = (int64_t)std::floor(tf[safe_end] * sample_rate);
         int64_t refined = end_sample;
-        if (!host_refine_end(audio, n, sample_rate, start_sample, end_sample, &refined)) return false;
+        if (!(refine ? (*refine)(start_sample, end_sample, &refined) : host_refine_end(audio, n, sample_rate, start_sample, end_sample, &refined)))
+            return false;
         if (refined < end_sample) {
             const double t_end = (double)refined / sample_rate;                  // js:1170
             int64_t new_end = safe_end;

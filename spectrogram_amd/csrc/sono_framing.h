@@ -6,6 +6,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <functional>
 #include <vector>
 
 namespace sono {
@@ -17,6 +18,20 @@ void host_savitzky_golay(const double *in, size_t n, double *out);
 // sample rate is too low for the 0.1 ms RMS window to have a hop of at least one sample.
 bool host_refine_end(const float *audio, size_t n, double sample_rate, int64_t start_sample, int64_t end_sample,
                      int64_t *refined);
+// The same in its three parts, for callers whose samples lie elsewhere (the GPU sums the windows of a whole
+// recording's calls in one launch): the windows of a span, their energies, and the walk over them.
+struct RefinePlan {
+    int64_t safe_start = 0;                  // first sample of the first window, in the audio the span counts in
+    int64_t window = 0, hop = 0, sustained = 0;
+    size_t steps = 0;                        // windows: window i covers samples safe_start + i * hop ... + window - 1
+};
+// 1: p is filled and has at least one window; 0: nothing to refine, the end stays where it is; -1: the sample rate is
+// too low for the window to have a hop.  n: samples of the audio.
+int host_refine_plan(size_t n, double sample_rate, int64_t start_sample, int64_t end_sample, RefinePlan &p);
+// sums[i] = the squares of window i's samples, added in order in double (js:1676-1683).  audio: sample 0 of the plan's count.
+void host_window_sums(const float *audio, const RefinePlan &p, double *sums);
+// The refined end sample (end_sample where the walk finds no earlier end), js:1685-1803.
+int64_t host_refine_from_sums(const RefinePlan &p, const double *sums, int64_t end_sample);
 
 // calculateAutoHighpassFilterFreq (batCallDetector.js:4028-4035), kHz.
 double host_auto_highpass_khz(double peak_khz);
@@ -35,9 +50,11 @@ struct CallFrame {
 struct FrameRun { uint64_t start, end; };
 // The per-segment part of detectCalls (batCallDetector.js:1128-1208; padding 3 ms, both duration filters) or,
 // with full_file_rules, of processFullFile (batCallDetector.js:739-810; padding 5 ms, only the <= 1 ms discard).
+// refine (or nullptr: host_refine_end on audio): answers refineEndUsingOscillogram for a span of the n samples.
+using RefineFn = std::function<bool(int64_t start_sample, int64_t end_sample, int64_t *refined)>;
 bool host_frame_calls(const FrameRun *segs, size_t count, const double *time_frames, size_t frames, const float *audio,
                       size_t n, double sample_rate, uint32_t fft_size, double padding_ms, double min_call_duration_ms,
-                      bool full_file_rules, std::vector<CallFrame> &out);
+                      bool full_file_rules, std::vector<CallFrame> &out, const RefineFn *refine = nullptr);
 
 // Peak frequency of measureFrequencyParameters' first step (batCallDetector.js:3021-3036), kHz: the peak bin's
 // centre, moved by a parabola through the peak and its two neighbours where it has both (interior = true).
