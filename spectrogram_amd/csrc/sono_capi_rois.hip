@@ -509,29 +509,38 @@ static int frame_roi_calls(const HostSamples &hs, const float *x_filtered, size_
             return fail(SONO_EINVAL, "sono_frame_roi_calls: region outside the recording");
     struct Cand { uint64_t s, e, peak_frame; double power, time; };
     // Regions are independent: they are shared out over host threads and their calls joined in region order.
-    std::vector<std::vector<sono_roi_call>> per_region(n_rois);
+    // What the threads find goes into lists of their own (a list per region would be tens of thousands of small
+    // allocations, made by one thread and released by another); a region knows whose list holds its entries and where.
+    const unsigned int nt = (unsigned int)std::min<size_t>(sono::host_threads(), std::max<size_t>(n_rois / 64, 1));
+    struct Found {
+        std::vector<sono_roi_call> calls;
+        std::vector<Cand> kept;                              // resident: the candidates the echo filter kept ...
+        std::vector<sono::RefinePlan> spans;                 // ... and the spans with windows to sum, in the order the refinement asks
+    };
+    struct Where { uint32_t owner = 0, calls_owner = 0; size_t calls_at = 0, calls_n = 0, kept_at = 0, kept_n = 0, spans_at = 0, spans_n = 0; };
+    std::vector<Found> found(nt);
+    std::vector<Where> where(n_rois);
     std::atomic<size_t> next{0};
     std::atomic<bool> low_rate{false};
-    // resident: per region the spans with windows to sum (in the order the refinement asks), then where each region's
-    // first span's sums begin
-    std::vector<std::vector<sono::RefinePlan>> spans(resident ? n_rois : 0);
-    std::vector<size_t> sums_at(resident ? n_rois + 1 : 0);
-    std::vector<std::vector<Cand>> kept_of(resident ? n_rois : 0);      // the candidates the echo filter kept, per region
+    std::vector<size_t> sums_at(resident ? n_rois + 1 : 0);  // resident: where each region's first span's sums begin
     const double *sums = nullptr;
     bool listing = resident != nullptr;                      // first walk: list the spans, make no calls
-    auto work = [&]() {
+    auto work = [&](unsigned int me) {
         std::vector<double> tf;
         std::vector<float> converted;
         std::vector<sono::CallFrame> framed;
         std::vector<Cand> cands, kept;
+        Found &mine = found[me];
         for (size_t r = next.fetch_add(1); r < n_rois; r = next.fetch_add(1)) {
             const size_t row = (size_t)t->row0[r], F = (size_t)(t->row0[r + 1] - t->row0[r]);
             if (F == 0) continue;
             const float *pdb = t->peak_db + row;
             tf.resize(F);
             for (size_t f = 0; f < F; ++f) tf[f] = ((double)f * (double)t->hop + (double)fft_size / 2) / sample_rate;    // js:1350-1351
-            if (resident && !listing) {
-                kept = kept_of[r];                                                      // found on the first walk
+            Where &here = where[r];
+            if (resident && !listing) {                                                 // found on the first walk
+                const Cand *first = found[here.owner].kept.data() + here.kept_at;
+                kept.assign(first, first + here.kept_n);
             } else {
                 float gmax = -INFINITY;
                 for (size_t f = 0; f < F; ++f) if (pdb[f] > gmax) gmax = pdb[f];       // js:1544-1550
@@ -556,8 +565,15 @@ static int frame_roi_calls(const HostSamples &hs, const float *x_filtered, size_
                     for (const Cand &k : kept) if (std::fabs(c.time - k.time) < 0.030) { close = true; break; }
                     if (!close) kept.push_back(c);
                 }
-                if (resident) kept_of[r] = kept;
+                if (resident) {
+                    here.owner = me;
+                    here.kept_at = mine.kept.size(); here.kept_n = kept.size();
+                    mine.kept.insert(mine.kept.end(), kept.begin(), kept.end());
+                    here.spans_at = mine.spans.size(); here.spans_n = 0;
+                }
             }
+            const sono::RefinePlan *listed = resident && !listing ? found[here.owner].spans.data() + here.spans_at : nullptr;
+            if (!listing) { here.calls_owner = me; here.calls_at = mine.calls.size(); here.calls_n = 0; }
             const double offset = (double)rois[r].start / sample_rate;                  // js:737
             const size_t region_len = (size_t)(rois[r].end - rois[r].start);
             const float *audio = kept.empty() || resident ? nullptr : region_samples(hs, x_filtered, rois, t, r, sample_rate, converted);
@@ -567,9 +583,9 @@ static int frame_roi_calls(const HostSamples &hs, const float *x_filtered, size_
                 sono::RefinePlan plan;
                 const int planned = sono::host_refine_plan(region_len, sample_rate, start_sample, end_sample, plan);
                 if (planned <= 0) return planned == 0;
-                if (listing) { spans[r].push_back(plan); return true; }
+                if (listing) { mine.spans.push_back(plan); ++here.spans_n; return true; }
                 size_t at = sums_at[r];
-                for (size_t k = 0; k < asked; ++k) at += spans[r][k].steps;
+                for (size_t k = 0; k < asked; ++k) at += listed[k].steps;
                 ++asked;
                 *refined = sono::host_refine_from_sums(plan, sums + at, end_sample);
                 return true;
@@ -585,8 +601,9 @@ static int frame_roi_calls(const HostSamples &hs, const float *x_filtered, size_
                 for (const sono::CallFrame &k : framed) {
                     size_t pk = (size_t)k.start_frame;
                     for (size_t q = pk; q <= (size_t)k.end_frame; ++q) if (pdb[q] > pdb[pk]) pk = q;
-                    per_region[r].emplace_back();
-                    sono_roi_call &o = per_region[r].back();
+                    mine.calls.emplace_back();
+                    ++here.calls_n;
+                    sono_roi_call &o = mine.calls.back();
                     o.roi = r; o.start_frame = k.start_frame; o.end_frame = k.end_frame; o.peak_frame = pk;
                     o.start_time_s = k.start_time_s + offset;                           // js:822-823
                     o.end_time_s = k.end_time_s + offset;
@@ -609,13 +626,11 @@ static int frame_roi_calls(const HostSamples &hs, const float *x_filtered, size_
             }
         }
     };
-    const unsigned int nt = (unsigned int)std::min<size_t>(sono::host_threads(),
-                                                           std::max<size_t>(n_rois / 64, 1));
     auto walk = [&]() {
         next = 0;
         std::vector<std::thread> pool;
-        for (unsigned int w = 1; w < nt; ++w) pool.emplace_back(work);
-        work();
+        for (unsigned int w = 1; w < nt; ++w) pool.emplace_back(work, w);
+        work(0);
         for (std::thread &th : pool) th.join();
     };
     StageTimer timer("sono_frame_roi_calls");
@@ -627,10 +642,11 @@ static int frame_roi_calls(const HostSamples &hs, const float *x_filtered, size_
         // the spans' windows, summed where the samples lie
         sono_engine *e = resident->e;
         size_t n_spans = 0, windows = 0;
+        auto spans_of = [&](size_t r) { return found[where[r].owner].spans.data() + where[r].spans_at; };
         for (size_t r = 0; r < n_rois; ++r) {
             sums_at[r] = windows;
-            n_spans += spans[r].size();
-            for (const sono::RefinePlan &p : spans[r]) windows += p.steps;
+            n_spans += where[r].spans_n;
+            for (size_t k = 0; k < where[r].spans_n; ++k) windows += spans_of(r)[k].steps;
         }
         sums_at[n_rois] = windows;
         if (n_spans) {
@@ -643,7 +659,8 @@ static int frame_roi_calls(const HostSamples &hs, const float *x_filtered, size_
             uint32_t window = 0, hop = 0;
             size_t k = 0, at = 0;
             for (size_t r = 0; r < n_rois; ++r)
-                for (const sono::RefinePlan &p : spans[r]) {
+                for (size_t q = 0; q < where[r].spans_n; ++q) {
+                    const sono::RefinePlan &p = spans_of(r)[q];
                     const uint64_t first = rois[r].start + (uint64_t)p.safe_start;
                     if (first + (uint64_t)(p.steps - 1) * (uint64_t)p.hop + (uint64_t)p.window > rois[r].end)
                         return fail(SONO_EINVAL, "sono_frame_roi_calls: a span's windows leave its region");
@@ -667,16 +684,18 @@ static int frame_roi_calls(const HostSamples &hs, const float *x_filtered, size_
     }
     size_t made = 0;
     if (grown) {
-        size_t found = 0;
-        for (size_t r = 0; r < n_rois; ++r) found += per_region[r].size();
-        grown->resize(found);
+        size_t total = 0;
+        for (const Found &f : found) total += f.calls.size();
+        grown->resize(total);
         out = grown->data();
-        cap = found;
+        cap = total;
     }
-    for (size_t r = 0; r < n_rois; ++r) {
-        if (made + per_region[r].size() > cap || (!out && !per_region[r].empty()))
+    for (size_t r = 0; r < n_rois; ++r) {                    // in the order of the regions
+        const Where &here = where[r];
+        if (made + here.calls_n > cap || (!out && here.calls_n))
             return fail(SONO_ECAPACITY, "sono_frame_roi_calls: output buffer too small");
-        for (const sono_roi_call &k : per_region[r]) out[made++] = k;
+        const sono_roi_call *first = found[here.calls_owner].calls.data() + here.calls_at;
+        for (size_t k = 0; k < here.calls_n; ++k) out[made++] = first[k];
     }
     timer.lap("calls joined");
     if (count) *count = made;
