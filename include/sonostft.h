@@ -600,7 +600,11 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filter
  * = peak + 80 dB, quality, region time -> file time).  Calls come in the reference's order (per region, strongest
  * first).  SONO_EREFERENCE: SONO_DEBUG_MODE is not set and the reference would raise on one of the calls (its promise rejects).
  * The recording is read from the caller's memory by a second thread for the length of the call (it crosses the link
- * in pieces while the pieces that have arrived are worked on); x must stay unchanged until the call returns. */
+ * in pieces while the pieces that have arrived are worked on); x must stay unchanged until the call returns.  A third
+ * thread frames and measures the calls of one group of regions while the next group is analysed (the measurement on a
+ * companion engine the engine creates on first use and keeps: engine option "no_measure_overlap").  No sample returns
+ * to the host: the automatic high-pass filters the resident recording in place, and what the framing stage needs of
+ * the samples (the energies of 0.1 ms windows, js:1676-1683) is summed on the GPU. */
 typedef struct sono_full_file_options {
     double threshold_db;            /* options.threshold_dB of the fast scan, reference default -60 */
     double padding_ms;              /* options.padding_ms of mergeAndPadSegments, default 5 */
