@@ -606,6 +606,24 @@ int sono_stft_mag_f32_ragged_dev(sono_engine *e, const sono_ragged_batch *in, ui
     return run_ragged(e, in, noverlap, sono::MODE_MAG, a, hip_stream, "sono_stft_mag_f32_ragged_dev");
 }
 
+}  // extern "C"
+
+// sono_stft_mag_f32_ragged_dev for a caller that reads bins lo..hi of the rows only (the detector's region analysis and
+// measurement: 316 of 512 bins at the usual band): the other bins need not be written, and at the analysis hop the
+// kernel's time is the rows' way to HBM.
+int sono::stft_mag_ragged_band(sono_engine *e, const sono_ragged_batch *in, uint32_t noverlap, uint32_t lo, uint32_t hi, float *d_out)
+{
+    if (!e || !d_out || noverlap >= e->N) return fail(SONO_EINVAL, "stft_mag_ragged_band: bad argument");
+    sono::StftArgs a;
+    fill_common(e, noverlap, a);
+    a.out_mag = d_out;
+    if (hi >= lo && hi < e->N / 2) { a.band_lo = lo; a.band_hi = hi; }
+    if (const int rc = check_aligned(d_out, 16, "stft_mag_ragged_band", "d_out")) return rc;
+    return run_ragged(e, in, noverlap, sono::MODE_MAG, a, nullptr, "stft_mag_ragged_band");
+}
+
+extern "C" {
+
 int sono_stft_band_active_dev(sono_engine *e, const sono_batch *in, uint32_t noverlap, uint32_t min_bin, uint32_t max_bin,
                               double target_energy_sum, uint8_t *d_active, double *d_band_energy, void *hip_stream)
 {

@@ -133,7 +133,7 @@ int peaks_enqueue(sono_engine *e, const float *d_src, const std::vector<uint64_t
     HIP_TRY(e->d_mags.reserve(frames * bins * sizeof(float)));
     HIP_TRY(e->d_out.reserve(frames * sizeof(sono::FramePeak)));
     sono_ragged_batch rb{d_src, off.size(), off.data(), len.data()};
-    int rc = sono_stft_mag_f32_ragged_dev(e, &rb, b.noverlap, (float *)e->d_mags.p, nullptr);
+    int rc = sono::stft_mag_ragged_band(e, &rb, b.noverlap, b.min_bin, b.min_bin + b.nb - 1, (float *)e->d_mags.p);
     if (rc) return rc;
     if (sono::db_peaks_fits(b.nb)) {
         // nobody reads the dB matrix of a region but the peak records (and the noise floors, which convert their six
@@ -819,7 +819,7 @@ static int measure_roi_calls(sono_engine *e, const float *x, const float *x_filt
             HIP_TRY(hipMemcpyAsync(slot.d_in.p, slot.h_in.p, bt.samples * sizeof(float), hipMemcpyHostToDevice, s));
         }
         sono_ragged_batch rb{d_rec ? d_rec : (const float *)slot.d_in.p, cnt, bt.off.data(), bt.len.data()};
-        int rc = sono_stft_mag_f32_ragged_dev(e, &rb, b.noverlap, (float *)e->d_mags.p, nullptr);
+        int rc = sono::stft_mag_ragged_band(e, &rb, b.noverlap, b.min_bin, b.min_bin + b.nb - 1, (float *)e->d_mags.p);
         if (rc) return rc;
         rc = sono_detect_power_db_dev(e, (const float *)e->d_mags.p, bt.frames, bins, b.min_bin, b.nb, (float *)slot.d_db.p, nullptr);
         if (rc) return rc;

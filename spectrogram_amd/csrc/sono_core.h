@@ -60,7 +60,7 @@ struct StftArgs {
     float inv_n;                  // 1/N: |2X| * inv_n = |X| * 2/N (lib.rs:150)
     float q_a, q_c;               // code = round(q_a * log2(max(|2X|^2, q_floor)) + q_c), saturated to [0,255] (make_quant)
     float q_floor;                // 0 = no floor (it would not change any code, see make_quant)
-    unsigned int band_lo, band_hi;   // MODE_BAND: bins band_lo..band_hi (inclusive, band_hi < N/2)
+    unsigned int band_lo, band_hi;   // MODE_BAND: bins band_lo..band_hi (inclusive, band_hi < N/2); MODE_MAG, tiled kernel, band_hi > 0: only the bins the caller will read (more may be written)
     double band_target;              // MODE_BAND: a frame is active iff its band energy > band_target
     // MODE_BANK: the bank's non-zero taps as bank_taps() lists them (tap k of filter i at k * filters + i, filters with
     // fewer taps padded with weight 0), at most kBankLdsTaps entries; rows of `bank_filters` codes go to out_u8

@@ -132,6 +132,9 @@ private:
 // h_src may be changed after the call returns.  Small arrays take the plain copy.
 int upload_host_array(sono_engine *e, void *d_dst, const void *h_src, size_t bytes, hipStream_t s, unsigned int threads = 0);
 
+// sono_stft_mag_f32_ragged_dev on the engine's stream, for a caller that reads bins lo..hi of the rows only (sono_capi.hip).
+int stft_mag_ragged_band(sono_engine *e, const sono_ragged_batch *in, uint32_t noverlap, uint32_t lo, uint32_t hi, float *d_out);
+
 // fastScanSegmentsWasm (batCallDetector.js:878-949) on a recording that already lies in HBM (sono_capi_detect.hip).
 int fast_scan_resident(sono_engine *e, const float *d_x, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
                        double threshold_db, sono_segment *out, size_t cap, size_t *count);

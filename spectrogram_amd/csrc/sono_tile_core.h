@@ -774,10 +774,15 @@ struct TileLane {
                 constexpr int i = decltype(i_)::value;
                 float p[4] = {p4[i].x * fix, p4[i].y, p4[i].z, p4[i].w};
                 if (MODE == MODE_MAG) {
-                    float4 o;
-                    o.x = fast_sqrt(p[0]) * a.inv_n; o.y = fast_sqrt(p[1]) * a.inv_n;
-                    o.z = fast_sqrt(p[2]) * a.inv_n; o.w = fast_sqrt(p[3]) * a.inv_n;
-                    *(float4 *)((a.out_mag + tile_elem) + ((size_t)lane_elem + 2 * G::R1 * (m0 + i))) = o;
+                    // a caller that reads a band of the rows only (band_hi > 0) gets the groups of four bins that
+                    // touch it; the rest of the matrix keeps what it held
+                    const unsigned int k0 = (unsigned int)(4 * l + 2 * G::R1 * (m0 + i));
+                    if (a.band_hi == 0u || (k0 + 3u >= a.band_lo && k0 <= a.band_hi)) {
+                        float4 o;
+                        o.x = fast_sqrt(p[0]) * a.inv_n; o.y = fast_sqrt(p[1]) * a.inv_n;
+                        o.z = fast_sqrt(p[2]) * a.inv_n; o.w = fast_sqrt(p[3]) * a.inv_n;
+                        *(float4 *)((a.out_mag + tile_elem) + ((size_t)lane_elem + 2 * G::R1 * (m0 + i))) = o;
+                    }
                 } else {
                     if (MODE == MODE_U8 && a.out_u8) {
                         unsigned int packed = quantise<FLOOR, 0>(p[0], qa, qc, a.q_floor);
