@@ -453,6 +453,43 @@ def test_upload_beside_the_analysis_changes_nothing(golden):
     e.free()
 
 
+def test_a_sample_rate_too_low_for_the_oscillogram_window_is_refused_on_every_way():
+    """refineEndUsingOscillogram's RMS window is 0.1 ms with a hop of half of it (batCallDetector.js:1660-1664): below
+    20 kHz the hop has no sample and the reference's loop would never advance.  The library refuses such a recording
+    with SONO_EINVAL wherever the refinement is reached: in the whole-file detection, whose windows are summed on the
+    GPU -- piece by piece, with a group's calls framed on a thread of its own, and in one piece --, and in the batched
+    form that frames on the host."""
+    import spectrogram_amd.framing as frm
+    sr = 16000
+    rng = np.random.default_rng(5)
+    x = (0.001 * rng.standard_normal(4 * sr)).astype(np.float32)
+    for k in range(8):                                                            # loud bursts of 30 ms at 4 kHz
+        at = int((0.2 + 0.45 * k) * sr)
+        n = int(0.03 * sr)
+        x[at:at + n] += (0.5 * np.hanning(n) * np.sin(2 * np.pi * 4000 * np.arange(n) / sr)).astype(np.float32)
+    e = sa.SpectrogramEngine(256, "hann")
+    opt, cfg = {"threshold_dB": -40.0}, {"debugMode": True}
+    for pieces, in_line in ((False, False), (True, False), (True, True)):
+        e.set_option("no_upload_overlap", not pieces)
+        e.set_option("small_upload_pieces", pieces)
+        e.set_option("no_measure_overlap", in_line)
+        with pytest.raises(sa.SonoError) as err:
+            frm.process_full_file_native(e, x, sr, 1.0, 7.0, opt, cfg)
+        assert err.value.status == sa.SONO_EINVAL and "20 kHz" in str(err.value), err.value
+    with pytest.raises(sa.SonoError) as err:
+        frm.process_full_file_batched(e, x, sr, 1.0, 7.0, opt, cfg)
+    assert err.value.status == sa.SONO_EINVAL and "20 kHz" in str(err.value), err.value
+    # the engine is as good as new afterwards
+    e.set_option("no_upload_overlap", False)
+    e.set_option("small_upload_pieces", False)
+    e.set_option("no_measure_overlap", False)
+    y = _mixed_calls(384000, 2.0, 31)
+    e2 = sa.SpectrogramEngine(1024, "hann")
+    assert len(frm.process_full_file_native(e2, y, 384000, 10.0, 128.0, {"threshold_dB": -50.0}, cfg)) > 5
+    e.free()
+    e2.free()
+
+
 def test_rms_based_snr(golden):
     g, meta = golden
     e = sa.SpectrogramEngine(1024, "hann")
