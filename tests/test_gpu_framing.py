@@ -434,6 +434,23 @@ def test_upload_beside_the_analysis_changes_nothing(golden):
             assert got[0] == got[1] == got[2], (len(x), opt, cfg)
             rows_seen += len(got[0]) if isinstance(got[0], list) else 0
     assert rows_seen > 200
+    # with the calls' spectrograms kept (the measurement then runs on host threads, and the tail hands the rows on)
+    x, rate, flow, fhigh, opt, cfg = recordings[0]
+    kept = []
+    for pieces, in_line in ((False, False), (True, False), (True, True)):
+        e.set_option("no_upload_overlap", not pieces)
+        e.set_option("small_upload_pieces", pieces)
+        e.set_option("no_measure_overlap", in_line)
+        kept.append(frm.process_full_file_native(e, x, rate, flow, fhigh, opt, cfg, keep_spectrograms=True))
+    assert len(kept[0]) > 20 and len(kept[0]) == len(kept[1]) == len(kept[2])
+    for a, b, c in zip(*kept):
+        assert a.keys() == b.keys() == c.keys()
+        for key, va in a.items():
+            for vo in (b[key], c[key]):
+                if isinstance(va, (list, tuple, np.ndarray)):
+                    assert len(va) == len(vo) and all(np.array_equal(np.asarray(p), np.asarray(q), equal_nan=True) for p, q in zip(va, vo)), key
+                else:
+                    assert va == vo or (va != va and vo != vo), key
     # one channel of an interleaved 16-bit recording, piece by piece
     x = _mixed_calls(sr, 3.0, 26)
     q = np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)
