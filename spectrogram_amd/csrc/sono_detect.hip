@@ -578,6 +578,12 @@ __global__ __launch_bounds__(kThreads) void zone_floors_regions_kernel(const flo
 
 // in_place != 0: the filtered samples also replace the region's own samples in src (regions are disjoint, and a
 // sample is read before it is written).
+//
+// A lane per region, and a region is a serial recurrence: what the kernel can do about its time is not to wait for
+// memory once per sample.  Samples are fetched sixteen at a time, the next sixteen before the current ones are worked
+// on (the loads do not depend on the recurrence; written out by hand because the in-place form makes the output alias
+// the input, and a load may then not be moved above a store by the compiler): 2.2 -> 0.6 ms for regions of 6 000 samples.
+constexpr int kHighpassBlock = 16;
 __global__ __launch_bounds__(64) void highpass_regions_kernel(const float *src, float *dst, const HighpassJob *jobs,
                                                               size_t n_jobs, const HighpassCoef *coefs, int in_place)
 {
@@ -590,9 +596,9 @@ __global__ __launch_bounds__(64) void highpass_regions_kernel(const float *src, 
     float *z = in_place ? const_cast<float *>(src) + job.src : nullptr;
     double ax1 = 0, ax2 = 0, ay1 = 0, ay2 = 0;      // first section
     double bx1 = 0, bx2 = 0, by1 = 0, by2 = 0;      // second section
-    for (unsigned long long i = 0; i < job.len; ++i) {
+    auto filter = [&](float sample) {
         // y0 = b0*x0 + b1*x1 + b2*x2 - a1*y1 - a2*y2, left to right, nothing fused (js:4131)
-        const double x0 = (double)x[i];
+        const double x0 = (double)sample;
         double s1 = __dadd_rn(__dmul_rn(c.b0, x0), __dmul_rn(c.b1, ax1));
         s1 = __dadd_rn(s1, __dmul_rn(c.b2, ax2));
         s1 = __dsub_rn(s1, __dmul_rn(c.a1, ay1));
@@ -604,8 +610,35 @@ __global__ __launch_bounds__(64) void highpass_regions_kernel(const float *src, 
         s2 = __dsub_rn(s2, __dmul_rn(c.a1, by1));
         s2 = __dsub_rn(s2, __dmul_rn(c.a2, by2));
         bx2 = bx1; bx1 = m; by2 = by1; by1 = s2;
-        y[i] = (float)s2;
-        if (z) z[i] = (float)s2;
+        return (float)s2;
+    };
+    const unsigned long long len = job.len, blocks = len / kHighpassBlock;
+    float cur[kHighpassBlock], nxt[kHighpassBlock];
+    if (blocks) {
+#pragma unroll
+        for (int j = 0; j < kHighpassBlock; ++j) cur[j] = x[j];
+    }
+    for (unsigned long long b = 0; b < blocks; ++b) {
+        const unsigned long long i = b * kHighpassBlock;
+        if (b + 1 < blocks) {
+#pragma unroll
+            for (int j = 0; j < kHighpassBlock; ++j) nxt[j] = x[i + kHighpassBlock + j];
+        }
+        float out[kHighpassBlock];
+#pragma unroll
+        for (int j = 0; j < kHighpassBlock; ++j) out[j] = filter(cur[j]);
+#pragma unroll
+        for (int j = 0; j < kHighpassBlock; ++j) {
+            y[i + j] = out[j];
+            if (z) z[i + j] = out[j];
+        }
+#pragma unroll
+        for (int j = 0; j < kHighpassBlock; ++j) cur[j] = nxt[j];
+    }
+    for (unsigned long long i = blocks * kHighpassBlock; i < len; ++i) {
+        const float v = filter(x[i]);
+        y[i] = v;
+        if (z) z[i] = v;
     }
 }
 
