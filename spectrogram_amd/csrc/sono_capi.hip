@@ -229,6 +229,8 @@ void sono_engine_destroy(sono_engine *e)
     e->d_count.release(); e->d_select_tmp.release();
     e->h_in.release(); e->h_out.release();
     e->d_refine.release(); e->h_refine.release();
+    e->d_frame_table.release();
+    for (auto &tables : e->frame_tables) tables.release();
     for (auto &slot : e->measure_slot) slot.release();
     e->d_measure_tables.release(); e->d_measure_scratch.release();
     for (auto &slot : e->upload_slot) slot.release();
@@ -333,7 +335,8 @@ int sono_engine_release_memory(sono_engine *e)
     for (auto &slot : e->measure_slot) slot.release();
     e->d_measure_tables.release(); e->d_measure_scratch.release();
     for (auto &slot : e->upload_slot) slot.release();
-    for (auto &tables : e->frame_tables) { tables.clear(); tables.shrink_to_fit(); }
+    for (auto &tables : e->frame_tables) tables.release();
+    e->d_frame_table.release();
     e->scan_segments.clear(); e->scan_segments.shrink_to_fit();
     e->full_file_slices.clear(); e->full_file_slices.shrink_to_fit();
     if (e->pipe) { sono::stream_pipe_destroy(e->pipe); e->pipe = nullptr; }

@@ -151,6 +151,57 @@ int peaks_enqueue(sono_engine *e, const float *d_src, const std::vector<uint64_t
     return SONO_OK;
 }
 
+// peaks_enqueue for bands that db_peaks_fits: the records go straight into the regions' table in HBM (`table`), span by
+// span (spans[i]: rows of the batch's matrix -> entries of the table; built by the caller into slot.h_spans), and what
+// the automatic high-pass asks about each span comes back in slot.h_out when `want_best`.  Nothing waited for.
+int peaks_enqueue_spans(sono_engine *e, const float *d_src, const std::vector<uint64_t> &off, const std::vector<uint64_t> &len,
+                        const Band &b, size_t frames, size_t n_spans, const sono::PeakTable &table, sono_engine::MeasureSlot &slot,
+                        bool want_best)
+{
+    const uint32_t N = e->N, bins = N / 2;
+    HIP_TRY(e->d_mags.reserve(frames * bins * sizeof(float)));
+    sono_ragged_batch rb{d_src, off.size(), off.data(), len.data()};
+    int rc = sono::stft_mag_ragged_band(e, &rb, b.noverlap, b.min_bin, b.min_bin + b.nb - 1, (float *)e->d_mags.p);
+    if (rc) return rc;
+    const size_t sb = n_spans * sizeof(sono::PeakSpan), bb = n_spans * sizeof(sono::SpanBest);
+    HIP_TRY(slot.d_spans.reserve(sb + bb + 8));
+    sono::PeakSpan *d_spans = (sono::PeakSpan *)slot.d_spans.p;
+    sono::SpanBest *d_best = (sono::SpanBest *)((char *)slot.d_spans.p + sb);
+    HIP_TRY(hipMemcpyAsync(d_spans, slot.h_spans.p, sb, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(sono::launch_db_peaks_spans((const float *)e->d_mags.p, d_spans, n_spans, bins, b.min_bin, b.nb, N, table,
+                                        want_best ? d_best : nullptr, e->stream));
+    if (want_best) {
+        if (!slot.h_out.reserve((bb ? bb : 1))) return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
+        HIP_TRY(hipMemcpyAsync(slot.h_out.p, d_best, bb, hipMemcpyDeviceToHost, e->stream));
+    }
+    return SONO_OK;
+}
+
+// The spans of a run of regions: region i (rows[i] = its first entry in the table, F(i) rows) starts at row `row` of the
+// batch's matrix; spans of at most kPeakSpanRows rows, region after region.  region_of (optional): span -> i.
+template <typename FramesOf>
+bool build_spans(size_t cnt, const std::vector<uint64_t> &rows, FramesOf &&frames_of, sono::HostBuf &h_spans, size_t *n_spans,
+                 std::vector<uint32_t> *region_of)
+{
+    size_t n = 0;
+    for (size_t i = 0; i < cnt; ++i) n += (frames_of(i) + sono::kPeakSpanRows - 1) / sono::kPeakSpanRows;
+    if (!h_spans.reserve((n ? n : 1) * sizeof(sono::PeakSpan))) return false;
+    sono::PeakSpan *sp = (sono::PeakSpan *)h_spans.p;
+    if (region_of) region_of->resize(n);
+    size_t row = 0, k = 0;
+    for (size_t i = 0; i < cnt; ++i) {
+        const size_t F = frames_of(i);
+        for (size_t f = 0; f < F; f += sono::kPeakSpanRows, ++k) {
+            sp[k] = sono::PeakSpan{(unsigned long long)(row + f), (unsigned long long)(rows[i] + f),
+                                   (uint32_t)std::min<size_t>(sono::kPeakSpanRows, F - f), 0u};
+            if (region_of) (*region_of)[k] = (uint32_t)i;
+        }
+        row += F;
+    }
+    *n_spans = n;
+    return true;
+}
+
 // peaks_collect: the records (arrived: the caller has waited) -> the table's six arrays, the regions shared out over
 // host threads.  feat_rows[i] = where region i's records go in the host arrays.
 void peaks_collect(sono_engine *e, const std::vector<uint64_t> &len, const std::vector<uint64_t> &feat_rows, const Band &b,
@@ -255,6 +306,31 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
     DeviceGuard guard(e->device);
     hipStream_t s = e->stream;
     StageTimer timer("sono_analyze_rois");
+    // Bands of up to 512 bins: the GPU files the per-frame records into the six arrays of the table itself (in HBM),
+    // the second pass overwrites the filtered regions' entries there, and the finished arrays reach `out` in six plain
+    // copies at the end; of the first pass only a few numbers per region come back (noise floors; the loudest frame's
+    // bin, for the automatic high-pass).  Wider bands go through the dB matrix and per-row records the host files.
+    const bool on_device = sono::db_peaks_fits(b.nb);
+    sono::PeakTable table{};
+    if (on_device && total) {
+        HIP_TRY(e->d_frame_table.reserve(6 * total * sizeof(float)));
+        float *base = (float *)e->d_frame_table.p;
+        table = sono::PeakTable{base, (int32_t *)(base + total), base + 2 * total, base + 3 * total, (int32_t *)(base + 4 * total),
+                                (int32_t *)(base + 5 * total)};
+    }
+    auto download_table = [&]() -> int {
+        if (!on_device || !total) return SONO_OK;
+        const size_t bytes = total * sizeof(float);
+        HIP_TRY(hipMemcpyAsync(out->peak_db, table.db, bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->peak_bin, table.bin, bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->peak_left_db, table.left, bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->peak_right_db, table.right, bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->inst_lo_bin, table.lo12, bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out->inst_hi_bin, table.hi12, bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        timer.lap("table to the host");
+        return SONO_OK;
+    };
     // All regions' samples stay in HBM for the whole call (packed, region after region): the first pass works through
     // them in batches of at most kBatchFrames frames, the automatic high-pass then filters every region that needs it
     // in ONE launch -- the filter is a serial recurrence per region, one lane each, so its time is that of the longest
@@ -278,6 +354,8 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
         std::vector<uint64_t> off, len, rows;
         std::vector<unsigned long long> first_row;           // of each region in the batch's matrices
         std::vector<unsigned int> used;                      // frames of each region that count for its noise floors (js:622-627)
+        size_t n_spans = 0;                                  // on_device: the batch's row spans, and the region of each
+        std::vector<uint32_t> span_region;
     };
     std::vector<PeakBatch> plan;
     for (size_t r0 = 0; r0 < n_rois;) {
@@ -321,7 +399,15 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
             HIP_TRY(hipMemcpyAsync(d_all + src_off[pb.r0], packed, pb.samples * sizeof(float), hipMemcpyHostToDevice, s));
         }
         if (pb.frames == 0) return SONO_OK;
-        int rc = peaks_enqueue(e, d_all, pb.off, pb.len, b, pb.frames, slot.h_out);
+        int rc;
+        if (on_device) {
+            if (!build_spans(cnt, pb.rows, [&](size_t i) { return (size_t)(out->row0[pb.r0 + i + 1] - out->row0[pb.r0 + i]); },
+                             slot.h_spans, &pb.n_spans, &pb.span_region))
+                return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
+            rc = peaks_enqueue_spans(e, d_all, pb.off, pb.len, b, pb.frames, pb.n_spans, table, slot, true);
+        } else {
+            rc = peaks_enqueue(e, d_all, pb.off, pb.len, b, pb.frames, slot.h_out);
+        }
         if (rc) return rc;
         // ---- noise floors of every region's first six frames (js:622-627), from the unfiltered spectrogram ----
         const size_t tb = cnt * sizeof(unsigned long long), ub = cnt * sizeof(unsigned int);
@@ -336,7 +422,7 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
         HIP_TRY(hipMemcpyAsync(d_fr, pb.first_row.data(), tb, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(d_used, pb.used.data(), ub, hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(d_zone, zone_of_bin.data(), b.nb, hipMemcpyHostToDevice, s));
-        if (sono::db_peaks_fits(b.nb))
+        if (on_device)
             HIP_TRY(sono::launch_zone_floors_regions_mags((const float *)e->d_mags.p, N / 2, b.min_bin, N, d_fr, d_used, cnt, b.nb,
                                                           d_zone, (uint32_t)zones, SONO_MAX_ZONES, d_floors, s));
         else
@@ -357,7 +443,18 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
         }
         HIP_TRY(hipEventSynchronize(slot.done));
         timer.lap("wait for STFT, dB, peaks, noise floors");
-        peaks_collect(e, pb.len, pb.rows, b, pb.frames, out, slot.h_out);
+        std::vector<float> span_db;                          // on_device: every region's loudest frame, joined from its spans in order
+        std::vector<int32_t> span_bin;
+        if (on_device) {
+            span_db.assign(cnt, -INFINITY); span_bin.assign(cnt, 0);
+            const sono::SpanBest *sb = (const sono::SpanBest *)slot.h_out.p;
+            for (size_t k2 = 0; k2 < pb.n_spans; ++k2) {
+                const uint32_t i = pb.span_region[k2];
+                if (sb[k2].db > span_db[i]) { span_db[i] = sb[k2].db; span_bin[i] = sb[k2].bin; }
+            }
+        } else {
+            peaks_collect(e, pb.len, pb.rows, b, pb.frames, out, slot.h_out);
+        }
         std::memcpy(out->zonal + pb.r0 * SONO_MAX_ZONES, slot.h_jobs.p, cnt * SONO_MAX_ZONES * sizeof(double));
         // ---- automatic high-pass (js:631-671): regions whose loudest bin lies at 30 kHz or above ----
         for (size_t i = 0; auto_highpass && i < cnt; ++i) {
@@ -365,8 +462,10 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
             if (F == 0) continue;
             float best = -INFINITY;
             int32_t bin = 0;
-            for (size_t f = 0; f < F; ++f)                                         // first maximum in frame order (js:635-644)
-                if (out->peak_db[pb.rows[i] + f] > best) { best = out->peak_db[pb.rows[i] + f]; bin = out->peak_bin[pb.rows[i] + f]; }
+            if (on_device) bin = span_bin[i];
+            else
+                for (size_t f = 0; f < F; ++f)                                     // first maximum in frame order (js:635-644)
+                    if (out->peak_db[pb.rows[i] + f] > best) { best = out->peak_db[pb.rows[i] + f]; bin = out->peak_bin[pb.rows[i] + f]; }
             if (bin < 0) bin = 0;
             const double cutoff = sono::host_auto_highpass_khz((double)freq_bins[bin] / 1000);          // js:646-647
             out->highpass_khz[pb.r0 + i] = (float)cutoff;
@@ -388,7 +487,7 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
         if (rc == SONO_OK) rc = collect(k);
         if (rc) { (void)hipStreamSynchronize(s); return rc; }
     }
-    if (jobs.empty()) return SONO_OK;
+    if (jobs.empty()) return download_table();
     // ---- the high-pass of all regions that need it, one launch; the filtered samples packed job after job ----
     const size_t jb = jobs.size() * sizeof(sono::HighpassJob);
     HIP_TRY(e->d_runs.reserve(filtered_samples * sizeof(float)));
@@ -436,7 +535,7 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
         });
     }
     // ---- second pass over the filtered regions, in batches, two in flight like the first ----
-    struct FilteredBatch { std::vector<uint64_t> off, len, rows; size_t frames = 0; };
+    struct FilteredBatch { std::vector<uint64_t> off, len, rows; std::vector<size_t> region_frames; size_t frames = 0; };
     std::vector<FilteredBatch> plan2;
     for (size_t k0 = 0; k0 < jobs.size();) {
         FilteredBatch fbatch;
@@ -445,6 +544,7 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
             const size_t r = job_region[k1], F = (size_t)(out->row0[r + 1] - out->row0[r]);
             if (k1 > k0 && fbatch.frames + F > kBatchFrames) break;
             fbatch.off.push_back(jobs[k1].dst); fbatch.len.push_back(jobs[k1].len); fbatch.rows.push_back(out->row0[r]);
+            fbatch.region_frames.push_back(F);
             fbatch.frames += F;
             ++k1;
         }
@@ -453,7 +553,16 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
     }
     auto enqueue2 = [&](size_t k) -> int {
         sono_engine::MeasureSlot &slot = e->measure_slot[k & 1];
-        int rc2 = peaks_enqueue(e, (const float *)e->d_runs.p, plan2[k].off, plan2[k].len, b, plan2[k].frames, slot.h_out);
+        int rc2;
+        if (on_device) {
+            // the filtered regions' records replace the first pass's in the table
+            size_t n_spans = 0;
+            if (!build_spans(plan2[k].off.size(), plan2[k].rows, [&](size_t i) { return plan2[k].region_frames[i]; }, slot.h_spans, &n_spans, nullptr))
+                return fail(SONO_ENOMEM, "sono_analyze_rois: cannot allocate host staging memory");
+            rc2 = peaks_enqueue_spans(e, (const float *)e->d_runs.p, plan2[k].off, plan2[k].len, b, plan2[k].frames, n_spans, table, slot, false);
+        } else {
+            rc2 = peaks_enqueue(e, (const float *)e->d_runs.p, plan2[k].off, plan2[k].len, b, plan2[k].frames, slot.h_out);
+        }
         if (rc2) return rc2;
         HIP_TRY(hipEventRecord(slot.done, s));
         return SONO_OK;
@@ -462,10 +571,11 @@ static int analyze_rois(sono_engine *e, const float *x, size_t n, const sono_seg
     for (size_t k = 0; k < plan2.size() && rc == SONO_OK; ++k) {
         if (k + 1 < plan2.size()) rc = enqueue2(k + 1);
         if (rc == SONO_OK && hipEventSynchronize(e->measure_slot[k & 1].done) != hipSuccess) rc = sono::hip_fail(hipGetLastError(), "hipEventSynchronize");
-        if (rc == SONO_OK) peaks_collect(e, plan2[k].len, plan2[k].rows, b, plan2[k].frames, out, e->measure_slot[k & 1].h_out);
+        if (rc == SONO_OK && !on_device) peaks_collect(e, plan2[k].len, plan2[k].rows, b, plan2[k].frames, out, e->measure_slot[k & 1].h_out);
     }
     if (rc) (void)hipStreamSynchronize(s);
     timer.lap("second pass");
+    if (rc == SONO_OK) rc = download_table();
     if (copier.joinable()) copier.join();
     if (filtered) (void)hipEventDestroy(filtered);
     if (down) (void)hipStreamDestroy(down);
@@ -962,9 +1072,9 @@ static int analyze_regions(sono_engine *e, const HostSamples &hs, size_t n, doub
     if (rc) return rc;
     const size_t total = (size_t)g.row0[n_rois];
     // six per-frame arrays, every entry of which the analysis writes: one block the engine keeps (fresh pages again)
-    std::vector<uint32_t> &tables = e->frame_tables[set];
-    if (tables.size() < 6 * (total + 1)) tables.resize(6 * (total + 1));
-    float *peak_db = (float *)tables.data(), *left = peak_db + (total + 1), *right = left + (total + 1);
+    sono::HostBuf &tables = e->frame_tables[set];
+    if (!tables.reserve(6 * (total + 1) * sizeof(uint32_t))) return fail(SONO_ENOMEM, "sono_process_full_file: cannot allocate the regions' tables");
+    float *peak_db = (float *)tables.p, *left = peak_db + (total + 1), *right = left + (total + 1);
     int32_t *peak_bin = (int32_t *)(right + (total + 1)), *ilo = peak_bin + (total + 1), *ihi = ilo + (total + 1);
     g.hp.resize(n_rois + 1);
     g.zonal.resize((n_rois + 1) * SONO_MAX_ZONES);

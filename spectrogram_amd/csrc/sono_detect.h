@@ -45,6 +45,18 @@ bool db_peaks_fits(uint32_t nb);
 hipError_t launch_db_peaks(const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin, uint32_t nb, uint32_t fft_size,
                            FramePeak *d_out, hipStream_t s);
 
+// launch_db_peaks for the rows of regions, filed where the regions' table wants them: span i covers `rows` consecutive
+// rows of the magnitude matrix from first_row on, and their records go to entries table_row ... of the six arrays of
+// `table` (device memory).  d_span_best[i] (may be nullptr) = the span's largest peak_db in row order, first one
+// kept (strict >, from -infinity; bin 0 if none), with its peak bin: the automatic high-pass's question about a region
+// (batCallDetector.js:635-644), answered span by span.  A region longer than kPeakSpanRows rows is cut into several spans.
+struct PeakSpan { unsigned long long first_row, table_row; uint32_t rows, pad; };
+struct PeakTable { float *db; int32_t *bin; float *left, *right; int32_t *lo12, *hi12; };
+struct SpanBest { float db; int32_t bin; };
+constexpr uint32_t kPeakSpanRows = 64;
+hipError_t launch_db_peaks_spans(const float *d_mags, const PeakSpan *d_spans, size_t n_spans, uint32_t bins, uint32_t min_bin,
+                                 uint32_t nb, uint32_t fft_size, const PeakTable &table, SpanBest *d_span_best, hipStream_t s);
+
 // First / last frame of every maximal run of non-zero flags, as two flag arrays.
 hipError_t launch_run_edges(const uint8_t *d_active, size_t frames, uint8_t *d_is_start, uint8_t *d_is_end,
                             hipStream_t s);

@@ -297,6 +297,63 @@ __global__ __launch_bounds__(kThreads) void frame_peaks_kernel(const float *db, 
 // frame_peaks_kernel on the dB values of a magnitude row that never leave the registers: power_db_kernel and
 // frame_peaks_kernel in one pass for rows of up to 64 * kRowRegs bins, when nobody else needs the dB matrix (the region
 // analysis: 2.5 KB of traffic per frame less).  Same values, same record.
+// One row's record; every lane of the wave returns the same one.
+template <typename ToDb>
+__device__ __forceinline__ FramePeak db_peaks_row(const float *src, uint32_t nb, int lane, ToDb &&to_db)
+{
+    float v[kRowRegs];
+    load_row(src, nb, lane, 0.0f, v);
+#pragma unroll
+    for (int k = 0; k < kRowRegs; ++k) {
+        if (64u * k < nb) v[k] = to_db(v[k]);                                // a chunk of 64 bins that the band reaches: all lanes or none
+        if ((uint32_t)lane + 64u * k >= nb) v[k] = NAN;
+    }
+    // The row's maximum by one reduction over the lanes, then every question about positions by ballots: which
+    // lanes hold the maximum (the first of them is the peak bin), which lie above peak - 12 dB (the first and the
+    // last of them are the extent).  A ballot answers for 64 bins at once and its answer is the same in every lane,
+    // so no bin numbers travel between lanes.  Same bins as frame_peaks_kernel: strict >, ascending -- the first
+    // maximum; a NaN (also the fill) is never a maximum and never above a threshold.
+    float best = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kRowRegs; ++k)
+        if (v[k] > best) best = v[k];
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        if (ov > best) best = ov;
+    }
+    int best_bin = -1, lo = 0x7FFFFFFF, hi = -1;
+    const double thr = (double)best - 12;                                    // js:3061-3073
+    const bool any = best > -INFINITY;                                       // else no entry was ever above the start value
+#pragma unroll
+    for (int k = 0; k < kRowRegs; ++k) {
+        if (64u * k >= nb) continue;
+        const unsigned long long at_peak = __ballot(any && v[k] == best);
+        if (at_peak && best_bin < 0) best_bin = 64 * k + (int)__builtin_ctzll(at_peak);
+        const unsigned long long above = __ballot((double)v[k] > thr);
+        if (above) {
+            if (lo == 0x7FFFFFFF) lo = 64 * k + (int)__builtin_ctzll(above);
+            hi = 64 * k + 63 - (int)__builtin_clzll(above);
+        }
+    }
+    // the peak's neighbours, from the lanes that hold them
+    auto value_at = [&](int bin) {
+        float r = NAN;
+#pragma unroll
+        for (int k = 0; k < kRowRegs; ++k)
+            if ((bin >> 6) == k) r = __shfl(v[k], bin & 63, 64);
+        return r;
+    };
+    if (best_bin >= 0) best = value_at(best_bin);                            // the entry met first (a -0 before a +0 stays a -0)
+    FramePeak r;
+    r.lo12 = lo == 0x7FFFFFFF ? -1 : lo;
+    r.hi12 = hi;
+    r.bin = best_bin;
+    r.db = best;
+    r.left = best_bin > 0 ? value_at(best_bin - 1) : NAN;
+    r.right = best_bin >= 0 && (uint32_t)best_bin + 1 < nb ? value_at(best_bin + 1) : NAN;
+    return r;
+}
+
 __global__ __launch_bounds__(kThreads) void db_peaks_kernel(const float *mags, size_t frames, uint32_t bins, uint32_t min_bin,
                                                             uint32_t nb, DbLaw law, FramePeak *out)
 {
@@ -305,62 +362,40 @@ __global__ __launch_bounds__(kThreads) void db_peaks_kernel(const float *mags, s
     const int lane = threadIdx.x & 63;
     auto to_db = [&](float mag) { return db_of_mag(mag, law.fft_size, law.scale, s_inv_c, s_log10_c); };
     for_each_row(frames, [&](size_t f) {
-        const float *src = mags + f * bins + min_bin;
-        float v[kRowRegs];
-        load_row(src, nb, lane, 0.0f, v);
-#pragma unroll
-        for (int k = 0; k < kRowRegs; ++k) {
-            if (64u * k < nb) v[k] = to_db(v[k]);                                // a chunk of 64 bins that the band reaches: all lanes or none
-            if ((uint32_t)lane + 64u * k >= nb) v[k] = NAN;
-        }
-        // The row's maximum by one reduction over the lanes, then every question about positions by ballots: which
-        // lanes hold the maximum (the first of them is the peak bin), which lie above peak - 12 dB (the first and the
-        // last of them are the extent).  A ballot answers for 64 bins at once and its answer is the same in every lane,
-        // so no bin numbers travel between lanes.  Same bins as frame_peaks_kernel: strict >, ascending -- the first
-        // maximum; a NaN (also the fill) is never a maximum and never above a threshold.
+        const FramePeak r = db_peaks_row(mags + f * bins + min_bin, nb, lane, to_db);
+        if (lane == 0) out[f] = r;
+    });
+}
+
+// db_peaks_kernel for rows that belong to regions: a wave takes a span of consecutive rows of one region (PeakSpan),
+// files every row's record straight into the six per-frame arrays of the regions' table (PeakTable, in HBM: the
+// caller copies the finished arrays to the host as they are, nothing is re-sorted there) and notes the span's first
+// largest peak in row order -- what the automatic high-pass asks of a region (batCallDetector.js:635-644); the caller
+// joins a region's spans in order with the same strict comparison.
+__global__ __launch_bounds__(kThreads) void db_peaks_spans_kernel(const float *mags, const PeakSpan *spans, size_t n_spans, uint32_t bins,
+                                                                  uint32_t min_bin, uint32_t nb, DbLaw law, PeakTable t, SpanBest *span_best)
+{
+    __shared__ double s_inv_c[64], s_log10_c[64];
+    stage_db_table(law.table, s_inv_c, s_log10_c);
+    const int lane = threadIdx.x & 63;
+    auto to_db = [&](float mag) { return db_of_mag(mag, law.fft_size, law.scale, s_inv_c, s_log10_c); };
+    for_each_row(n_spans, [&](size_t i) {
+        const PeakSpan sp = spans[i];
         float best = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < kRowRegs; ++k)
-            if (v[k] > best) best = v[k];
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o, 64);
-            if (ov > best) best = ov;
+        int32_t bin = 0;
+        for (uint32_t k = 0; k < sp.rows; ++k) {
+            const FramePeak r = db_peaks_row(mags + (size_t)(sp.first_row + k) * bins + min_bin, nb, lane, to_db);
+            if (r.db > best) { best = r.db; bin = r.bin; }
+            const size_t row = (size_t)sp.table_row + k;
+            // six lanes, one array each
+            if (lane == 0) t.db[row] = r.db;
+            if (lane == 1) t.bin[row] = r.bin;
+            if (lane == 2) t.left[row] = r.left;
+            if (lane == 3) t.right[row] = r.right;
+            if (lane == 4) t.lo12[row] = r.lo12;
+            if (lane == 5) t.hi12[row] = r.hi12;
         }
-        int best_bin = -1, lo = 0x7FFFFFFF, hi = -1;
-        const double thr = (double)best - 12;                                    // js:3061-3073
-        const bool any = best > -INFINITY;                                       // else no entry was ever above the start value
-#pragma unroll
-        for (int k = 0; k < kRowRegs; ++k) {
-            if (64u * k >= nb) continue;
-            const unsigned long long at_peak = __ballot(any && v[k] == best);
-            if (at_peak && best_bin < 0) best_bin = 64 * k + (int)__builtin_ctzll(at_peak);
-            const unsigned long long above = __ballot((double)v[k] > thr);
-            if (above) {
-                if (lo == 0x7FFFFFFF) lo = 64 * k + (int)__builtin_ctzll(above);
-                hi = 64 * k + 63 - (int)__builtin_clzll(above);
-            }
-        }
-        // the peak's neighbours, from the lanes that hold them
-        auto value_at = [&](int bin) {
-            float r = NAN;
-#pragma unroll
-            for (int k = 0; k < kRowRegs; ++k)
-                if ((bin >> 6) == k) r = __shfl(v[k], bin & 63, 64);
-            return r;
-        };
-        if (best_bin >= 0) best = value_at(best_bin);                            // the entry met first (a -0 before a +0 stays a -0)
-        const float left = best_bin > 0 ? value_at(best_bin - 1) : NAN;
-        const float right = best_bin >= 0 && (uint32_t)best_bin + 1 < nb ? value_at(best_bin + 1) : NAN;
-        if (lane == 0) {
-            FramePeak r;
-            r.lo12 = lo == 0x7FFFFFFF ? -1 : lo;
-            r.hi12 = hi;
-            r.bin = best_bin;
-            r.db = best;
-            r.left = left;
-            r.right = right;
-            out[f] = r;
-        }
+        if (lane == 0 && span_best) span_best[i] = SpanBest{best, bin};
     });
 }
 
@@ -790,6 +825,15 @@ hipError_t launch_db_peaks(const float *d_mags, size_t frames, uint32_t bins, ui
     if (frames == 0) return hipSuccess;
     hipLaunchKernelGGL(db_peaks_kernel, dim3(rows_grid_capped(frames)), dim3(kThreads), 0, s, d_mags, frames, bins, min_bin, nb,
                        db_law(fft_size), d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_db_peaks_spans(const float *d_mags, const PeakSpan *d_spans, size_t n_spans, uint32_t bins, uint32_t min_bin,
+                                 uint32_t nb, uint32_t fft_size, const PeakTable &table, SpanBest *d_span_best, hipStream_t s)
+{
+    if (n_spans == 0) return hipSuccess;
+    hipLaunchKernelGGL(db_peaks_spans_kernel, dim3(rows_grid_capped(n_spans)), dim3(kThreads), 0, s, d_mags, d_spans, n_spans, bins,
+                       min_bin, nb, db_law(fft_size), table, d_span_best);
     return hipGetLastError();
 }
 

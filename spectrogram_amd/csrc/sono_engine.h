@@ -159,7 +159,8 @@ struct sono_engine {
     sono::DevBuf d_rec;                     // sono_process_full_file: the whole recording, resident from the fast scan on
     // ... and, per group of regions, the per-frame records of its regions (six 4-byte arrays): two sets, one for the
     // group whose calls are being framed, one for the group being analysed meanwhile
-    std::vector<uint32_t> frame_tables[2];
+    sono::HostBuf frame_tables[2];          // (pinned: the finished arrays arrive from the GPU in plain copies)
+    sono::DevBuf d_frame_table;             // region analysis: the six per-frame arrays of the regions being analysed, filled by the GPU
     std::vector<sono_segment> scan_segments;   // ... and the fast scan's segments (one per half frame at most)
     sono::HostBuf h_in, h_out;              // staging of the whole-file passes (packed samples; records / dB matrices)
     sono::DevBuf d_refine;                  // call framing on a resident recording: the spans whose windows are summed, and the sums
@@ -170,11 +171,13 @@ struct sono_engine {
         sono::DevBuf d_in, d_db;
         sono::HostBuf h_jobs;               // measurement on the GPU: the batch's calls ...
         sono::DevBuf d_jobs, d_results;     // ... on the device, and what the kernel measured (copied to h_out instead of the dB)
+        sono::HostBuf h_spans;              // region analysis: the batch's row spans (sono::PeakSpan) ...
+        sono::DevBuf d_spans;               // ... on the device, followed by what each span found (sono::SpanBest)
         hipEvent_t done = nullptr;          // recorded behind the copy of the dB matrices (or of the results) to h_out
         void release()
         {
             h_in.release(); h_out.release(); d_in.release(); d_db.release();
-            h_jobs.release(); d_jobs.release(); d_results.release();
+            h_jobs.release(); d_jobs.release(); d_results.release(); h_spans.release(); d_spans.release();
             if (done) { (void)hipEventDestroy(done); done = nullptr; }
         }
     };
