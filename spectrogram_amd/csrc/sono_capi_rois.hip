@@ -13,7 +13,9 @@
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1055,6 +1057,8 @@ struct GroupTail {
     std::vector<double> zonal;
     sono_roi_table t{};
     size_t roi_base = 0;
+    std::vector<sono_roi_call> framed;       // what the framing found, for the measurement
+    size_t n_calls = 0;
 };
 
 // Analysis of a group of regions (js:609-671) on engine e, into its buffer set `set`; the rest of the group's way is left in `g`.
@@ -1087,31 +1091,35 @@ static int analyze_regions(sono_engine *e, const HostSamples &hs, size_t n, doub
     return SONO_OK;
 }
 
-// The rest of an analysed group's way: framing (js:677-794, host threads), measurement (js:797) of the calls on engine
-// em (its stream, its buffers) and what follows it (js:802-827); the calls kept join the list of engine e.
-static int finish_regions(sono_engine *e, sono_engine *em, const HostSamples &hs, size_t n, double sample_rate, double flow_khz,
-                          double fhigh_khz, const sono_full_file_options *opt, GroupTail &g, size_t *calls_seen, float *d_rec,
-                          StageTimes &times)
+// The rest of an analysed group's way, first half: the framing of its calls (js:677-794, host threads; the windows of
+// the oscillogram refinement summed on engine ef: its stream, its buffers).
+static int frame_group(sono_engine *e, sono_engine *ef, const HostSamples &hs, size_t n, double sample_rate,
+                       const sono_full_file_options *opt, GroupTail &g, float *d_rec, StageTimes &times)
 {
-    auto t0 = std::chrono::steady_clock::now();
-    auto lap = [&t0](double &into) {
-        const auto t1 = std::chrono::steady_clock::now();
-        into += std::chrono::duration<double, std::milli>(t1 - t0).count();
-        t0 = t1;
-    };
+    const auto t0 = std::chrono::steady_clock::now();
     // the list is sized by the framing: a bound from the frame count would be hundreds of MB of fresh pages
-    std::vector<sono_roi_call> framed;
-    size_t n_calls = 0;
-    const ResidentRecording resident{em, d_rec};
+    g.n_calls = 0;
+    const ResidentRecording resident{ef, d_rec};
     int rc = frame_roi_calls(hs, nullptr, n, g.rois.data(), g.rois.size(), &g.t, sample_rate, e->N, opt->call_threshold_db,
-                             opt->min_call_duration_ms, nullptr, 0, &n_calls, &framed, &resident);
-    if (rc) return rc;
-    lap(times.framing);
+                             opt->min_call_duration_ms, nullptr, 0, &g.n_calls, &g.framed, &resident);
+    times.framing += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+// Second half: the measurement (js:797) of the framed calls on engine em (its stream, its buffers) and what follows it
+// (js:802-827); the calls kept join the list of engine e.
+static int measure_group(sono_engine *e, sono_engine *em, const HostSamples &hs, size_t n, double sample_rate, double flow_khz,
+                         double fhigh_khz, const sono_full_file_options *opt, GroupTail &g, size_t *calls_seen, float *d_rec,
+                         StageTimes &times)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t n_calls = g.n_calls;
+    const std::vector<sono_roi_call> &framed = g.framed;
     std::vector<sono_call_measurement> meas(n_calls + 1);
     const bool keep_slices = (opt->debug_mode & SONO_KEEP_CALL_SPECTROGRAMS) != 0;
     std::vector<sono::FullFileSlice> slices(keep_slices ? n_calls : 0);
-    rc = measure_roi_calls(em, hs.x, nullptr, n, g.rois.data(), g.rois.size(), &g.t, framed.data(), n_calls, sample_rate, flow_khz,
-                           fhigh_khz, opt->hop_percent, opt->debug_mode, opt->threads, meas.data(), keep_slices ? &slices : nullptr, d_rec);
+    int rc = measure_roi_calls(em, hs.x, nullptr, n, g.rois.data(), g.rois.size(), &g.t, framed.data(), n_calls, sample_rate, flow_khz,
+                               fhigh_khz, opt->hop_percent, opt->debug_mode, opt->threads, meas.data(), keep_slices ? &slices : nullptr, d_rec);
     if (rc) return rc;
     e->full_file_axes = {g.t.hop, g.t.min_bin, g.t.num_bins, sample_rate};
     std::vector<sono_full_file_call> &kept = e->full_file_calls;
@@ -1143,39 +1151,83 @@ static int finish_regions(sono_engine *e, sono_engine *em, const HostSamples &hs
         o.quality = o.snr_db < 10 ? 0 : o.snr_db < 15 ? 1 : o.snr_db < 20 ? 2 : o.snr_db < 30 ? 3 : 4;    // getQualityRating, js:375-387
     }
     *calls_seen += n_calls;
-    lap(times.measurement);
+    times.measurement += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SONO_OK;
 }
 
-// The groups' tails, one at a time and in the groups' order, on a thread of their own: group k's calls are framed
-// (host threads) and measured (on the engine's companion: a stream and buffers of its own) while group k + 1 is
-// scanned and analysed.
-struct TailRunner {
-    std::thread worker;
-    std::unique_ptr<GroupTail> group;
-    int rc = SONO_OK;
-    std::string error;
-    double ms = 0;                           // the tails' own time, beside whatever else went on
-    // -> once the tail that is running (if any) has ended; its error becomes this thread's
-    int wait()
+// Both halves in line, on one engine.
+static int finish_regions(sono_engine *e, sono_engine *em, const HostSamples &hs, size_t n, double sample_rate, double flow_khz,
+                          double fhigh_khz, const sono_full_file_options *opt, GroupTail &g, size_t *calls_seen, float *d_rec,
+                          StageTimes &times)
+{
+    int rc = frame_group(e, em, hs, n, sample_rate, opt, g, d_rec, times);
+    if (rc) return rc;
+    return measure_group(e, em, hs, n, sample_rate, flow_khz, fhigh_khz, opt, g, calls_seen, d_rec, times);
+}
+
+// The groups' tails on threads of their own, beside the scan and analysis of the groups that follow: group k's calls are
+// framed (host threads; the window sums on the framing engine) while group k - 1's are measured (on the measuring
+// engine), each kind of stage one group at a time and in the groups' order, so the calls join the list in the order of
+// the recording.  A tail's thread frames as soon as the tail before it has framed, and measures as soon as that tail has
+// ended; a failure anywhere ends the tails behind it without measuring.
+struct TailPipeline {
+    struct Tail {
+        std::unique_ptr<GroupTail> group;
+        std::thread worker;
+        std::mutex m;
+        std::condition_variable cv;
+        bool framed = false, ended = false;
+        int rc = SONO_OK;
+        std::string error;
+        void mark(bool Tail::*flag) { { std::lock_guard<std::mutex> l(m); this->*flag = true; } cv.notify_all(); }
+        void await(bool Tail::*flag) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return this->*flag; }); }
+    };
+    std::vector<std::unique_ptr<Tail>> tails;        // in the groups' order; joined ones stay (their rc is read at the end)
+    std::atomic<long long> us{0};                    // the tails' own time, beside whatever else went on
+    using Stage = std::function<int(GroupTail &)>;
+    void start(std::unique_ptr<GroupTail> g, Stage frame, Stage measure)
     {
-        if (worker.joinable()) worker.join();
-        group.reset();
-        if (rc != SONO_OK) { const int r = rc; rc = SONO_OK; return fail(r, error); }
-        return SONO_OK;
-    }
-    void start(std::unique_ptr<GroupTail> g, std::function<int(GroupTail &)> fn)
-    {
-        group = std::move(g);
-        GroupTail *gp = group.get();
-        worker = std::thread([this, gp, fn]() {
-            const auto t0 = std::chrono::steady_clock::now();
-            rc = fn(*gp);
-            if (rc != SONO_OK) error = sono_last_error();
-            ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        Tail *prev = tails.empty() ? nullptr : tails.back().get();
+        tails.emplace_back(new Tail());
+        Tail *t = tails.back().get();
+        t->group = std::move(g);
+        t->worker = std::thread([this, t, prev, frame, measure]() {
+            if (prev) prev->await(&Tail::framed);
+            auto t0 = std::chrono::steady_clock::now();
+            int rc = frame(*t->group);
+            if (rc != SONO_OK) t->error = sono_last_error();
+            us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+            t->mark(&Tail::framed);
+            if (prev) {
+                prev->await(&Tail::ended);
+                if (rc == SONO_OK && prev->rc != SONO_OK) { rc = prev->rc; t->error = prev->error; }
+            }
+            if (rc == SONO_OK) {
+                t0 = std::chrono::steady_clock::now();
+                rc = measure(*t->group);
+                if (rc != SONO_OK) t->error = sono_last_error();
+                us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+            }
+            t->rc = rc;
+            t->mark(&Tail::ended);
         });
     }
-    ~TailRunner() { if (worker.joinable()) worker.join(); }
+    // -> once the tail started `back` tails ago (0: the last one) has ended, if there is one; what it held is released
+    void wait_back(size_t back)
+    {
+        if (tails.size() <= back) return;
+        Tail *t = tails[tails.size() - 1 - back].get();
+        if (t->worker.joinable()) t->worker.join();
+        t->group.reset();
+    }
+    // -> once every tail has ended; the first failure (they carry it down the line) becomes this thread's
+    int finish()
+    {
+        for (auto &t : tails) if (t->worker.joinable()) t->worker.join();
+        for (auto &t : tails) if (t->rc != SONO_OK) return fail(t->rc, t->error);
+        return SONO_OK;
+    }
+    ~TailPipeline() { for (auto &t : tails) if (t->worker.joinable()) t->worker.join(); }
 };
 
 // The recording's way to the GPU, piece by piece, on a thread and a stream of its own: piece p has arrived (and, for
@@ -1284,33 +1336,37 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
     // with the next pieces' scan and the next group's analysis; the two groups' records and filtered samples lie in the
     // engine's two sets of buffers.  One such tail at a time, in the groups' order: the calls join the list in the order
     // of the recording.
-    sono_engine *em = nullptr;
+    sono_engine *em = nullptr, *ef = nullptr;
     if (!whole && !e->no_measure_overlap) {
-        if (!e->measure_engine && sono_engine_create(N, e->window_name.c_str(), 1, e->alpha, e->device, &e->measure_engine) != SONO_OK)
-            e->measure_engine = nullptr;                     // without it the tails run in line
-        em = e->measure_engine;
-        if (em) {
-            em->host_measure = e->host_measure;
-            em->tables.force_generic = e->tables.force_generic;
-            em->tables.tile.any_hop = e->tables.tile.any_hop;
-            em->tables.tile.balance.fixed = e->tables.tile.balance.fixed;
+        for (sono_engine **companion : {&e->measure_engine, &e->frame_engine}) {
+            if (!*companion && sono_engine_create(N, e->window_name.c_str(), 1, e->alpha, e->device, companion) != SONO_OK)
+                *companion = nullptr;                        // without them the tails run in line
+            if (*companion) {
+                (*companion)->host_measure = e->host_measure;
+                (*companion)->tables.force_generic = e->tables.force_generic;
+                (*companion)->tables.tile.any_hop = e->tables.tile.any_hop;
+                (*companion)->tables.tile.balance.fixed = e->tables.tile.balance.fixed;
+            }
         }
+        if (e->measure_engine && e->frame_engine) { em = e->measure_engine; ef = e->frame_engine; }
     }
-    TailRunner tails;
     unsigned int groups = 0;
-    StageTimes tail_times;                                   // a tail's own clock, beside this thread's
-    auto run_group = [&](const sono_segment *rois, size_t n_rois, size_t roi_base, bool more_to_come) -> int {
+    StageTimes tail_times;                                   // the tails' own clocks, beside this thread's
+    TailPipeline tails;                                      // (after everything its threads refer to: it joins them when it goes)
+    auto run_group = [&](const sono_segment *rois, size_t n_rois, size_t roi_base) -> int {
         if (n_rois == 0) return SONO_OK;
         std::unique_ptr<GroupTail> g(new GroupTail());
-        // the buffer set the tail before the running one read: that tail has ended (a tail starts when the one before it has)
-        int r = analyze_regions(e, hs, n, sample_rate, flow_khz, fhigh_khz, opt, rois, n_rois, roi_base, d_rec, groups++ & 1u, times, *g);
-        const int before = tails.wait();                     // the group before this one: its calls come first
-        if (r == SONO_OK) r = before;
+        // Three sets of tables: this group's, the set of the group being framed and the set of the group being measured.
+        // The set this analysis writes was read by the tail started three groups ago: that one must have ended.
+        tails.wait_back(2);
+        int r = analyze_regions(e, hs, n, sample_rate, flow_khz, fhigh_khz, opt, rois, n_rois, roi_base, d_rec, groups++ % 3u, times, *g);
         if (r != SONO_OK) return r;
-        if (em && more_to_come) {
-            tails.start(std::move(g), [&, em, d_rec](GroupTail &gt) {
-                return finish_regions(e, em, hs, n, sample_rate, flow_khz, fhigh_khz, opt, gt, &calls_seen, d_rec, tail_times);
-            });
+        if (em) {
+            tails.start(std::move(g),
+                        [&, ef, d_rec](GroupTail &gt) { return frame_group(e, ef, hs, n, sample_rate, opt, gt, d_rec, tail_times); },
+                        [&, em, d_rec](GroupTail &gt) {
+                            return measure_group(e, em, hs, n, sample_rate, flow_khz, fhigh_khz, opt, gt, &calls_seen, d_rec, tail_times);
+                        });
             return SONO_OK;
         }
         return finish_regions(e, e, hs, n, sample_rate, flow_khz, fhigh_khz, opt, *g, &calls_seen, d_rec, times);
@@ -1332,7 +1388,7 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
         size_t n_rois = 0;
         rc = sono_merge_and_pad_segments(raw.data(), n_raw, n, sample_rate, opt->padding_ms, rois.data(), rois.size(), &n_rois);
         if (rc) return rc;
-        rc = run_group(rois.data(), n_rois, 0, false);
+        rc = run_group(rois.data(), n_rois, 0);
         if (rc) return rc;
     } else {
         HIP_TRY(e->d_flags.reserve(F));
@@ -1388,13 +1444,13 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
             // Regions are handed on some ten thousand at a time: the measurement is one wave per call, and fewer calls
             // than the GPU has room for waves leave it idle for as long as one call takes.
             if (!group.empty() && (last_piece || group.size() >= (e->small_upload_pieces ? (size_t)6 : (size_t)12000))) {
-                rc = run_group(group.data(), group.size(), roi_base, !last_piece);
+                rc = run_group(group.data(), group.size(), roi_base);
                 if (rc) return rc;
                 roi_base += group.size();
                 group.clear();
             }
         }
-        rc = tails.wait();                                   // (the last group finishes in line: nothing is running here)
+        rc = tails.finish();
         if (rc) return rc;
         if (timer.on) {
             std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "waiting for pieces, fast scan", t_wait);
@@ -1405,7 +1461,7 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
         std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "region analysis (GPU)", times.analysis);
         std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "framing (host)", times.framing);
         std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "measurement (GPU + threads)", times.measurement);
-        std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "beside the next analysis:", tails.ms);
+        std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "on threads of their own:", (double)tails.us.load() / 1000);
         std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "   framing", tail_times.framing);
         std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "   measurement", tail_times.measurement);
     }
