@@ -221,6 +221,7 @@ void sono_engine_destroy(sono_engine *e)
     if (!e) return;
     if (e->measure_engine) { sono_engine_destroy(e->measure_engine); e->measure_engine = nullptr; }
     if (e->frame_engine) { sono_engine_destroy(e->frame_engine); e->frame_engine = nullptr; }
+    for (sono_engine *&a : e->analysis_engine) if (a) { sono_engine_destroy(a); a = nullptr; }
     DeviceGuard guard(e->device);
     if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
     e->tables.release();
@@ -324,6 +325,7 @@ int sono_engine_release_memory(sono_engine *e)
     if (!e) return fail(SONO_EINVAL, "sono_engine_release_memory: NULL engine");
     if (e->measure_engine) (void)sono_engine_release_memory(e->measure_engine);
     if (e->frame_engine) (void)sono_engine_release_memory(e->frame_engine);
+    for (sono_engine *a : e->analysis_engine) if (a) (void)sono_engine_release_memory(a);
     DeviceGuard guard(e->device);
     (void)hipStreamSynchronize(e->stream);
     e->bank.clear(); e->num_filters = 0; e->use_bank = false; e->bank_taps_ready = false;       // lib.rs:683-692

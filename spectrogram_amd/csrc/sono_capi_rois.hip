@@ -1061,22 +1061,21 @@ struct GroupTail {
     size_t n_calls = 0;
 };
 
-// Analysis of a group of regions (js:609-671) on engine e, into its buffer set `set`; the rest of the group's way is left in `g`.
-static int analyze_regions(sono_engine *e, const HostSamples &hs, size_t n, double sample_rate, double flow_khz, double fhigh_khz,
-                           const sono_full_file_options *opt, const sono_segment *rois, size_t n_rois, size_t roi_base, float *d_rec,
-                           unsigned int set, StageTimes &times, GroupTail &g)
+// Analysis of the group of regions g.rois (js:609-671) on engine e, into buffer set `set` of engine `keeper`; the rest of the group's way is left in `g`.
+static int analyze_regions(sono_engine *e, sono_engine *keeper, const HostSamples &hs, size_t n, double sample_rate, double flow_khz,
+                           double fhigh_khz, const sono_full_file_options *opt, float *d_rec, unsigned int set, StageTimes &times, GroupTail &g)
 {
     const uint32_t N = e->N;
     const auto t0 = std::chrono::steady_clock::now();
-    g.rois.assign(rois, rois + n_rois);
-    g.roi_base = roi_base;
+    const sono_segment *rois = g.rois.data();                // (the group's regions and roi_base are the caller's)
+    const size_t n_rois = g.rois.size();
     // per-region analysis, all regions at once (js:609-711)
     g.row0.resize(n_rois + 1);
     int rc = sono_roi_rows(rois, n_rois, N, opt->hop_percent, g.row0.data());
     if (rc) return rc;
     const size_t total = (size_t)g.row0[n_rois];
     // six per-frame arrays, every entry of which the analysis writes: one block the engine keeps (fresh pages again)
-    sono::HostBuf &tables = e->frame_tables[set];
+    sono::HostBuf &tables = keeper->frame_tables[set];
     if (!tables.reserve(6 * (total + 1) * sizeof(uint32_t))) return fail(SONO_ENOMEM, "sono_process_full_file: cannot allocate the regions' tables");
     float *peak_db = (float *)tables.p, *left = peak_db + (total + 1), *right = left + (total + 1);
     int32_t *peak_bin = (int32_t *)(right + (total + 1)), *ilo = peak_bin + (total + 1), *ihi = ilo + (total + 1);
@@ -1087,6 +1086,8 @@ static int analyze_regions(sono_engine *e, const HostSamples &hs, size_t n, doub
     // framing stage has the GPU sum the windows it asks about, and no sample returns to the host.
     rc = analyze_rois(e, hs.x, n, rois, n_rois, sample_rate, flow_khz, fhigh_khz, opt->hop_percent, 1, &g.t, total, nullptr, d_rec);
     if (rc) return rc;
+    static std::mutex clock;                                 // (two groups may be analysed side by side)
+    std::lock_guard<std::mutex> l(clock);
     times.analysis += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SONO_OK;
 }
@@ -1165,62 +1166,66 @@ static int finish_regions(sono_engine *e, sono_engine *em, const HostSamples &hs
     return measure_group(e, em, hs, n, sample_rate, flow_khz, fhigh_khz, opt, g, calls_seen, d_rec, times);
 }
 
-// The groups' tails on threads of their own, beside the scan and analysis of the groups that follow: group k's calls are
-// framed (host threads; the window sums on the framing engine) while group k - 1's are measured (on the measuring
-// engine), each kind of stage one group at a time and in the groups' order, so the calls join the list in the order of
-// the recording.  A tail's thread frames as soon as the tail before it has framed, and measures as soon as that tail has
-// ended; a failure anywhere ends the tails behind it without measuring.
+// The groups' way from their regions to their calls on threads of their own, beside the scan of the pieces that
+// follow: group k is analysed (on the analysing engine) while group k - 1's calls are framed (host threads; the window
+// sums on the framing engine) and group k - 2's are measured (on the measuring engine) -- each kind of stage one group
+// at a time and in the groups' order, so the calls join the list in the order of the recording.  A group's thread
+// analyses as soon as the group two before it has been analysed (two analysing engines take the groups in turn: one
+// group's waits for the GPU are the other's work) and the group four before it has ended (whose set of tables it writes), frames as soon as the group before it has been framed, and measures as soon as that group has
+// ended; a failure anywhere ends the groups behind it without further work.
 struct TailPipeline {
     struct Tail {
         std::unique_ptr<GroupTail> group;
         std::thread worker;
         std::mutex m;
         std::condition_variable cv;
-        bool framed = false, ended = false;
+        bool analysed = false, framed = false, ended = false;
         int rc = SONO_OK;
         std::string error;
         void mark(bool Tail::*flag) { { std::lock_guard<std::mutex> l(m); this->*flag = true; } cv.notify_all(); }
         void await(bool Tail::*flag) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return this->*flag; }); }
     };
-    std::vector<std::unique_ptr<Tail>> tails;        // in the groups' order; joined ones stay (their rc is read at the end)
-    std::atomic<long long> us{0};                    // the tails' own time, beside whatever else went on
+    static constexpr unsigned int kAnalysers = 2;    // groups analysed side by side (one analysing engine each)
+    static constexpr unsigned int kSets = kAnalysers + 2;    // sets of tables: being analysed, being framed, being measured
+    std::vector<std::unique_ptr<Tail>> tails;        // in the groups' order; ended ones stay (their rc is read at the end)
+    std::atomic<long long> us{0};                    // the threads' own time in their stages, beside whatever else went on
     using Stage = std::function<int(GroupTail &)>;
-    void start(std::unique_ptr<GroupTail> g, Stage frame, Stage measure)
+    using Analysis = std::function<int(GroupTail &, unsigned int k)>;      // k: the group's number (engine k % kAnalysers, set k % kSets)
+    void start(std::unique_ptr<GroupTail> g, Analysis analyse, Stage frame, Stage measure)
     {
-        Tail *prev = tails.empty() ? nullptr : tails.back().get();
+        const size_t k = tails.size();
+        Tail *prev = k ? tails[k - 1].get() : nullptr, *owner = k >= kSets ? tails[k - kSets].get() : nullptr;
+        Tail *before = k >= kAnalysers ? tails[k - kAnalysers].get() : nullptr;      // the group that had this group's analysing engine
         tails.emplace_back(new Tail());
         Tail *t = tails.back().get();
         t->group = std::move(g);
-        t->worker = std::thread([this, t, prev, frame, measure]() {
+        t->worker = std::thread([this, t, prev, owner, before, k, analyse, frame, measure]() {
+            int rc = SONO_OK;
+            auto run = [&](const std::function<int()> &stage) {
+                if (rc != SONO_OK) return;
+                const auto t0 = std::chrono::steady_clock::now();
+                rc = stage();
+                if (rc != SONO_OK) t->error = sono_last_error();
+                us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+            };
+            if (before) before->await(&Tail::analysed);
+            if (owner) owner->await(&Tail::ended);
+            run([&] { return analyse(*t->group, (unsigned int)k); });
+            t->mark(&Tail::analysed);
             if (prev) prev->await(&Tail::framed);
-            auto t0 = std::chrono::steady_clock::now();
-            int rc = frame(*t->group);
-            if (rc != SONO_OK) t->error = sono_last_error();
-            us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+            run([&] { return frame(*t->group); });
             t->mark(&Tail::framed);
             if (prev) {
                 prev->await(&Tail::ended);
                 if (rc == SONO_OK && prev->rc != SONO_OK) { rc = prev->rc; t->error = prev->error; }
             }
-            if (rc == SONO_OK) {
-                t0 = std::chrono::steady_clock::now();
-                rc = measure(*t->group);
-                if (rc != SONO_OK) t->error = sono_last_error();
-                us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
-            }
+            run([&] { return measure(*t->group); });
             t->rc = rc;
+            t->group.reset();
             t->mark(&Tail::ended);
         });
     }
-    // -> once the tail started `back` tails ago (0: the last one) has ended, if there is one; what it held is released
-    void wait_back(size_t back)
-    {
-        if (tails.size() <= back) return;
-        Tail *t = tails[tails.size() - 1 - back].get();
-        if (t->worker.joinable()) t->worker.join();
-        t->group.reset();
-    }
-    // -> once every tail has ended; the first failure (they carry it down the line) becomes this thread's
+    // -> once every group has ended; the first failure (they carry it down the line) becomes this thread's
     int finish()
     {
         for (auto &t : tails) if (t->worker.joinable()) t->worker.join();
@@ -1336,11 +1341,11 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
     // with the next pieces' scan and the next group's analysis; the two groups' records and filtered samples lie in the
     // engine's two sets of buffers.  One such tail at a time, in the groups' order: the calls join the list in the order
     // of the recording.
-    sono_engine *em = nullptr, *ef = nullptr;
+    sono_engine *ea[2] = {nullptr, nullptr}, *ef = nullptr, *em = nullptr;
     if (!whole && !e->no_measure_overlap) {
-        for (sono_engine **companion : {&e->measure_engine, &e->frame_engine}) {
+        for (sono_engine **companion : {&e->analysis_engine[0], &e->analysis_engine[1], &e->frame_engine, &e->measure_engine}) {
             if (!*companion && sono_engine_create(N, e->window_name.c_str(), 1, e->alpha, e->device, companion) != SONO_OK)
-                *companion = nullptr;                        // without them the tails run in line
+                *companion = nullptr;                        // without them the groups are worked on in line
             if (*companion) {
                 (*companion)->host_measure = e->host_measure;
                 (*companion)->tables.force_generic = e->tables.force_generic;
@@ -1348,27 +1353,32 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
                 (*companion)->tables.tile.balance.fixed = e->tables.tile.balance.fixed;
             }
         }
-        if (e->measure_engine && e->frame_engine) { em = e->measure_engine; ef = e->frame_engine; }
+        if (e->analysis_engine[0] && e->analysis_engine[1] && e->frame_engine && e->measure_engine) {
+            ea[0] = e->analysis_engine[0]; ea[1] = e->analysis_engine[1]; ef = e->frame_engine; em = e->measure_engine;
+        }
     }
-    unsigned int groups = 0;
-    StageTimes tail_times;                                   // the tails' own clocks, beside this thread's
+    StageTimes tail_times;                                   // the stages' own clocks on the groups' threads, beside this thread's
     TailPipeline tails;                                      // (after everything its threads refer to: it joins them when it goes)
     auto run_group = [&](const sono_segment *rois, size_t n_rois, size_t roi_base) -> int {
         if (n_rois == 0) return SONO_OK;
         std::unique_ptr<GroupTail> g(new GroupTail());
-        // Three sets of tables: this group's, the set of the group being framed and the set of the group being measured.
-        // The set this analysis writes was read by the tail started three groups ago: that one must have ended.
-        tails.wait_back(2);
-        int r = analyze_regions(e, hs, n, sample_rate, flow_khz, fhigh_khz, opt, rois, n_rois, roi_base, d_rec, groups++ % 3u, times, *g);
-        if (r != SONO_OK) return r;
+        g->rois.assign(rois, rois + n_rois);
+        g->roi_base = roi_base;
         if (em) {
             tails.start(std::move(g),
+                        [&, ea, d_rec](GroupTail &gt, unsigned int k) {
+                            // (the sets of tables are the first analysing engine's)
+                            return analyze_regions(ea[k % TailPipeline::kAnalysers], ea[0], hs, n, sample_rate, flow_khz, fhigh_khz, opt, d_rec,
+                                                   k % TailPipeline::kSets, tail_times, gt);
+                        },
                         [&, ef, d_rec](GroupTail &gt) { return frame_group(e, ef, hs, n, sample_rate, opt, gt, d_rec, tail_times); },
                         [&, em, d_rec](GroupTail &gt) {
                             return measure_group(e, em, hs, n, sample_rate, flow_khz, fhigh_khz, opt, gt, &calls_seen, d_rec, tail_times);
                         });
             return SONO_OK;
         }
+        int r = analyze_regions(e, e, hs, n, sample_rate, flow_khz, fhigh_khz, opt, d_rec, 0u, times, *g);
+        if (r != SONO_OK) return r;
         return finish_regions(e, e, hs, n, sample_rate, flow_khz, fhigh_khz, opt, *g, &calls_seen, d_rec, times);
     };
     PieceUpload up(e, hs, n, piece, d_rec);
@@ -1464,6 +1474,7 @@ static int process_full_file(sono_engine *e, const HostSamples &hs, size_t n, do
         std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "framing (host)", times.framing);
         std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "measurement (GPU + threads)", times.measurement);
         std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "on threads of their own:", (double)tails.us.load() / 1000);
+        std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "   region analysis", tail_times.analysis);
         std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "   framing", tail_times.framing);
         std::fprintf(stderr, "[sono_process_full_file] %-28s %8.2f ms\n", "   measurement", tail_times.measurement);
     }

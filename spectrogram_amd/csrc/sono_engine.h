@@ -157,9 +157,9 @@ struct sono_engine {
     // device scratch of the detector front end (sono_capi_detect.hip)
     sono::DevBuf d_db, d_flags, d_edges, d_runs, d_count, d_select_tmp;
     sono::DevBuf d_rec;                     // sono_process_full_file: the whole recording, resident from the fast scan on
-    // ... and, per group of regions, the per-frame records of its regions (six 4-byte arrays): three sets, one for the
-    // group whose calls are being measured, one for the group being framed, one for the group being analysed meanwhile
-    sono::HostBuf frame_tables[3];          // (pinned: the finished arrays arrive from the GPU in plain copies)
+    // ... and, per group of regions, the per-frame records of its regions (six 4-byte arrays): four sets: one for the
+    // group whose calls are being measured, one for the group being framed, two for the groups being analysed meanwhile
+    sono::HostBuf frame_tables[4];          // (pinned: the finished arrays arrive from the GPU in plain copies)
     sono::DevBuf d_frame_table;             // region analysis: the six per-frame arrays of the regions being analysed, filled by the GPU
     std::vector<sono_segment> scan_segments;   // ... and the fast scan's segments (one per half frame at most)
     sono::HostBuf h_in, h_out;              // staging of the whole-file passes (packed samples; records / dB matrices)
@@ -187,6 +187,7 @@ struct sono_engine {
     bool small_upload_pieces = false;       // engine option "small_upload_pieces": pieces of 64 fft sizes instead of 2^26 samples (tests: many pieces from a short recording)
     bool host_measure = false;              // engine option "host_measure": the calls' dB matrices go to the host and are measured there
     bool no_measure_overlap = false;        // engine option "no_measure_overlap": whole-file detection frames and measures a group's calls before it analyses the next group
+    sono_engine *analysis_engine[2] = {nullptr, nullptr};   // whole-file detection, piece by piece: the companions that analyse the groups of regions in turn while this engine scans the next pieces,
     sono_engine *frame_engine = nullptr;    // ... and the one on whose stream the next group's framing has its windows summed meanwhile
     sono_engine *measure_engine = nullptr;  // whole-file detection: the companion (same fft size and window) on whose stream and buffers a group's calls are measured beside the next group's analysis; created on first use
     // pinned pieces of upload_host_array, each guarded by an event recorded behind its copy to the device
