@@ -52,7 +52,9 @@ def _all_headers():
 # no GPU sanitizer on this hardware pool).  Loaded through SONO_LIB_PATH by tools/asan_tests.sh.
 ASAN_LIB = os.path.join(LIBDIR, "libsonostft_asan.so")
 ASAN_OBJDIR = os.path.join(HERE, "build", "asan")
-ASAN_HOST = ["-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined", "-Xarch_host", "-fno-omit-frame-pointer", "-g"]
+# (-fno-sanitize=function: a kernel launched through a pointer to its host stub reads as a call through a wrong function type)
+ASAN_HOST = ["-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined", "-Xarch_host", "-fno-sanitize=function",
+             "-Xarch_host", "-fno-omit-frame-pointer", "-g"]
 
 
 def build(force=False, verbose=False, asan=False):
