@@ -98,9 +98,9 @@ uint32_t sono_host_threads(void);
  *                                          analyses it, instead of working on the pieces that have arrived while the next
  *                                          ones cross the link
  *   "no_measure_overlap" (SONO_NO_MEASURE_OVERLAP) sono_process_full_file frames and measures a group of regions' calls
- *                                          before it goes on, instead of beside the next groups' scan and analysis (on
- *                                          threads of their own, framing and measurement each on a companion engine --
- *                                          a stream and buffers of its own, created on first use)
+ *                                          in line, instead of on threads of their own beside the scan of the next
+ *                                          pieces (analysis, framing and measurement each on companion engines --
+ *                                          streams and buffers of their own, created on first use)
  *   "small_upload_pieces" (no variable)    those pieces are 64 fft sizes long instead of 2^26 samples (tests: many pieces
  *                                          and several groups of regions from a few seconds of audio)
  * None of them changes a result bit (the tests compare the forms).  SONO_EINVAL for an unknown name.
@@ -600,10 +600,11 @@ int sono_measure_roi_calls(sono_engine *e, const float *x, const float *x_filter
  * = peak + 80 dB, quality, region time -> file time).  Calls come in the reference's order (per region, strongest
  * first).  SONO_EREFERENCE: SONO_DEBUG_MODE is not set and the reference would raise on one of the calls (its promise rejects).
  * The recording is read from the caller's memory by a second thread for the length of the call (it crosses the link
- * in pieces while the pieces that have arrived are worked on); x must stay unchanged until the call returns.  Further
- * threads frame the calls of one group of regions (3 000 at a time) and measure those of the group before it while the
- * next group is analysed (each of the two stages on a companion engine the engine creates on first use and keeps:
- * engine option "no_measure_overlap"); all of them have ended when the call returns.  No sample returns
+ * in pieces while the pieces that have arrived are scanned); x must stay unchanged until the call returns.  Further
+ * threads, one per group of regions (3 000 at a time), analyse a group, frame its calls and measure them, each stage in
+ * the groups' order and beside the other stages of the neighbouring groups (on four companion engines the engine
+ * creates on first use and keeps -- two that analyse, one that frames, one that measures: engine option
+ * "no_measure_overlap"); all of them have ended when the call returns.  No sample returns
  * to the host: the automatic high-pass filters the resident recording in place, and what the framing stage needs of
  * the samples (the energies of 0.1 ms windows, js:1676-1683) is summed on the GPU. */
 typedef struct sono_full_file_options {
