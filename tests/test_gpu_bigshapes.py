@@ -209,7 +209,7 @@ def test_ten_thousand_files_in_one_launch():
 
 def test_whole_file_detection_at_production_piece_size():
     """Forty minutes of one 16-bit channel through sono_process_full_file_pcm16 as a survey runs it: the recording
-    crosses the link in pieces of 2^26 samples (fourteen of them here) and its 24 000 regions are handed on in two
+    crosses the link in pieces of 2^26 samples (fourteen of them here) and its 24 000 regions are handed on in eight
     groups while later pieces are still on their way.  Every row of the call table equals the one-piece form's bit for
     bit; the pulses come every 100 ms, so there are as many calls as tenths of a second."""
     import torch
