@@ -258,7 +258,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # (SONO_BENCH_FORCE_DIST=1 under a one-rank launcher: the process group, barrier and collectives of the multi-rank
+    # path over RCCL on a box with one GPU)
+    distributed = world > 1 or (os.environ.get("SONO_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     # SONO_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
     backend = os.environ.get("SONO_BENCH_BACKEND", "nccl")
     device_index = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
