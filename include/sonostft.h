@@ -330,6 +330,20 @@ int sono_detect_frame_features_dev(sono_engine *e, const float *d_db, size_t fra
                                    uint32_t peak_b0, uint32_t peak_b1, uint32_t low_max_bin, double low_threshold_db,
                                    uint32_t high_min_bin, double high_threshold_db, sono_frame_features *d_out,
                                    void *hip_stream);
+/* Per row of a magnitude matrix (frames x bins, device memory), over bins min_bin .. min_bin + num_bins - 1 converted to
+ * dB as sono_detect_power_db_dev does: the first bin (band-relative) of the largest dB value, that value and its two
+ * neighbours (NaN at the ends of the band) -- the inputs of the parabolic peak interpolation, batCallDetector.js:3010-3034
+ * -- and the lowest and highest bin above (peak - 12 dB), the vertical-click filter's "instantaneous bandwidth"
+ * (js:3059-3088).  What the batched region analysis (sono_analyze_rois) keeps of every analysis frame.  form 0: a dB
+ * matrix in engine scratch, then a pass over it; 1: one pass, the dB values staying in registers (num_bins <= 512; the
+ * form the region analysis uses).  Same records from both. */
+typedef struct sono_frame_peak {
+    int32_t bin;                    /* -1: the row holds no value above -infinity */
+    float db, left_db, right_db;
+    int32_t lo12_bin, hi12_bin;     /* -1: none */
+} sono_frame_peak;
+int sono_detect_frame_peaks_dev(sono_engine *e, const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin,
+                                uint32_t num_bins, sono_frame_peak *d_out, int form, void *hip_stream);
 /* Maximal runs of non-zero flags, in increasing order: run i covers frames
  * d_first[i] .. d_last[i] (both arrays need `frames/2 + 1` entries), *d_count runs.
  * Synchronises the stream (it sizes a temporary from the result). */

@@ -221,6 +221,8 @@ _SIGNATURES = {
                                               C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sono_detect_power_db_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                            C.c_void_p, C.c_void_p]),
+    "sono_detect_frame_peaks_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_void_p, C.c_int, C.c_void_p]),
     "sono_detect_db_max_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "sono_detect_db_active_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_double, C.c_void_p,
                                             C.c_void_p]),

@@ -2,6 +2,8 @@
 // the array passes of modules/batCallDetector.js that follow the STFT.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -68,6 +70,27 @@ int sono_detect_power_db_dev(sono_engine *e, const float *d_mags, size_t frames,
     if ((uint64_t)min_bin + num_bins > bins) return fail(SONO_EINVAL, "sono_detect_power_db_dev: band exceeds the bins");
     DeviceGuard guard(e->device);
     HIP_TRY(sono::launch_power_db(d_mags, frames, bins, min_bin, num_bins, e->N, d_db, pick(e, hip_stream)));
+    return SONO_OK;
+}
+
+int sono_detect_frame_peaks_dev(sono_engine *e, const float *d_mags, size_t frames, uint32_t bins, uint32_t min_bin,
+                                uint32_t num_bins, sono_frame_peak *d_out, int form, void *hip_stream)
+{
+    static_assert(sizeof(sono_frame_peak) == sizeof(sono::FramePeak) && offsetof(sono_frame_peak, db) == offsetof(sono::FramePeak, db) &&
+                      offsetof(sono_frame_peak, lo12_bin) == offsetof(sono::FramePeak, lo12), "the record of the kernels is the record of the header");
+    if (!e || (frames && (!d_mags || !d_out))) return fail(SONO_EINVAL, "sono_detect_frame_peaks_dev: NULL argument");
+    if (num_bins == 0 || (uint64_t)min_bin + num_bins > bins) return fail(SONO_EINVAL, "sono_detect_frame_peaks_dev: band exceeds the bins");
+    if (form != 0 && form != 1) return fail(SONO_EINVAL, "sono_detect_frame_peaks_dev: form must be 0 or 1");
+    if (form != 0 && !sono::db_peaks_fits(num_bins)) return fail(SONO_EINVAL, "sono_detect_frame_peaks_dev: the one-pass form takes bands of up to 512 bins");
+    DeviceGuard guard(e->device);
+    hipStream_t s = pick(e, hip_stream);
+    if (form == 0) {
+        HIP_TRY(e->d_db.reserve((frames ? frames : 1) * (size_t)num_bins * sizeof(float)));
+        HIP_TRY(sono::launch_power_db(d_mags, frames, bins, min_bin, num_bins, e->N, (float *)e->d_db.p, s));
+        HIP_TRY(sono::launch_frame_peaks((const float *)e->d_db.p, frames, num_bins, (sono::FramePeak *)d_out, s));
+    } else {
+        HIP_TRY(sono::launch_db_peaks(d_mags, frames, bins, min_bin, num_bins, e->N, (sono::FramePeak *)d_out, s));
+    }
     return SONO_OK;
 }
 

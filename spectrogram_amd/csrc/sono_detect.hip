@@ -297,17 +297,11 @@ __global__ __launch_bounds__(kThreads) void frame_peaks_kernel(const float *db, 
 // frame_peaks_kernel on the dB values of a magnitude row that never leave the registers: power_db_kernel and
 // frame_peaks_kernel in one pass for rows of up to 64 * kRowRegs bins, when nobody else needs the dB matrix (the region
 // analysis: 2.5 KB of traffic per frame less).  Same values, same record.
-// One row's record; every lane of the wave returns the same one.
-template <typename ToDb>
-__device__ __forceinline__ FramePeak db_peaks_row(const float *src, uint32_t nb, int lane, ToDb &&to_db)
+//
+// db_peaks_plain: the record from the dB values v[k] of the row's bins lane + 64 k (NaN beyond the row); every lane of
+// the wave returns the same record.
+__device__ __forceinline__ FramePeak db_peaks_plain(const float (&v)[kRowRegs], uint32_t nb)
 {
-    float v[kRowRegs];
-    load_row(src, nb, lane, 0.0f, v);
-#pragma unroll
-    for (int k = 0; k < kRowRegs; ++k) {
-        if (64u * k < nb) v[k] = to_db(v[k]);                                // a chunk of 64 bins that the band reaches: all lanes or none
-        if ((uint32_t)lane + 64u * k >= nb) v[k] = NAN;
-    }
     // The row's maximum by one reduction over the lanes, then every question about positions by ballots: which
     // lanes hold the maximum (the first of them is the peak bin), which lie above peak - 12 dB (the first and the
     // last of them are the extent).  A ballot answers for 64 bins at once and its answer is the same in every lane,
@@ -352,6 +346,20 @@ __device__ __forceinline__ FramePeak db_peaks_row(const float *src, uint32_t nb,
     r.left = best_bin > 0 ? value_at(best_bin - 1) : NAN;
     r.right = best_bin >= 0 && (uint32_t)best_bin + 1 < nb ? value_at(best_bin + 1) : NAN;
     return r;
+}
+
+// One row's record from its magnitudes at src: every bin of the band converted.
+template <typename ToDb>
+__device__ __forceinline__ FramePeak db_peaks_row(const float *src, uint32_t nb, int lane, ToDb &&to_db)
+{
+    float v[kRowRegs];
+    load_row(src, nb, lane, 0.0f, v);
+#pragma unroll
+    for (int k = 0; k < kRowRegs; ++k) {
+        if (64u * k < nb) v[k] = to_db(v[k]);                                // a chunk of 64 bins that the band reaches: all lanes or none
+        if ((uint32_t)lane + 64u * k >= nb) v[k] = NAN;
+    }
+    return db_peaks_plain(v, nb);
 }
 
 __global__ __launch_bounds__(kThreads) void db_peaks_kernel(const float *mags, size_t frames, uint32_t bins, uint32_t min_bin,

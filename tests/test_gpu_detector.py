@@ -187,3 +187,71 @@ def test_db_matrix_is_the_library_logarithm_rounded_to_f32():
     assert not (differ & ~ambiguous).any(), np.argwhere(differ & ~ambiguous)[:5]
     assert differ.sum() <= 4 and (got[2, 3:13] == -160.0).all() and np.isinf(got[3, 3:13]).all() and (got[0] == -160.0).all()
     e.free()
+
+
+@pytest.mark.parametrize("min_bin,nb", [(26, 316), (0, 512), (3, 64), (100, 65), (5, 1)])
+def test_frame_peak_records_equal_in_both_forms(min_bin, nb):
+    """sono_detect_frame_peaks_dev: the dB matrix + row pass (form 0) and the one-pass form the region analysis uses (1)
+    leave the same records, bit for bit, on rows built around the places where the two could part: exact ties and
+    near-ties of the largest magnitude (neighbouring floats, which round to one dB value: the first bin wins),
+    magnitudes on both sides of 10^(-12/20) of the largest one float apart, peaks at the ends of a chunk of 64 bins and
+    of the band, quiet rows down to the floor of the dB law, all-zero rows, and rows that hold a NaN, an infinity or a
+    negative number."""
+    import torch
+    bins, N = 512, 1024
+    rng = np.random.default_rng(nb * 1000 + min_bin)
+    rows = []
+
+    def noise(scale=1e-3):
+        return (rng.rayleigh(scale, bins)).astype(np.float32)
+
+    spots = sorted({0, 1, nb // 2, nb - 1, min(63, nb - 1), min(64, nb - 1), min(65, nb - 1), min(127, nb - 1), min(128, nb - 1)})
+    for b in spots:                                             # a clear peak at the ends of chunks and of the band
+        r = noise(); r[min_bin + b] = 0.3; rows.append(r)
+    for b in spots:                                             # exact ties with a later bin, near-ties one to 40 floats below
+        for ulps in (0, 1, 2, 3, 5, 8, 13, 40):
+            r = noise(); r[min_bin + b] = 0.25
+            other = min_bin + (b + 7) % nb
+            r[other] = np.float32(0.25) if ulps == 0 else np.nextafter(np.float32(0.25), np.float32(0), dtype=np.float32) - np.float32((ulps - 1) * 2.0 ** -26)
+            rows.append(r)
+    ratio = np.float32(10.0 ** (-12.0 / 20.0))
+    for top in (0.5, 0.123456, 3.3e-3):                         # magnitudes around peak - 12 dB, float by float
+        edge = np.float32(np.float32(top) * ratio)
+        for k in range(-6, 7):
+            r = noise(1e-6); r[min_bin + nb // 3] = np.float32(top)
+            v = edge
+            for _ in range(abs(k)):
+                v = np.nextafter(v, np.float32(1.0 if k > 0 else 0.0), dtype=np.float32)
+            r[min_bin + (nb // 3 + 70) % nb] = v
+            r[min_bin + (nb // 3 + 5) % nb] = v if nb > 8 else r[min_bin + (nb // 3 + 5) % nb]
+            rows.append(r)
+    for scale in (1e-5, 1e-6, 3e-7, 1e-7, 3e-8, 1e-8, 1e-9, 1e-12):   # quiet rows: the floor of the law comes within 12 dB of the peak
+        rows.append(noise(scale)); r = noise(scale); r[min_bin + nb // 2] = np.float32(scale * 8); rows.append(r)
+    rows.append(np.zeros(bins, np.float32))
+    for bad in (np.nan, np.inf, -1.0):
+        r = noise(); r[min_bin + nb // 2] = 0.2; r[min_bin + (nb // 2 + 3) % nb] = np.float32(bad); rows.append(r)
+        r = noise(); r[min_bin + nb // 2] = np.float32(bad); rows.append(r)
+    for _ in range(4000):                                       # and plain rows, with and without a tone
+        r = noise(10.0 ** rng.uniform(-5, -1))
+        if rng.random() < 0.7:
+            r[min_bin + rng.integers(0, nb)] = np.float32(10.0 ** rng.uniform(-4, 0))
+        rows.append(r)
+    mags = torch.from_numpy(np.stack(rows)).cuda()
+    F = mags.shape[0]
+    e = sa.SpectrogramEngine(N, "hann")
+    rec = np.dtype([("bin", "<i4"), ("db", "<f4"), ("left", "<f4"), ("right", "<f4"), ("lo", "<i4"), ("hi", "<i4")])
+    got = []
+    for form in (0, 1):
+        out = torch.zeros(F * 6, dtype=torch.int32, device="cuda")
+        sa._check(sa.lib().sono_detect_frame_peaks_dev(e._handle(), mags.data_ptr(), F, bins, min_bin, nb, out.data_ptr(), form, None))
+        torch.cuda.synchronize()
+        got.append(out.cpu().numpy().view(rec))
+    for form in (1,):
+        same = got[form].view(np.int32).reshape(F, 6) == got[0].view(np.int32).reshape(F, 6)
+        bad_rows = np.flatnonzero(~same.all(axis=1))
+        assert bad_rows.size == 0, (form, bad_rows[:5], got[form][bad_rows[:3]], got[0][bad_rows[:3]])
+    # the records mean what they say: the peak is the first largest dB value of the row
+    db = 10 * np.log10(np.maximum(mags.cpu().numpy()[:, min_bin:min_bin + nb].astype(np.float64) ** 2 / N, 1e-16))
+    clean = np.isfinite(db).all(axis=1)
+    assert np.abs(got[1]["db"][clean] - np.nanmax(db[clean], axis=1)).max() < 1e-4
+    e.free()
