@@ -2,6 +2,7 @@
 """Copies what one profiling call on the GPU box left under gpurun_out/ into profiles/ (the round's cfg2 counters and
 trace summary, the workloads' bench lines, the whole-file detection's kernel table and counters).
 
+  gpurun --timeout 1200 -- 'bash tools/profile_all.sh'      (on the GPU box)
   python tools/keep_profiles.py r03
 """
 import csv
