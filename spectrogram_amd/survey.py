@@ -66,7 +66,7 @@ def _settings_key(sample_rate, flow_khz, fhigh_khz, options, config):
 
 
 def detect_units(units, sample_rate, flow_khz=10.0, fhigh_khz=128.0, options=None, config=None, rank=0, world=1,
-                 engine=None, threads=0, shard_dir=None, detect=None):
+                 engine=None, threads=0, shard_dir=None, detect=None, in_flight=1):
     """This rank's share of `units` = [(file_id, channel, samples or a callable returning them[, length])]: the
     reference's whole-file detection on each, calls as float64 rows in sharding.COLUMNS order (file, channel, then the
     table's numeric columns).  Units keep their order within the rank.
@@ -80,12 +80,18 @@ def detect_units(units, sample_rate, flow_khz=10.0, fhigh_khz=128.0, options=Non
     temporary name and renamed), and a unit whose shard exists is read back instead of detected again: a survey that
     was killed is started again with the same arguments and skips what it had finished.
 
+    in_flight: units worked on side by side on this rank's GPU, each on a thread and an engine of its own (the library
+    calls leave the interpreter lock).  A short recording's detection is a chain of small launches and waits -- 3 ms
+    for five seconds of audio, of which the GPU is busy for a fraction -- so a survey of many short files gains from
+    several in flight; hour-long recordings fill the card and the link on their own.  Same table, same order.
+
     detect: the per-unit detector, (engine, samples, file_id, channel) -> rows; default the library's whole-file
     detection.  (The CPU tests of the sharding logic pass a stand-in.)"""
     import os
+    import threading
     from . import SonoError, measure as _ms
     own = engine is None and detect is None
-    e = SpectrogramEngine(ANALYSIS_FFT, ANALYSIS_WINDOW) if own else engine
+    default_detect = detect is None
     if detect is None:
         def detect(eng, x, file_id, channel):
             return framing.process_full_file_table(eng, x, sample_rate, flow_khz, fhigh_khz, options, config, threads=threads,
@@ -93,51 +99,93 @@ def detect_units(units, sample_rate, flow_khz=10.0, fhigh_khz=128.0, options=Non
     key = _settings_key(sample_rate, flow_khz, fhigh_khz, options, config)
     if shard_dir:
         os.makedirs(shard_dir, exist_ok=True)
-    rows, rejected = [], []
     empty = np.zeros((0, len(sharding.COLUMNS)), np.float64)
-    try:
-        for i in units_of_rank(units, rank, world):
-            file_id, channel, unit = units[i][0], units[i][1], units[i][2]
-            path = _shard_path(shard_dir, key, file_id, channel) if shard_dir else None
-            if path and os.path.exists(path):
-                with np.load(path, allow_pickle=False) as z:
-                    code, msg, r = int(z["code"]), str(z["message"]), z["rows"]
-                if code:
-                    rejected.append((file_id, channel, code, msg))
-                else:
-                    rows.append(r)
-                continue
-            code, msg, r = 0, "", empty
+    mine = list(units_of_rank(units, rank, world))
+
+    def one_unit(e, i):
+        """-> (code, message, rows) of unit i, its shard written or read."""
+        file_id, channel, unit = units[i][0], units[i][1], units[i][2]
+        path = _shard_path(shard_dir, key, file_id, channel) if shard_dir else None
+        if path and os.path.exists(path):
+            with np.load(path, allow_pickle=False) as z:
+                return int(z["code"]), str(z["message"]), z["rows"]
+        code, msg, r = 0, "", empty
+        try:
+            x = _samples(unit)
+        except Exception as err:          # noqa: BLE001 -- whatever a caller's loader raises stays with this unit
+            code, msg = REJECT_LOAD_FAILED, f"{type(err).__name__}: {err}"
+        if not code:
             try:
-                x = _samples(unit)
-            except Exception as err:          # noqa: BLE001 -- whatever a caller's loader raises stays with this unit
-                code, msg = REJECT_LOAD_FAILED, f"{type(err).__name__}: {err}"
-            if not code:
-                try:
-                    r = np.asarray(detect(e, x, file_id, channel), np.float64).reshape(-1, len(sharding.COLUMNS))
-                except _ms.ReferenceThrows as err:
-                    code, msg = REJECT_REFERENCE_THROWS, str(err)
-                except (SonoError, MemoryError, ValueError, RuntimeError) as err:
-                    code, msg = REJECT_DETECTION_FAILED, f"{type(err).__name__}: {err}"
-            if code:
-                rejected.append((file_id, channel, code, msg))
-                r = empty
-            else:
-                rows.append(r)
-            if path:
-                tmp = path + f".tmp{os.getpid()}"
-                with open(tmp, "wb") as fh:
-                    np.savez(fh, rows=r, code=np.int64(code), message=np.str_(msg))
-                os.replace(tmp, path)
-    finally:
-        if own and e is not None:
-            e.free()
+                r = np.asarray(detect(e, x, file_id, channel), np.float64).reshape(-1, len(sharding.COLUMNS))
+            except _ms.ReferenceThrows as err:
+                code, msg = REJECT_REFERENCE_THROWS, str(err)
+            except (SonoError, MemoryError, ValueError, RuntimeError) as err:
+                code, msg = REJECT_DETECTION_FAILED, f"{type(err).__name__}: {err}"
+        if code:
+            r = empty
+        if path:
+            tmp = path + f".tmp{os.getpid()}_{threading.get_ident()}"
+            with open(tmp, "wb") as fh:
+                np.savez(fh, rows=r, code=np.int64(code), message=np.str_(msg))
+            os.replace(tmp, path)
+        return code, msg, r
+
+    workers = max(1, min(int(in_flight), len(mine)))
+    if engine is not None and default_detect:
+        workers = 1                           # one engine, one call at a time
+    results = [None] * len(mine)
+    if workers == 1:
+        e = SpectrogramEngine(ANALYSIS_FFT, ANALYSIS_WINDOW) if own else engine
+        try:
+            for k, i in enumerate(mine):
+                results[k] = one_unit(e, i)
+        finally:
+            if own and e is not None:
+                e.free()
+    else:
+        # the threads draw the rank's units in order; what cannot be contained in a unit (an engine that cannot be
+        # created, an exception outside the ones above) ends the survey on this rank like it does with one thread
+        lock, state = threading.Lock(), {"next": 0, "fatal": None}
+
+        def work():
+            e = None
+            try:
+                e = SpectrogramEngine(ANALYSIS_FFT, ANALYSIS_WINDOW) if default_detect else engine
+                while True:
+                    with lock:
+                        k = state["next"]
+                        if k >= len(mine) or state["fatal"] is not None:
+                            return
+                        state["next"] = k + 1
+                    results[k] = one_unit(e, mine[k])
+            except BaseException as err:      # noqa: BLE001 -- raised again on the calling thread below
+                with lock:
+                    if state["fatal"] is None:
+                        state["fatal"] = err
+            finally:
+                if default_detect and e is not None:
+                    e.free()
+
+        pool = [threading.Thread(target=work) for _ in range(workers)]
+        for t in pool:
+            t.start()
+        for t in pool:
+            t.join()
+        if state["fatal"] is not None:
+            raise state["fatal"]
+    rows, rejected = [], []
+    for k, i in enumerate(mine):
+        code, msg, r = results[k]
+        if code:
+            rejected.append((units[i][0], units[i][1], code, msg))
+        else:
+            rows.append(r)
     table = np.concatenate(rows, axis=0) if rows else empty
     return table, rejected
 
 
 def run_auto_detection(units, sample_rate, flow_khz=10.0, fhigh_khz=128.0, options=None, config=None, engine=None,
-                       collective_device=None, threads=0, shard_dir=None, detect=None):
+                       collective_device=None, threads=0, shard_dir=None, detect=None, in_flight=1):
     """detect_units on this process's rank of the initialised torch.distributed group (or on everything when there
     is none), then the gathered call-summary table, identical on every rank and ordered by (file, channel, start), and
     the gathered list of rejected units [(file, channel, REJECT_* code)], identical on every rank and ordered alike
@@ -157,7 +205,7 @@ def run_auto_detection(units, sample_rate, flow_khz=10.0, fhigh_khz=128.0, optio
     rows, rejected, fatal = None, [], None
     try:
         rows, rejected = detect_units(units, sample_rate, flow_khz, fhigh_khz, options, config, rank, world, engine, threads,
-                                      shard_dir, detect)
+                                      shard_dir, detect, in_flight)
     except Exception as err:                  # noqa: BLE001 -- reported to every rank below, then raised
         fatal = err
     bad_rank = sharding.agree_on_failure(fatal is not None, device=collective_device)

@@ -64,3 +64,20 @@ def test_a_failing_unit_is_contained_and_every_rank_learns_of_it(tmp_path):
         assert np.array_equal(np.load(tmp_path / f"table_w2_r{r}_bad.npy"), good, equal_nan=True)
         rej = np.load(tmp_path / f"rejected_w2_r{r}.npy")
         assert rej.tolist() == [[7, 0, survey.REJECT_LOAD_FAILED]]
+
+
+def test_short_recordings_in_flight_give_the_table_of_one_at_a_time():
+    """Twenty-four recordings of two to five seconds through survey.detect_units one at a time and four at a time (a
+    thread and an engine each): the same rows in the same order."""
+    import time
+    from spectrogram_amd import survey, synth
+    sr = 384000
+    units = [(i, 0, synth.chirp_numpy(0, int((2 + i % 4) * sr), sr, stream=i)) for i in range(24)]
+    t0 = time.perf_counter()
+    one, rej1 = survey.detect_units(units, sr, config={"debugMode": True})
+    t1 = time.perf_counter()
+    four, rej4 = survey.detect_units(units, sr, config={"debugMode": True}, in_flight=4)
+    t2 = time.perf_counter()
+    print(f"one at a time {1e3 * (t1 - t0):.1f} ms, four in flight {1e3 * (t2 - t1):.1f} ms, {one.shape[0]} calls")
+    assert one.shape[0] > 24 * 15 and rej1 == rej4 == []
+    assert np.array_equal(one.view(np.uint64), four.view(np.uint64))

@@ -194,3 +194,28 @@ def test_finished_units_are_read_back_from_their_shards(tmp_path):
     # other settings are other shards
     survey.detect_units(_fake_units()[:1], 384000, flow_khz=20.0, detect=counting, shard_dir=str(tmp_path))
     assert calls == [0]
+
+
+def test_units_in_flight_give_the_table_of_one_at_a_time(tmp_path):
+    """in_flight > 1: the rank's units on several threads, the same rows in the same order, failures contained and named
+    alike, shards written alike; something no unit can contain ends the survey as it does with one thread."""
+    import threading
+    import time
+    from spectrogram_amd import survey
+    seen = set()
+
+    def slow_first(engine, x, file_id, channel):                     # the first units finish last
+        seen.add(threading.get_ident())
+        time.sleep(0.05 if file_id < 2 else 0.0)
+        return _fake_detect(engine, x, file_id, channel)
+    one = survey.detect_units(_fake_units(), 384000, detect=_fake_detect)
+    many = survey.detect_units(_fake_units(), 384000, detect=slow_first, in_flight=3, shard_dir=str(tmp_path))
+    assert np.array_equal(one[0], many[0], equal_nan=True) and one[1] == many[1]
+    assert len(seen) > 1 and len(list(tmp_path.glob("unit_*.npz"))) == 7 and not list(tmp_path.glob("*.tmp*"))
+
+    def fatal(engine, x, file_id, channel):
+        if file_id == 3:
+            raise KeyError("this rank has lost its device")
+        return _fake_detect(engine, x, file_id, channel)
+    with pytest.raises(KeyError):
+        survey.detect_units(_fake_units(), 384000, detect=fatal, in_flight=3)
