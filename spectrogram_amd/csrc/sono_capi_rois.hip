@@ -1189,11 +1189,17 @@ struct TailPipeline {
     static constexpr unsigned int kSets = kAnalysers + 2;    // sets of tables: being analysed, being framed, being measured
     std::vector<std::unique_ptr<Tail>> tails;        // in the groups' order; ended ones stay (their rc is read at the end)
     std::atomic<long long> us{0};                    // the threads' own time in their stages, beside whatever else went on
+    size_t joined = 0;                               // tails before this one have been joined
     using Stage = std::function<int(GroupTail &)>;
     using Analysis = std::function<int(GroupTail &, unsigned int k)>;      // k: the group's number (engine k % kAnalysers, set k % kSets)
     void start(std::unique_ptr<GroupTail> g, Analysis analyse, Stage frame, Stage measure)
     {
         const size_t k = tails.size();
+        for (size_t j = joined; j < k; ++j) {                // groups that have ended give their threads back (in order: they end in order)
+            { std::lock_guard<std::mutex> l(tails[j]->m); if (!tails[j]->ended) break; }
+            if (tails[j]->worker.joinable()) tails[j]->worker.join();
+            joined = j + 1;
+        }
         Tail *prev = k ? tails[k - 1].get() : nullptr, *owner = k >= kSets ? tails[k - kSets].get() : nullptr;
         Tail *before = k >= kAnalysers ? tails[k - kAnalysers].get() : nullptr;      // the group that had this group's analysing engine
         tails.emplace_back(new Tail());
